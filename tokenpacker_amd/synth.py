@@ -1,0 +1,105 @@
+"""Deterministic synthetic CLIP features and projector parameters.
+
+Used by the tests, ``bench.py``, ``oracle/make_golden.py`` and ``__graft_entry__.smoke()`` so that
+every leg (reference module, oracle, HIP path) sees bit-identical inputs.  Everything is generated
+on the CPU from an explicit ``torch.Generator`` — nothing here touches the GPU or the oracle.
+
+Shapes follow SURVEY.md §8(d): ``x`` is the select-layer CLIP grid ``[B, 576, 1024]`` and
+``x_multi`` the four concatenated layers ``[B, 576, 4096]`` that
+``CLIPVisionTower.forward`` returns (reference ``llava/model/multimodal_encoder/clip_encoder.py:28-44,62``).
+"""
+from __future__ import annotations
+
+import hashlib
+from collections import OrderedDict
+
+import torch
+
+RAW_GRID = 24          # CLIP-L/14 @ 336 px
+N_TOKENS = RAW_GRID * RAW_GRID
+C_CLIP = 1024          # CLIP width == embed_dim == kv_dim
+C_MULTI = 4096         # 4 CLIP layers concatenated
+N_HEADS = 8
+
+
+def param_shapes(hidden_size: int) -> "OrderedDict[str, tuple]":
+    """State-dict names/shapes of the projector, in the reference's registration order
+    (reference ``llava/model/multimodal_projector/builder.py:40-85``)."""
+    D = hidden_size
+    E = C_CLIP
+    return OrderedDict([
+        ("q_proj_1.weight", (E, E)),
+        ("k_proj_1.0.weight", (E, C_MULTI)), ("k_proj_1.0.bias", (E,)),
+        ("k_proj_1.2.weight", (E, E)), ("k_proj_1.2.bias", (E,)),
+        ("v_proj_1.0.weight", (E, C_MULTI)), ("v_proj_1.0.bias", (E,)),
+        ("v_proj_1.2.weight", (E, E)), ("v_proj_1.2.bias", (E,)),
+        ("ln_q_1.weight", (E,)), ("ln_q_1.bias", (E,)),
+        ("ln_k_1.weight", (E,)), ("ln_k_1.bias", (E,)),
+        ("ln_v_1.weight", (E,)), ("ln_v_1.bias", (E,)),
+        ("clip_attn.in_proj_weight", (3 * E, E)), ("clip_attn.in_proj_bias", (3 * E,)),
+        ("clip_attn.out_proj.weight", (E, E)), ("clip_attn.out_proj.bias", (E,)),
+        ("mlp.0.weight", (D, E)), ("mlp.0.bias", (D,)),
+        ("mlp.2.weight", (D, D)), ("mlp.2.bias", (D,)),
+    ])
+
+
+def make_params(seed: int, hidden_size: int = 4096, dtype=torch.float32) -> "OrderedDict[str, torch.Tensor]":
+    """Non-trivial parameters: the reference's default init has zero biases and unit LayerNorm
+    affine, which would hide bias / affine bugs.
+
+    Linear weights ~ N(0, 1/fan_in) * 1.5 so activations stay O(1) through the chain (the
+    reference's trunc_normal(std=.02) gives tiny pre-LN activations; LN rescales them anyway),
+    biases ~ N(0, 0.1), LN gamma ~ 1 + N(0, 0.1), LN beta ~ N(0, 0.1).
+    """
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    out = OrderedDict()
+    for name, shape in param_shapes(hidden_size).items():
+        if name.startswith("ln_") and name.endswith(".weight"):
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif name.endswith("bias"):
+            t = 0.1 * torch.randn(shape, generator=g)
+        else:
+            fan_in = shape[1]
+            t = torch.randn(shape, generator=g) * (1.5 / fan_in ** 0.5)
+        out[name] = t.to(dtype)
+    return out
+
+
+def make_inputs(seed: int, B: int, dtype=torch.float32, layout: str = "contiguous",
+                tie_select_layer: bool = False):
+    """Synthetic ``(x, x_multi)``.
+
+    layout="contiguous": plain ``[B,576,C]`` tensors (eval path: fp16 tower -> bf16 cast copies).
+    layout="tower": both are ``[:, 1:]`` slices of CLS-prefixed ``[B,577,C]`` buffers, i.e. the
+    non-contiguous view the tower hands over when tower dtype == image dtype
+    (reference ``clip_encoder.py:37-38,62``; SURVEY.md §7 "hard parts").
+    tie_select_layer: x == x_multi[..., 3072:] as with ``mm_vision_select_layer=-2``.
+    The VALUES do not depend on ``layout``.
+    """
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    xm = torch.randn(B, N_TOKENS, C_MULTI, generator=g)
+    x = torch.randn(B, N_TOKENS, C_CLIP, generator=g)
+    if tie_select_layer:
+        x = xm[..., C_MULTI - C_CLIP:].clone()
+    x = x.to(dtype)
+    xm = xm.to(dtype)
+    if layout == "tower":
+        xb = torch.zeros(B, N_TOKENS + 1, C_CLIP, dtype=dtype)
+        xmb = torch.zeros(B, N_TOKENS + 1, C_MULTI, dtype=dtype)
+        xb[:, 1:] = x
+        xmb[:, 1:] = xm
+        x, xm = xb[:, 1:], xmb[:, 1:]
+    elif layout != "contiguous":
+        raise ValueError(f"unknown layout {layout!r}")
+    return x, xm
+
+
+def tensor_digest(*tensors: torch.Tensor) -> str:
+    """sha256 over the raw bytes (after .contiguous()); pins RNG streams in the golden files."""
+    h = hashlib.sha256()
+    for t in tensors:
+        t = t.detach().contiguous().cpu()
+        h.update(str(t.dtype).encode())
+        h.update(str(tuple(t.shape)).encode())
+        h.update(t.view(torch.uint8).numpy().tobytes())
+    return h.hexdigest()
