@@ -1,0 +1,204 @@
+/*
+ * tokenpacker.h — C ABI of libtokenpacker_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for ONE hot path: the TokenPacker region-to-point visual projector of
+ * CircleRadon/TokenPacker, reference `llava/model/multimodal_projector/builder.py:39-137`
+ * (class TokenPacker; called from `llava/model/llava_arch.py:97`).  The reference has no FFI of
+ * its own (it is 100 % eager PyTorch); the entry points below are what a binding for this path
+ * has to offer, and each one names the reference code it replaces.  The Python side
+ * (`tokenpacker_amd/_capi.py`) binds them with ctypes; INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *  - Plain C types only: device pointers, sizes, element strides, an opaque stream handle
+ *    (`hipStream_t` passed as `void*`; NULL = the legacy default stream).
+ *  - The caller owns every buffer.  The library allocates nothing on the device, keeps no global
+ *    mutable state except a thread-local error string and the tuning table of tp_set_tuning().
+ *  - Every call only ENQUEUES work on `stream`; it never synchronises the device.
+ *  - Return value: 0 on success, a negative tp_status otherwise; tp_last_error() describes the
+ *    failure for the calling thread.  Nothing throws across the ABI.
+ *  - All tensors are row-major.  `dtype` is the element type of activations AND weights.
+ */
+#ifndef TOKENPACKER_H_
+#define TOKENPACKER_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TP_ABI_VERSION 1
+
+typedef enum tp_status {
+    TP_OK = 0,
+    TP_ERR_INVALID_ARG = -1,   /* NULL pointer, bad shape, unsupported dtype ...                  */
+    TP_ERR_BAD_SCALE = -2,     /* raw_grid % scale_factor != 0 (reference builder.py:51-52)       */
+    TP_ERR_WORKSPACE = -3,     /* workspace / packed buffer too small                             */
+    TP_ERR_LAUNCH = -4         /* HIP reported an error when enqueueing                           */
+} tp_status;
+
+typedef enum tp_dtype {
+    TP_BF16 = 0,
+    TP_F16 = 1,
+    TP_F32 = 2                 /* only valid as tp_desc.out_dtype (fp32-output validation mode)   */
+} tp_dtype;
+
+/* Problem descriptor.  Mirrors the constructor arguments of the reference module
+ * (builder.py:40-49: raw_grid=24, embed_dim=1024, num_heads=8, kv_dim=1024, hidden_size,
+ * scale_factor) plus the batch.  embed_dim / kv_dim / the 4096-wide multi-level input are fixed
+ * by the reference (builder.py:61,67 hard-code nn.Linear(4096,1024)). */
+typedef struct tp_desc {
+    int32_t batch;         /* B: images or HD crops                                               */
+    int32_t raw_grid;      /* g: 24 for CLIP-L/14 @ 336 px; tokens per image N = g*g              */
+    int32_t scale_factor;  /* s: must divide raw_grid; M = (g/s)^2 coarse queries                 */
+    int32_t hidden_size;   /* D: LLM width (multiple of 128)                                      */
+    int32_t dtype;         /* tp_dtype of x, x_multi and all weights: TP_BF16 or TP_F16           */
+    int32_t out_dtype;     /* tp_dtype of `out`: == dtype, or TP_F32                              */
+    float   ln_eps;        /* 1e-6 (builder.py:48)                                                */
+    int32_t reserved;      /* must be 0                                                           */
+} tp_desc;
+
+/* The 23 tensors of the reference state dict, all of element type desc.dtype,
+ * each contiguous, nn.Linear layout [out_features, in_features]. */
+typedef struct tp_weights {
+    const void* q_proj_1_weight;        /* [1024,1024]  builder.py:59 (no bias)                   */
+    const void* k_proj_1_0_weight;      /* [1024,4096]  builder.py:61                             */
+    const void* k_proj_1_0_bias;        /* [1024]                                                 */
+    const void* k_proj_1_2_weight;      /* [1024,1024]  builder.py:64                             */
+    const void* k_proj_1_2_bias;        /* [1024]                                                 */
+    const void* v_proj_1_0_weight;      /* [1024,4096]  builder.py:67                             */
+    const void* v_proj_1_0_bias;
+    const void* v_proj_1_2_weight;      /* [1024,1024]  builder.py:70                             */
+    const void* v_proj_1_2_bias;
+    const void* ln_q_1_weight;          /* [1024]       builder.py:73                             */
+    const void* ln_q_1_bias;
+    const void* ln_k_1_weight;          /* [1024]       builder.py:74                             */
+    const void* ln_k_1_bias;
+    const void* ln_v_1_weight;          /* [1024]       builder.py:75                             */
+    const void* ln_v_1_bias;
+    const void* clip_attn_in_proj_weight;   /* [3072,1024]  builder.py:77 (q,k,v stacked)         */
+    const void* clip_attn_in_proj_bias;     /* [3072]                                             */
+    const void* clip_attn_out_proj_weight;  /* [1024,1024]                                        */
+    const void* clip_attn_out_proj_bias;    /* [1024]                                             */
+    const void* mlp_0_weight;           /* [D,1024]     builder.py:79                             */
+    const void* mlp_0_bias;             /* [D]                                                    */
+    const void* mlp_2_weight;           /* [D,D]        builder.py:82                             */
+    const void* mlp_2_bias;             /* [D]                                                    */
+} tp_weights;
+
+/* ---- library info ---------------------------------------------------------------------------- */
+int         tp_version(void);                 /* == TP_ABI_VERSION                                 */
+const char* tp_last_error(void);              /* thread-local, never NULL                          */
+
+/* ---- sizes ----------------------------------------------------------------------------------- */
+/* Bytes of the packed-weight buffer for (hidden_size, dtype); 0 on invalid arguments. */
+size_t tp_packed_weight_bytes(const tp_desc* desc);
+/* Bytes of scratch tp_forward() needs for this descriptor (depends on batch); 0 on invalid args. */
+size_t tp_workspace_bytes(const tp_desc* desc);
+
+/* ---- one-time weight preparation -------------------------------------------------------------
+ * Replaces what `TokenPacker.__init__` + `load_state_dict` leave in the nn.Parameters
+ * (builder.py:59-83, llava_arch.py:78-83): re-lays the 23 tensors out for the kernels — K/V first
+ * layers concatenated into one [2048,4096] operand, the three LayerNorm affines folded into the
+ * attention in-projection (W' = W·diag(gamma), c = rowsum(W'), b' = W·beta + b), biases widened to
+ * fp32.  Must be re-run whenever a parameter changes.  `packed` needs tp_packed_weight_bytes(). */
+int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, size_t packed_bytes,
+                    void* stream);
+
+/* ---- the hot path ------------------------------------------------------------------------------
+ * Replaces `TokenPacker.forward((x, x_multi))` (builder.py:107-137).
+ *   x        [B, g*g, 1024]  element strides x_strides[3]  (innermost stride must be 1)
+ *   x_multi  [B, g*g, 4096]  element strides xm_strides[3] (innermost stride must be 1)
+ *            — strides because the CLIP tower hands over `[:, 1:]` slices of CLS-prefixed
+ *              buffers (clip_encoder.py:37-38,62); base pointers must be 16-byte aligned and row
+ *              strides multiples of 8 elements.
+ *   out      [B, M, D] contiguous, element type desc.out_dtype.
+ * `attn_mask` of the reference signature is always None on the real path (llava_arch.py:97) and is
+ * not part of this ABI. */
+int tp_forward(const tp_desc* desc,
+               const void* x, const int64_t x_strides[3],
+               const void* x_multi, const int64_t xm_strides[3],
+               const void* packed_weights,
+               void* out,
+               void* workspace, size_t workspace_bytes,
+               void* stream);
+
+/* Same as tp_forward, additionally recording caller-owned HIP events (hipEvent_t, created with
+ * timing enabled) on `stream` at the TP_NUM_STAGES+1 stage boundaries, so a benchmark can time each
+ * kernel of the schedule inside the real forward (bench.py's `roofline` object).  Stages, in order:
+ * point_queries, kv_layer0(+GELU), kv_layer2(+stats), kv_inproj(LN-fold), q_proj_1(+stats),
+ * q_inproj(LN-fold), region_attention, out_proj, mlp0(+GELU), mlp2. */
+#define TP_NUM_STAGES 10
+int tp_forward_staged(const tp_desc* desc,
+                      const void* x, const int64_t x_strides[3],
+                      const void* x_multi, const int64_t xm_strides[3],
+                      const void* packed_weights,
+                      void* out,
+                      void* workspace, size_t workspace_bytes,
+                      void* stream,
+                      void* const* stage_events, int n_events);
+
+/* ---- per-kernel entry points (used by the parity tests; same kernels tp_forward launches) ---- */
+
+/* Coarse point queries: fp32 bilinear (align_corners=False) g*g -> (g/s)^2, cast back to dtype.
+ * Replaces builder.py:117-118.  q0 is [B, M, 1024] contiguous. */
+int tp_point_queries(const tp_desc* desc, const void* x, const int64_t x_strides[3], void* q0,
+                     void* stream);
+
+/* Region-to-point attention core on projected tensors (post in-proj, pre out-proj):
+ *   q [B, M, 1024], k and v [B, g*g, 1024] contiguous; o [B, M, 1024].
+ * 8 heads x d=128, logits scaled by 1/sqrt(128), softmax over the s*s tokens of the query's own
+ * region.  Replaces divide_feature (builder.py:96-105, 122-124) + the bmm/softmax/bmm of
+ * nn.MultiheadAttention (builder.py:126-130; torch/nn/functional.py:6576-6594). */
+int tp_region_attention(const tp_desc* desc, const void* q, const void* k, const void* v, void* o,
+                        void* stream);
+
+/* Generic fused linear used for every dense contraction of the path (11 nn.Linear calls of
+ * builder.py:112,113,120,126-130,136):  C[M,N] = epilogue(A[M,K] · W[N,K]^T).
+ * flags: TP_LINEAR_* below.  `bias` fp32 [N] or NULL.  With TP_LINEAR_LN_FOLD the epilogue applies
+ * a LayerNorm that precedes the linear: C = rstd_m·(acc − mu_m·colsum_n) + bias_n, (mu, rstd) taken
+ * from `row_stats_in` = [stats_parts][M][2] partial (sum, sum of squares) over ln_dim columns.
+ * With TP_LINEAR_ROW_STATS the kernel writes such partials of ITS output to `row_stats_out`
+ * ([N/stats_tile_n][M][2]; query the tile with tp_linear_stats_parts()). */
+enum {
+    TP_LINEAR_GELU = 1,        /* exact erf GELU after bias (nn.GELU(), builder.py:63,69,81)      */
+    TP_LINEAR_LN_FOLD = 2,
+    TP_LINEAR_ROW_STATS = 4,
+    TP_LINEAR_OUT_F32 = 8
+};
+typedef struct tp_linear_args {
+    int32_t M, N, K;           /* N % 128 == 0, K % 64 == 0                                        */
+    int32_t dtype;             /* TP_BF16 / TP_F16                                                 */
+    int32_t flags;
+    int32_t rows_per_batch;    /* A row r lives at A + (r / rpb)*a_batch_stride + (r % rpb)*lda   */
+    int64_t a_batch_stride;    /* elements; ignored when rows_per_batch >= M                       */
+    int64_t lda;               /* elements between consecutive rows of A                           */
+    int64_t ldc;               /* elements between consecutive rows of C                           */
+    const void* A;
+    const void* W;             /* [N,K] contiguous                                                 */
+    const float* bias;
+    void* C;
+    const float* row_stats_in; /* LN_FOLD                                                          */
+    const float* colsum;       /* LN_FOLD: fp32 [N]                                                */
+    int32_t stats_parts;       /* LN_FOLD: number of partial slabs in row_stats_in                 */
+    int32_t ln_dim;            /* LN_FOLD: normalised width (1024)                                 */
+    float   ln_eps;
+    int32_t tile;              /* 0 = auto, 128 or 256: force the block tile                       */
+    float*  row_stats_out;     /* ROW_STATS                                                        */
+} tp_linear_args;
+int tp_linear(const tp_linear_args* args, void* stream);
+/* Number of row-stat slabs a TP_LINEAR_ROW_STATS call with these M,N (and args->tile) writes. */
+int tp_linear_stats_parts(const tp_linear_args* args);
+
+/* ---- tuning knobs (benchmarks only; defaults are what tp_forward ships with) ------------------ */
+enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto | 128 | 256                                              */
+       TP_TUNE_XCD_SWIZZLE = 1, /* 1 (default) | 0                                                 */
+       TP_TUNE_COUNT_ = 8 };
+int tp_set_tuning(int key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOKENPACKER_H_ */

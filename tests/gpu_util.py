@@ -1,0 +1,90 @@
+"""Helpers for the -m gpu parity tests: thin wrappers over the C ABI and failure diagnostics."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from tokenpacker_amd import _capi
+
+DT = {torch.bfloat16: _capi.TP_BF16, torch.float16: _capi.TP_F16}
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def linear(A, W, bias=None, flags=0, tile=0, rows_per_batch=0, a_batch_stride=0, lda=None, M=None,
+           stats_in=None, colsum=None, stats_parts=0, ln_dim=1024, ln_eps=1e-6, want_stats=False):
+    """C = epilogue(A · W^T) through tp_linear.  A may be a 2-D tensor or a raw (ptr-bearing) tensor
+    with explicit M / lda / batch strides."""
+    lib = _capi.load_library()
+    N, K = W.shape
+    if M is None:
+        M = A.shape[0]
+    if lda is None:
+        lda = A.stride(0)
+    out_f32 = bool(flags & _capi.TP_LINEAR_OUT_F32)
+    C = torch.empty(M, N, dtype=torch.float32 if out_f32 else W.dtype, device=W.device)
+    args = _capi.tp_linear_args()
+    args.M, args.N, args.K = M, N, K
+    args.dtype = DT[W.dtype]
+    args.flags = flags | (_capi.TP_LINEAR_ROW_STATS if want_stats else 0)
+    args.rows_per_batch = rows_per_batch
+    args.a_batch_stride = a_batch_stride
+    args.lda, args.ldc = lda, N
+    args.A, args.W, args.C = A.data_ptr(), W.data_ptr(), C.data_ptr()
+    args.bias = bias.data_ptr() if bias is not None else None
+    args.row_stats_in = stats_in.data_ptr() if stats_in is not None else None
+    args.colsum = colsum.data_ptr() if colsum is not None else None
+    args.stats_parts, args.ln_dim, args.ln_eps, args.tile = stats_parts, ln_dim, ln_eps, tile
+    stats = None
+    if want_stats:
+        parts = lib.tp_linear_stats_parts(ctypes.byref(args))
+        assert parts > 0
+        stats = torch.full((parts, M, 2), float("nan"), dtype=torch.float32, device=W.device)
+        args.row_stats_out = stats.data_ptr()
+    _capi.check(lib.tp_linear(ctypes.byref(args), stream_ptr()), "tp_linear")
+    torch.cuda.synchronize()
+    return (C, stats) if want_stats else C
+
+
+def describe_mismatch(got: torch.Tensor, want: torch.Tensor, name: str, tol: float) -> str:
+    """Human-readable map of WHERE a 2-D result is wrong (16x16 block granularity) so that a layout
+    bug can be diagnosed from one failed GPU run."""
+    got = got.detach().float().cpu()
+    want = want.detach().float().cpu()
+    if got.dim() > 2:
+        got = got.reshape(-1, got.shape[-1])
+        want = want.reshape(-1, want.shape[-1])
+    err = (got - want).abs()
+    scale = want.abs().max().item() + 1e-30
+    bad = err > tol * scale
+    lines = [f"[{name}] shape={tuple(got.shape)} max|err|={err.max().item():.4e} max|ref|={scale:.4e} "
+             f"rel={err.max().item() / scale:.4e} tol={tol:.1e} bad={bad.float().mean().item() * 100:.2f}% "
+             f"nan={torch.isnan(got).sum().item()}"]
+    if bad.any():
+        idx = torch.nonzero(bad)[:8]
+        for r, c in idx.tolist():
+            lines.append(f"   ({r},{c}): got {got[r, c].item():.6f} want {want[r, c].item():.6f}")
+        R, Cc = got.shape
+        rb = bad.float().reshape(-1).new_zeros(((R + 15) // 16, (Cc + 15) // 16))
+        rows = torch.nonzero(bad)[:, 0] // 16
+        cols = torch.nonzero(bad)[:, 1] // 16
+        rb.index_put_((rows, cols), torch.ones(rows.shape[0]), accumulate=True)
+        lines.append(f"   bad 16x16 blocks: {(rb > 0).sum().item()} of {rb.numel()}; "
+                     f"row-blocks hit {sorted(set(rows.tolist()))[:24]} col-blocks hit {sorted(set(cols.tolist()))[:24]}")
+        # transposition hint
+        if R == Cc:
+            lines.append(f"   rel err vs want^T: {((got - want.t()).abs().max() / scale).item():.3e}")
+    return "\n".join(lines)
+
+
+def assert_close(got, want, name, tol):
+    got_f = got.detach().float().cpu()
+    want_f = want.detach().float().cpu()
+    scale = want_f.abs().max().item() + 1e-30
+    err = (got_f - want_f).abs().max().item() / scale
+    ok = err <= tol and not torch.isnan(got_f).any()
+    assert ok, describe_mismatch(got, want, name, tol)
+    return err

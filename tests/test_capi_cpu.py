@@ -1,0 +1,78 @@
+"""C-ABI library: loads without a GPU, exports every symbol include/tokenpacker.h declares, and
+rejects bad descriptors before touching the device.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from tokenpacker_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "tokenpacker.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tp_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _capi.load_library()
+    declared = _header_symbols()
+    assert set(declared) == set(_capi.EXPORTED_SYMBOLS), declared
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/tokenpacker.h but not exported"
+    assert lib.tp_version() == _capi.TP_ABI_VERSION
+
+
+def test_struct_layouts_match_header():
+    # tp_desc: 6 x int32 + float + int32; tp_weights: 23 pointers
+    assert ctypes.sizeof(_capi.tp_desc) == 32
+    assert ctypes.sizeof(_capi.tp_weights) == 23 * ctypes.sizeof(ctypes.c_void_p)
+    assert len(_capi.WEIGHT_FIELDS) == 23
+    assert ctypes.sizeof(_capi.tp_linear_args) == 6 * 4 + 3 * 8 + 6 * 8 + 4 * 4 + 8
+
+
+def test_sizes_and_descriptor_validation():
+    lib = _capi.load_library()
+    d = _capi.make_desc(256, 24, 2, 4096, _capi.TP_BF16)
+    packed = lib.tp_packed_weight_bytes(ctypes.byref(d))
+    # 36,722,688 parameters in 2-byte elements, + fp32 biases/colsums, + alignment
+    assert 36_722_688 * 2 <= packed < 36_722_688 * 2 + 200_000
+    ws = lib.tp_workspace_bytes(ctypes.byref(d))
+    assert 1.5e9 < ws < 3.5e9
+    # bad scale factor: the reference's ValueError (builder.py:51-52)
+    bad = _capi.make_desc(1, 24, 5, 4096, _capi.TP_BF16)
+    assert lib.tp_workspace_bytes(ctypes.byref(bad)) == 0
+    assert "scale_factor must be divisible by grid size" in _capi.last_error()
+    with pytest.raises(ValueError, match="scale_factor must be divisible by grid size"):
+        _capi.check(_capi.TP_ERR_BAD_SCALE, "x")
+    for kw in (dict(batch=0), dict(hidden_size=100), dict(dtype=_capi.TP_F32), dict(out_dtype=7)):
+        args = dict(batch=1, raw_grid=24, scale_factor=2, hidden_size=4096, dtype=_capi.TP_BF16)
+        out_dtype = kw.pop("out_dtype", None)
+        args.update(kw)
+        dd = _capi.make_desc(args["batch"], args["raw_grid"], args["scale_factor"], args["hidden_size"],
+                             args["dtype"], out_dtype)
+        assert lib.tp_packed_weight_bytes(ctypes.byref(dd)) == 0, kw
+        assert _capi.last_error()
+
+
+def test_null_arguments_are_rejected_before_launch():
+    lib = _capi.load_library()
+    d = _capi.make_desc(1, 24, 2, 256, _capi.TP_BF16)
+    st = _capi.strides3((576 * 1024, 1024, 1))
+    rc = lib.tp_forward(ctypes.byref(d), None, st, None, st, None, None, None, 0, None)
+    assert rc == _capi.TP_ERR_INVALID_ARG
+    rc = lib.tp_pack_weights(ctypes.byref(d), None, None, 0, None)
+    assert rc == _capi.TP_ERR_INVALID_ARG
+    a = _capi.tp_linear_args()
+    assert lib.tp_linear(ctypes.byref(a), None) == _capi.TP_ERR_INVALID_ARG
+    assert lib.tp_set_tuning(99, 0) == _capi.TP_ERR_INVALID_ARG
+    assert lib.tp_set_tuning(_capi.TP_TUNE_GEMM_TILE, 0) == _capi.TP_OK
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    monkeypatch.setattr(_capi, "_lib", None)
+    with pytest.raises(_capi.TokenPackerLibraryError, match="no CPU fallback"):
+        _capi.load_library(str(tmp_path / "libtokenpacker_hip.so"))

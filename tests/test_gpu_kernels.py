@@ -1,0 +1,176 @@
+"""Per-kernel parity on a real MI355X, through the C ABI (tp_linear / tp_point_queries /
+tp_region_attention).  Reference math is the oracle (fp64 on the same rounded operands)."""
+import ctypes
+import math
+
+import pytest
+import torch
+
+from oracle import tokenpacker_oracle as orc
+from tokenpacker_amd import _capi, synth
+from tests import gpu_util as gu
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.bfloat16, torch.float16]
+# fp32-out results differ from fp64 math only by fp32 accumulation order
+TOL_F32OUT = 2e-5
+# one rounding of the output to T: half-ulp relative to the value, measured against max|ref|
+TOL_ROUND = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
+
+
+def _rand(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).cuda()
+
+
+def _ref_linear(A, W, bias=None):
+    y = A.double().cpu() @ W.double().cpu().t()
+    return y if bias is None else y + bias.double().cpu()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 512, 256), (300, 256, 128), (1000, 1024, 1024), (77, 128, 4096)])
+def test_linear_plain(dtype, tile, M, N, K):
+    if tile == 256 and N % 256:
+        pytest.skip("tile 256 needs N % 256 == 0")
+    A = _rand((M, K), dtype, 1)
+    W = _rand((N, K), dtype, 2, K ** -0.5)      # asymmetric, non-square data: catches transposes
+    ref = _ref_linear(A, W)
+    C32 = gu.linear(A, W, flags=_capi.TP_LINEAR_OUT_F32, tile=tile)
+    gu.assert_close(C32, ref, f"linear f32out {dtype} tile{tile} {M}x{N}x{K}", TOL_F32OUT)
+    C = gu.linear(A, W, tile=tile)
+    assert C.dtype == dtype
+    gu.assert_close(C, ref, f"linear {dtype} tile{tile} {M}x{N}x{K}", TOL_ROUND[dtype] * 1.01 + TOL_F32OUT)
+    # the T output must be exactly the rounding of the fp32 output (same accumulators)
+    assert torch.equal(C, C32.to(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [128, 256])
+def test_linear_bias_gelu(dtype, tile):
+    M, N, K = 640, 512, 256
+    A = _rand((M, K), dtype, 3)
+    W = _rand((N, K), dtype, 4, K ** -0.5)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).cuda()
+    ref = orc.gelu_erf(_ref_linear(A, W, bias))
+    C32 = gu.linear(A, W, bias=bias, flags=_capi.TP_LINEAR_OUT_F32 | _capi.TP_LINEAR_GELU, tile=tile)
+    gu.assert_close(C32, ref, f"linear+bias+gelu {dtype} tile{tile}", 3e-5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [128, 256])
+def test_linear_strided_batch_rows(dtype, tile):
+    """A given as the tower's [:,1:] slice of a CLS-prefixed [B,577,K] buffer (clip_encoder.py:37-38)."""
+    B, T, K, N = 3, 576, 256, 256
+    buf = _rand((B, T + 1, K), dtype, 6)
+    A = buf[:, 1:]
+    assert not A.is_contiguous()
+    W = _rand((N, K), dtype, 7, K ** -0.5)
+    ref = _ref_linear(A.reshape(B * T, K), W)
+    C32 = gu.linear(A, W, flags=_capi.TP_LINEAR_OUT_F32, tile=tile, M=B * T, rows_per_batch=T,
+                    a_batch_stride=A.stride(0), lda=A.stride(1))
+    gu.assert_close(C32, ref, f"linear strided {dtype} tile{tile}", TOL_F32OUT)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [128, 256])
+def test_linear_row_stats_and_ln_fold(dtype, tile):
+    """GEMM#1 emits per-row (sum, sumsq) partials of its ROUNDED output; GEMM#2 consumes them to apply
+    LayerNorm folded into its epilogue.  Reference: LN then linear in fp64 (builder.py:112,120 + in-proj)."""
+    M, E = 700, 1024
+    A = _rand((M, 256), dtype, 8)
+    W1 = _rand((E, 256), dtype, 9, 256 ** -0.5)
+    b1 = (0.3 * torch.randn(E, generator=torch.Generator().manual_seed(10)) + 0.2).cuda()   # non-zero mean
+    H, stats = gu.linear(A, W1, bias=b1, tile=tile, want_stats=True)
+    parts = stats.shape[0]
+    assert parts == E // tile
+    Hd = H.double().cpu()
+    s = stats.double().cpu().sum(0)
+    assert torch.allclose(s[:, 0], Hd.sum(1), rtol=1e-5, atol=1e-3), "row sums"
+    assert torch.allclose(s[:, 1], (Hd * Hd).sum(1), rtol=1e-5, atol=1e-3), "row sums of squares"
+
+    # LN-fold operands prepared exactly like tp_pack_weights does
+    g = torch.Generator().manual_seed(11)
+    gamma = (1 + 0.1 * torch.randn(E, generator=g)).to(dtype)
+    beta = (0.1 * torch.randn(E, generator=g)).to(dtype)
+    W2 = (torch.randn(E, E, generator=g) * E ** -0.5).to(dtype)
+    b2 = (0.1 * torch.randn(E, generator=g)).to(dtype)
+    W2p = (W2.float() * gamma.float()).to(dtype)
+    colsum = W2p.float().sum(1).cuda()
+    biasp = (W2.float() @ beta.float() + b2.float()).cuda()
+    ref = orc.linear(orc.layer_norm(Hd, gamma.double(), beta.double()), W2.double(), b2.double())
+    C32 = gu.linear(H, W2p.cuda(), bias=biasp, flags=_capi.TP_LINEAR_OUT_F32 | _capi.TP_LINEAR_LN_FOLD, tile=tile,
+                    stats_in=stats, colsum=colsum, stats_parts=parts, ln_dim=E, ln_eps=1e-6)
+    # differences: W·gamma rounded to T once (pack) vs exact gamma in the reference
+    gu.assert_close(C32, ref, f"ln-fold {dtype} tile{tile}", TOL_ROUND[dtype])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("s", [1, 2, 3, 4, 6])
+@pytest.mark.parametrize("layout", ["contiguous", "tower"])
+def test_point_queries_bit_exact(dtype, s, layout):
+    B = 3
+    x, _ = synth.make_inputs(21, B, dtype, layout)
+    xg = x.cuda() if layout == "contiguous" else None
+    if layout == "tower":
+        buf = torch.zeros(B, 577, 1024, dtype=dtype).cuda()
+        buf[:, 1:] = x.cuda()
+        xg = buf[:, 1:]
+    M = (24 // s) ** 2
+    q0 = torch.empty(B, M, 1024, dtype=dtype, device="cuda")
+    lib = _capi.load_library()
+    desc = _capi.make_desc(B, 24, s, 4096, gu.DT[dtype])
+    _capi.check(lib.tp_point_queries(ctypes.byref(desc), xg.data_ptr(), _capi.strides3(xg.stride()),
+                                     q0.data_ptr(), gu.stream_ptr()), "tp_point_queries")
+    torch.cuda.synchronize()
+    want = orc.point_queries(x.float(), 24, s, io_dtype=dtype).to(dtype)     # fp32 math, one rounding
+    assert torch.equal(q0.cpu(), want), gu.describe_mismatch(q0, want, f"point_queries s={s}", 0.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("s", [1, 2, 3, 4, 6, 12])
+def test_region_attention(dtype, s):
+    B, g, E, H = 2, 24, 1024, 8
+    G = g // s
+    M = G * G
+    q = _rand((B, M, E), dtype, 31)
+    k = _rand((B, g * g, E), dtype, 32)
+    v = _rand((B, g * g, E), dtype, 33)
+    o = torch.empty(B, M, E, dtype=dtype, device="cuda")
+    lib = _capi.load_library()
+    desc = _capi.make_desc(B, g, s, 4096, gu.DT[dtype])
+    _capi.check(lib.tp_region_attention(ctypes.byref(desc), q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(),
+                                        gu.stream_ptr()), "tp_region_attention")
+    torch.cuda.synchronize()
+    d = E // H
+    Q = q.double().cpu().reshape(B, G, G, H, d) / math.sqrt(d)
+    K = orc.region_gather(k.double().cpu(), g, s).reshape(B, G, G, s * s, H, d)
+    V = orc.region_gather(v.double().cpu(), g, s).reshape(B, G, G, s * s, H, d)
+    P = torch.softmax(torch.einsum("bijhd,bijkhd->bijhk", Q, K), dim=-1)
+    ref = torch.einsum("bijhk,bijkhd->bijhd", P, V).reshape(B, M, E)
+    gu.assert_close(o, ref, f"region_attention {dtype} s={s}", TOL_ROUND[dtype] * 1.05 + 1e-5)
+
+
+def test_region_attention_peaked_softmax():
+    """Large logits (|q·k|/sqrt(d) ~ 60): exercises the running-max rescale across key groups."""
+    dtype, s, B, g, E = torch.bfloat16, 4, 1, 24, 1024
+    M = (g // s) ** 2
+    q = _rand((B, M, E), dtype, 41, 6.0)
+    k = _rand((B, g * g, E), dtype, 42, 1.0)
+    v = _rand((B, g * g, E), dtype, 43)
+    o = torch.empty(B, M, E, dtype=dtype, device="cuda")
+    lib = _capi.load_library()
+    desc = _capi.make_desc(B, g, s, 4096, gu.DT[dtype])
+    _capi.check(lib.tp_region_attention(ctypes.byref(desc), q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(),
+                                        gu.stream_ptr()), "tp_region_attention")
+    torch.cuda.synchronize()
+    G, H, d = g // s, 8, 128
+    Q = q.double().cpu().reshape(B, G, G, H, d) / math.sqrt(d)
+    K = orc.region_gather(k.double().cpu(), g, s).reshape(B, G, G, s * s, H, d)
+    V = orc.region_gather(v.double().cpu(), g, s).reshape(B, G, G, s * s, H, d)
+    P = torch.softmax(torch.einsum("bijhd,bijkhd->bijhk", Q, K), dim=-1)
+    assert P.max() > 0.99          # the case really is peaked
+    ref = torch.einsum("bijhk,bijkhd->bijhd", P, V).reshape(B, M, E)
+    gu.assert_close(o, ref, "region_attention peaked", 2.0 ** -8 * 1.05 + 1e-5)

@@ -1,0 +1,76 @@
+"""Drop-in boundary of the nn.Module, checked without a GPU."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tokenpacker_amd import TokenPacker, build_vision_projector, synth
+
+
+def test_state_dict_contract_names_shapes_order():
+    for D in (4096, 5120, 256):
+        m = TokenPacker(hidden_size=D)
+        sd = m.state_dict()
+        want = synth.param_shapes(D)
+        assert list(sd.keys()) == list(want.keys())
+        for k, shape in want.items():
+            assert tuple(sd[k].shape) == shape, k
+    assert sum(p.numel() for p in TokenPacker(hidden_size=4096).parameters()) == 36_722_688
+
+
+def test_load_reference_style_state_dict_strict():
+    params = synth.make_params(3, 256)
+    m = TokenPacker(hidden_size=256, scale_factor=3)
+    res = m.load_state_dict(params, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, params[k])
+    # projector-only checkpoints are stored with an 'mm_projector.' prefix and loaded through
+    # get_w() (llava_arch.py:80-83): emulate it
+    ckpt = {"model.mm_projector." + k: v for k, v in params.items()}
+    stripped = {k.split("mm_projector.")[1]: v for k, v in ckpt.items() if "mm_projector" in k}
+    TokenPacker(hidden_size=256).load_state_dict(stripped)
+
+
+def test_constructor_and_factory_mirror_reference():
+    cfg = type("Cfg", (), {"hidden_size": 5120, "scale_factor": 4, "mm_projector_type": "tokenpacker"})()
+    m = build_vision_projector(cfg)
+    assert isinstance(m, TokenPacker)
+    assert (m.raw_grid, m.grid_size, m.num_queries, m.scale_factor, m.embed_dim, m.num_heads) == (24, 6, 36, 4, 1024, 8)
+    assert m.mlp[2].weight.shape == (5120, 5120)
+    with pytest.raises(ValueError, match="scale_factor must be divisible by grid size"):
+        TokenPacker(scale_factor=5)
+    # default init follows the reference: zero biases, unit LayerNorm, small linear weights
+    m = TokenPacker(hidden_size=256)
+    assert float(m.k_proj_1[0].bias.abs().max()) == 0.0 and float(m.ln_k_1.weight.min()) == 1.0
+    assert 0.015 < float(m.q_proj_1.weight.std()) < 0.025
+    assert all(p.requires_grad for p in m.parameters())
+    m.requires_grad_(False)
+    assert not any(p.requires_grad for p in m.parameters())
+
+
+def test_cpu_tensors_raise_instead_of_falling_back():
+    m = TokenPacker(hidden_size=256).requires_grad_(False)
+    x = torch.zeros(1, 576, 1024, dtype=torch.bfloat16)
+    xm = torch.zeros(1, 576, 4096, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m((x, xm))
+
+
+def test_product_never_imports_the_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for path in glob.glob(os.path.join(root, "tokenpacker_amd", "**", "*.py"), recursive=True):
+        src = open(path).read()
+        assert "import oracle" not in src and "from oracle" not in src, path
+    bench = open(os.path.join(root, "bench.py")).read()
+    # bench.py may use the oracle only inside its cpu_baseline leg
+    assert bench.count("from oracle") + bench.count("import oracle") <= 1
+
+
+def test_golden_param_digests_are_reproducible():
+    for path in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")):
+        z = np.load(path)
+        p = synth.make_params(int(z["param_seed"]), int(z["hidden_size"]))
+        assert synth.tensor_digest(*p.values()) == str(z["params_sha256"])

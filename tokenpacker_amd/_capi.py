@@ -1,0 +1,156 @@
+"""ctypes binding of ``libtokenpacker_hip.so`` (C ABI declared in ``include/tokenpacker.h``).
+
+The library is the product's only compute path.  There is NO CPU / eager fallback: if the
+shared object is missing or a call fails, this module raises (``TokenPackerLibraryError`` /
+``RuntimeError`` / ``ValueError``) instead of computing the result some other way.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import (POINTER, Structure, byref, c_char_p, c_float, c_int, c_int32, c_int64,
+                    c_size_t, c_void_p)
+
+TP_ABI_VERSION = 1
+TP_BF16, TP_F16, TP_F32 = 0, 1, 2
+TP_OK, TP_ERR_INVALID_ARG, TP_ERR_BAD_SCALE, TP_ERR_WORKSPACE, TP_ERR_LAUNCH = 0, -1, -2, -3, -4
+TP_LINEAR_GELU, TP_LINEAR_LN_FOLD, TP_LINEAR_ROW_STATS, TP_LINEAR_OUT_F32 = 1, 2, 4, 8
+TP_TUNE_GEMM_TILE, TP_TUNE_XCD_SWIZZLE = 0, 1
+TP_NUM_STAGES = 10
+STAGE_NAMES = ("point_queries", "kv_layer0_gelu", "kv_layer2_stats", "kv_inproj_lnfold", "q_proj_1_stats",
+               "q_inproj_lnfold", "region_attention", "out_proj", "mlp0_gelu", "mlp2")
+
+LIB_NAME = "libtokenpacker_hip.so"
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+# every symbol include/tokenpacker.h declares
+EXPORTED_SYMBOLS = (
+    "tp_version", "tp_last_error", "tp_packed_weight_bytes", "tp_workspace_bytes",
+    "tp_pack_weights", "tp_forward", "tp_forward_staged", "tp_point_queries", "tp_region_attention", "tp_linear",
+    "tp_linear_stats_parts", "tp_set_tuning",
+)
+
+# state-dict name -> tp_weights field order (include/tokenpacker.h)
+WEIGHT_FIELDS = (
+    "q_proj_1.weight",
+    "k_proj_1.0.weight", "k_proj_1.0.bias", "k_proj_1.2.weight", "k_proj_1.2.bias",
+    "v_proj_1.0.weight", "v_proj_1.0.bias", "v_proj_1.2.weight", "v_proj_1.2.bias",
+    "ln_q_1.weight", "ln_q_1.bias", "ln_k_1.weight", "ln_k_1.bias", "ln_v_1.weight", "ln_v_1.bias",
+    "clip_attn.in_proj_weight", "clip_attn.in_proj_bias",
+    "clip_attn.out_proj.weight", "clip_attn.out_proj.bias",
+    "mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias",
+)
+
+
+class TokenPackerLibraryError(RuntimeError):
+    pass
+
+
+class tp_desc(Structure):
+    _fields_ = [("batch", c_int32), ("raw_grid", c_int32), ("scale_factor", c_int32),
+                ("hidden_size", c_int32), ("dtype", c_int32), ("out_dtype", c_int32),
+                ("ln_eps", c_float), ("reserved", c_int32)]
+
+
+class tp_weights(Structure):
+    _fields_ = [(name.replace(".", "_"), c_void_p) for name in WEIGHT_FIELDS]
+
+
+class tp_linear_args(Structure):
+    _fields_ = [("M", c_int32), ("N", c_int32), ("K", c_int32), ("dtype", c_int32),
+                ("flags", c_int32), ("rows_per_batch", c_int32),
+                ("a_batch_stride", c_int64), ("lda", c_int64), ("ldc", c_int64),
+                ("A", c_void_p), ("W", c_void_p), ("bias", c_void_p), ("C", c_void_p),
+                ("row_stats_in", c_void_p), ("colsum", c_void_p),
+                ("stats_parts", c_int32), ("ln_dim", c_int32), ("ln_eps", c_float),
+                ("tile", c_int32), ("row_stats_out", c_void_p)]
+
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
+    """dlopen the C-ABI library and declare its prototypes.  Loading needs no GPU.
+
+    Inside a torch process, ``import torch`` must come first so that the HIP runtime the library
+    binds to (SONAME ``libamdhip64.so.7``) is the one torch already loaded — device pointers and
+    streams are then shared.  ``tokenpacker_amd.projector`` guarantees that order.
+    """
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise TokenPackerLibraryError(
+            f"{path} not found: build it with `make -C tokenpacker_amd/csrc` "
+            f"(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            f"There is no CPU fallback for the TokenPacker projector.")
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:  # pragma: no cover - depends on the environment
+        raise TokenPackerLibraryError(f"cannot load {path}: {e}") from e
+
+    lib.tp_version.restype = c_int
+    lib.tp_version.argtypes = []
+    lib.tp_last_error.restype = c_char_p
+    lib.tp_last_error.argtypes = []
+    lib.tp_packed_weight_bytes.restype = c_size_t
+    lib.tp_packed_weight_bytes.argtypes = [POINTER(tp_desc)]
+    lib.tp_workspace_bytes.restype = c_size_t
+    lib.tp_workspace_bytes.argtypes = [POINTER(tp_desc)]
+    lib.tp_pack_weights.restype = c_int
+    lib.tp_pack_weights.argtypes = [POINTER(tp_desc), POINTER(tp_weights), c_void_p, c_size_t, c_void_p]
+    lib.tp_forward.restype = c_int
+    lib.tp_forward.argtypes = [POINTER(tp_desc), c_void_p, POINTER(c_int64), c_void_p, POINTER(c_int64),
+                               c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.tp_forward_staged.restype = c_int
+    lib.tp_forward_staged.argtypes = lib.tp_forward.argtypes + [POINTER(c_void_p), c_int]
+    lib.tp_point_queries.restype = c_int
+    lib.tp_point_queries.argtypes = [POINTER(tp_desc), c_void_p, POINTER(c_int64), c_void_p, c_void_p]
+    lib.tp_region_attention.restype = c_int
+    lib.tp_region_attention.argtypes = [POINTER(tp_desc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.tp_linear.restype = c_int
+    lib.tp_linear.argtypes = [POINTER(tp_linear_args), c_void_p]
+    lib.tp_linear_stats_parts.restype = c_int
+    lib.tp_linear_stats_parts.argtypes = [POINTER(tp_linear_args)]
+    lib.tp_set_tuning.restype = c_int
+    lib.tp_set_tuning.argtypes = [c_int, c_int]
+
+    if lib.tp_version() != TP_ABI_VERSION:
+        raise TokenPackerLibraryError(
+            f"{path}: ABI version {lib.tp_version()} != expected {TP_ABI_VERSION}; rebuild the library")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load_library().tp_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str) -> None:
+    """Map a tp_status to the reference's exception conventions: bad
+    scale_factor / arguments -> ValueError (builder.py:51-52), everything else RuntimeError."""
+    if rc == TP_OK:
+        return
+    msg = last_error()
+    if rc in (TP_ERR_BAD_SCALE, TP_ERR_INVALID_ARG):
+        raise ValueError(msg if rc == TP_ERR_BAD_SCALE else f"{what}: {msg}")
+    raise RuntimeError(f"{what} failed ({rc}): {msg}")
+
+
+def make_desc(batch: int, raw_grid: int, scale_factor: int, hidden_size: int, dtype: int,
+              out_dtype: int | None = None, ln_eps: float = 1e-6) -> tp_desc:
+    return tp_desc(batch, raw_grid, scale_factor, hidden_size, dtype,
+                   dtype if out_dtype is None else out_dtype, ln_eps, 0)
+
+
+def strides3(st) -> "ctypes.Array":
+    return (c_int64 * 3)(int(st[0]), int(st[1]), int(st[2]))
+
+
+def set_tuning(key: int, value: int) -> None:
+    check(load_library().tp_set_tuning(key, value), "tp_set_tuning")
+
+
+__all__ = [n for n in dir() if n.startswith(("TP_", "tp_"))] + [
+    "load_library", "last_error", "check", "make_desc", "strides3", "set_tuning",
+    "TokenPackerLibraryError", "WEIGHT_FIELDS", "EXPORTED_SYMBOLS", "LIB_PATH", "byref"]

@@ -1,0 +1,391 @@
+// tp_api.hip — extern "C" surface of libtokenpacker_hip.so (see include/tokenpacker.h) and the
+// launch schedule of the TokenPacker forward on one MI355X.
+//
+// Forward schedule (reference builder.py:107-137, line numbers per step):
+//   1  point_queries     x -> q0                       [B*M,1024]          :117-118
+//   2  linear+GELU       x_multi · [Wk0;Wv0]^T -> Hkv  [B*N,2048]          :112,113 (x_multi read ONCE)
+//   3  linear x2 (+stats) Hkv[:, g] · W{k,v}2^T -> H2[g] [2][B*N,1024]     :112,113
+//   4  linear x2 LN-fold  LN(H2[g]) · Win{k,v}^T -> K,V [2][B*N,1024]      :112,113 LN + :126-130 in-proj
+//   5  linear (+stats)    q0 · Wq1^T -> Q1pre           [B*M,1024]         :120
+//   6  linear LN-fold     LN(Q1pre) · Winq^T -> Q       [B*M,1024]         :120 LN + :126-130 in-proj
+//   7  region_attention   (Q, K, V) -> O                [B*M,1024]         :122-130
+//   8  linear             O · Wout^T + b -> A1          [B*M,1024]         :126-130 out_proj
+//   9  linear+GELU        A1 · Wm0^T + b -> A2          [B*M,D]            :136
+//   10 linear             A2 · Wm2^T + b -> out         [B*M,D]            :136
+#include "tp_internal.h"
+#include <cstdarg>
+#include <cstdio>
+#include <atomic>
+
+namespace tp {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return TP_ERR_LAUNCH;
+    }
+    return TP_OK;
+}
+
+static std::atomic<int> g_tuning[TP_TUNE_COUNT_] = {{0}, {1}, {0}, {0}, {0}, {0}, {0}, {0}};
+int tuning(int key) { return (key >= 0 && key < TP_TUNE_COUNT_) ? g_tuning[key].load() : 0; }
+
+static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+PackedLayout packed_layout(int D) {
+    PackedLayout L{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
+    const size_t E = kEmbed;
+    L.w_kv0 = take(2 * E * kMulti * 2);  L.b_kv0 = take(2 * E * 4);
+    L.w_kv2 = take(2 * E * E * 2);       L.b_kv2 = take(2 * E * 4);
+    L.w_q1 = take(E * E * 2);
+    L.w_in_kv = take(2 * E * E * 2);     L.c_in_kv = take(2 * E * 4);  L.b_in_kv = take(2 * E * 4);
+    L.w_in_q = take(E * E * 2);          L.c_in_q = take(E * 4);       L.b_in_q = take(E * 4);
+    L.w_out = take(E * E * 2);           L.b_out = take(E * 4);
+    L.w_m0 = take((size_t)D * E * 2);    L.b_m0 = take((size_t)D * 4);
+    L.w_m2 = take((size_t)D * D * 2);    L.b_m2 = take((size_t)D * 4);
+    L.total = off;
+    return L;
+}
+
+WorkspaceLayout workspace_layout(int B, int grid, int s, int D) {
+    WorkspaceLayout L{};
+    const size_t N = (size_t)grid * grid, G = grid / s, M = G * G, E = kEmbed;
+    const size_t rows_kv = (size_t)B * N, rows_q = (size_t)B * M;
+    L.stats_parts_kv = gemm_stats_parts((int)rows_kv, kEmbed, 0);
+    L.stats_parts_q = gemm_stats_parts((int)rows_q, kEmbed, 0);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
+    L.q0 = take(rows_q * E * 2);
+    L.hkv = take(rows_kv * 2 * E * 2);
+    L.h2 = take(2 * rows_kv * E * 2);
+    L.stats_kv = take(2 * (size_t)8 * rows_kv * 2 * 4);     // up to 8 slabs (tile 128) per group
+    L.kv = take(2 * rows_kv * E * 2);
+    L.q1pre = take(rows_q * E * 2);
+    L.stats_q = take((size_t)8 * rows_q * 2 * 4);
+    L.q = take(rows_q * E * 2);
+    L.o = take(rows_q * E * 2);
+    L.a1 = take(rows_q * E * 2);
+    L.a2 = take(rows_q * (size_t)D * 2);
+    L.total = off;
+    return L;
+}
+
+static int validate_desc(const tp_desc* d) {
+    if (!d) { set_error("tp_desc is NULL"); return TP_ERR_INVALID_ARG; }
+    if (d->batch <= 0 || d->raw_grid <= 0 || d->scale_factor <= 0 || d->hidden_size <= 0) {
+        set_error("tp_desc: batch/raw_grid/scale_factor/hidden_size must be positive (got %d/%d/%d/%d)",
+                  d->batch, d->raw_grid, d->scale_factor, d->hidden_size);
+        return TP_ERR_INVALID_ARG;
+    }
+    if (d->raw_grid % d->scale_factor != 0) {
+        set_error("scale_factor must be divisible by grid size");    // the reference's message, builder.py:52
+        return TP_ERR_BAD_SCALE;
+    }
+    if (d->hidden_size % 128 != 0) {
+        set_error("tp_desc: hidden_size %d must be a multiple of 128", d->hidden_size);
+        return TP_ERR_INVALID_ARG;
+    }
+    if (d->dtype != TP_BF16 && d->dtype != TP_F16) {
+        set_error("tp_desc: dtype %d unsupported (TP_BF16 / TP_F16)", d->dtype);
+        return TP_ERR_INVALID_ARG;
+    }
+    if (d->out_dtype != d->dtype && d->out_dtype != TP_F32) {
+        set_error("tp_desc: out_dtype %d must equal dtype or be TP_F32", d->out_dtype);
+        return TP_ERR_INVALID_ARG;
+    }
+    if ((long long)d->batch * d->raw_grid * d->raw_grid > 0x7fffffffLL / 2) {
+        set_error("tp_desc: batch*grid*grid too large for 32-bit row indices");
+        return TP_ERR_INVALID_ARG;
+    }
+    if (!(d->ln_eps > 0.f)) { set_error("tp_desc: ln_eps must be > 0"); return TP_ERR_INVALID_ARG; }
+    return TP_OK;
+}
+
+static GemmArgs plain_gemm(const void* A, long long lda_elems, const void* W, void* C, long long ldc,
+                           int M, int N, int K, const float* bias, int flags) {
+    GemmArgs a{};
+    a.A = (const char*)A; a.W = (const char*)W; a.C = (char*)C;
+    a.bias = bias;
+    a.lda_bytes = lda_elems * 2; a.a_batch_stride_bytes = 0; a.rows_per_batch = M;
+    a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.flags = flags; a.groups = 1;
+    a.inv_ln_dim = 1.f / kEmbed; a.ln_eps = 1e-6f;
+    return a;
+}
+
+}  // namespace tp
+
+using namespace tp;
+
+extern "C" {
+
+int tp_version(void) { return TP_ABI_VERSION; }
+
+const char* tp_last_error(void) { return g_err; }
+
+int tp_set_tuning(int key, int value) {
+    if (key < 0 || key >= TP_TUNE_COUNT_) { set_error("tp_set_tuning: bad key %d", key); return TP_ERR_INVALID_ARG; }
+    g_tuning[key].store(value);
+    return TP_OK;
+}
+
+size_t tp_packed_weight_bytes(const tp_desc* desc) {
+    if (validate_desc(desc) != TP_OK) return 0;
+    return packed_layout(desc->hidden_size).total;
+}
+
+size_t tp_workspace_bytes(const tp_desc* desc) {
+    if (validate_desc(desc) != TP_OK) return 0;
+    return workspace_layout(desc->batch, desc->raw_grid, desc->scale_factor, desc->hidden_size).total;
+}
+
+int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, size_t packed_bytes,
+                    void* stream_) {
+    int rc = validate_desc(desc);
+    if (rc != TP_OK) return rc;
+    if (!raw || !packed) { set_error("tp_pack_weights: NULL argument"); return TP_ERR_INVALID_ARG; }
+    const void* const* ptrs = reinterpret_cast<const void* const*>(raw);
+    for (size_t i = 0; i < sizeof(tp_weights) / sizeof(void*); ++i)
+        if (!ptrs[i]) { set_error("tp_pack_weights: weight pointer #%zu is NULL", i); return TP_ERR_INVALID_ARG; }
+    const int D = desc->hidden_size, dt = desc->dtype;
+    const PackedLayout L = packed_layout(D);
+    if (packed_bytes < L.total) {
+        set_error("tp_pack_weights: packed buffer %zu B < required %zu B", packed_bytes, L.total);
+        return TP_ERR_WORKSPACE;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    char* P = (char*)packed;
+    const size_t E = kEmbed;
+    auto copy = [&](size_t off, const void* src, size_t bytes) -> int {
+        hipError_t e = hipMemcpyAsync(P + off, src, bytes, hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) { set_error("tp_pack_weights: hipMemcpyAsync: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
+        return TP_OK;
+    };
+#define TP_TRY(expr) do { int rc_ = (expr); if (rc_ != TP_OK) return rc_; } while (0)
+    // K/V first layers concatenated: one GEMM reads x_multi once
+    TP_TRY(copy(L.w_kv0, raw->k_proj_1_0_weight, E * kMulti * 2));
+    TP_TRY(copy(L.w_kv0 + E * kMulti * 2, raw->v_proj_1_0_weight, E * kMulti * 2));
+    TP_TRY(pack_cast_f32_launch(dt, raw->k_proj_1_0_bias, (float*)(P + L.b_kv0), (int)E, stream));
+    TP_TRY(pack_cast_f32_launch(dt, raw->v_proj_1_0_bias, (float*)(P + L.b_kv0) + E, (int)E, stream));
+    TP_TRY(copy(L.w_kv2, raw->k_proj_1_2_weight, E * E * 2));
+    TP_TRY(copy(L.w_kv2 + E * E * 2, raw->v_proj_1_2_weight, E * E * 2));
+    TP_TRY(pack_cast_f32_launch(dt, raw->k_proj_1_2_bias, (float*)(P + L.b_kv2), (int)E, stream));
+    TP_TRY(pack_cast_f32_launch(dt, raw->v_proj_1_2_bias, (float*)(P + L.b_kv2) + E, (int)E, stream));
+    TP_TRY(copy(L.w_q1, raw->q_proj_1_weight, E * E * 2));
+    // LayerNorm affines folded into the q/k/v in-projections (in_proj rows: q | k | v)
+    const char* inw = (const char*)raw->clip_attn_in_proj_weight;
+    const char* inb = (const char*)raw->clip_attn_in_proj_bias;
+    TP_TRY(pack_ln_fold_launch(dt, inw, inb, raw->ln_q_1_weight, raw->ln_q_1_bias, P + L.w_in_q,
+                               (float*)(P + L.c_in_q), (float*)(P + L.b_in_q), (int)E, (int)E, stream));
+    TP_TRY(pack_ln_fold_launch(dt, inw + E * E * 2, inb + E * 2, raw->ln_k_1_weight, raw->ln_k_1_bias,
+                               P + L.w_in_kv, (float*)(P + L.c_in_kv), (float*)(P + L.b_in_kv), (int)E, (int)E, stream));
+    TP_TRY(pack_ln_fold_launch(dt, inw + 2 * E * E * 2, inb + 2 * E * 2, raw->ln_v_1_weight, raw->ln_v_1_bias,
+                               P + L.w_in_kv + E * E * 2, (float*)(P + L.c_in_kv) + E, (float*)(P + L.b_in_kv) + E,
+                               (int)E, (int)E, stream));
+    TP_TRY(copy(L.w_out, raw->clip_attn_out_proj_weight, E * E * 2));
+    TP_TRY(pack_cast_f32_launch(dt, raw->clip_attn_out_proj_bias, (float*)(P + L.b_out), (int)E, stream));
+    TP_TRY(copy(L.w_m0, raw->mlp_0_weight, (size_t)D * E * 2));
+    TP_TRY(pack_cast_f32_launch(dt, raw->mlp_0_bias, (float*)(P + L.b_m0), D, stream));
+    TP_TRY(copy(L.w_m2, raw->mlp_2_weight, (size_t)D * D * 2));
+    TP_TRY(pack_cast_f32_launch(dt, raw->mlp_2_bias, (float*)(P + L.b_m2), D, stream));
+    return TP_OK;
+}
+
+static int check_strides(const char* name, const void* p, const int64_t st[3]) {
+    if (!p || !st) { set_error("%s: NULL pointer", name); return TP_ERR_INVALID_ARG; }
+    if (st[2] != 1) { set_error("%s: innermost stride must be 1 (got %lld)", name, (long long)st[2]); return TP_ERR_INVALID_ARG; }
+    if (st[1] % 8 != 0 || st[0] % 8 != 0 || ((uintptr_t)p & 15) != 0) {
+        set_error("%s: base pointer must be 16-byte aligned and strides multiples of 8 elements", name);
+        return TP_ERR_INVALID_ARG;
+    }
+    return TP_OK;
+}
+
+int tp_point_queries(const tp_desc* desc, const void* x, const int64_t x_strides[3], void* q0, void* stream) {
+    TP_TRY(validate_desc(desc));
+    TP_TRY(check_strides("x", x, x_strides));
+    if (!q0) { set_error("tp_point_queries: q0 is NULL"); return TP_ERR_INVALID_ARG; }
+    return point_queries_launch(desc->dtype, x, x_strides, q0, desc->batch, desc->raw_grid,
+                                desc->scale_factor, (hipStream_t)stream);
+}
+
+int tp_region_attention(const tp_desc* desc, const void* q, const void* k, const void* v, void* o, void* stream) {
+    TP_TRY(validate_desc(desc));
+    if (!q || !k || !v || !o) { set_error("tp_region_attention: NULL pointer"); return TP_ERR_INVALID_ARG; }
+    return region_attention_launch(desc->dtype, q, k, v, o, desc->batch, desc->raw_grid,
+                                   desc->scale_factor, (hipStream_t)stream);
+}
+
+int tp_linear_stats_parts(const tp_linear_args* a) {
+    if (!a || a->N <= 0 || a->N % 128 != 0) return 0;
+    return gemm_stats_parts(a->M, a->N, a->tile);
+}
+
+int tp_linear(const tp_linear_args* a, void* stream) {
+    if (!a || !a->A || !a->W || !a->C) { set_error("tp_linear: NULL argument"); return TP_ERR_INVALID_ARG; }
+    if ((a->flags & TP_LINEAR_LN_FOLD) && (!a->row_stats_in || !a->colsum || a->stats_parts <= 0 || a->ln_dim <= 0)) {
+        set_error("tp_linear: LN_FOLD needs row_stats_in, colsum, stats_parts, ln_dim");
+        return TP_ERR_INVALID_ARG;
+    }
+    if ((a->flags & TP_LINEAR_ROW_STATS) && !a->row_stats_out) {
+        set_error("tp_linear: ROW_STATS needs row_stats_out");
+        return TP_ERR_INVALID_ARG;
+    }
+    if (a->lda % 8 != 0 || a->a_batch_stride % 8 != 0 || ((uintptr_t)a->A & 15) || ((uintptr_t)a->W & 15) ||
+        ((uintptr_t)a->C & 15) || a->ldc % 4 != 0) {
+        set_error("tp_linear: A/W/C must be 16-byte aligned, lda and batch stride multiples of 8 elements");
+        return TP_ERR_INVALID_ARG;
+    }
+    GemmArgs g{};
+    g.A = (const char*)a->A; g.W = (const char*)a->W; g.C = (char*)a->C;
+    g.bias = a->bias; g.stats_in = a->row_stats_in; g.colsum = a->colsum; g.stats_out = a->row_stats_out;
+    g.rows_per_batch = (a->rows_per_batch > 0 && a->rows_per_batch < a->M) ? a->rows_per_batch : a->M;
+    g.a_batch_stride_bytes = a->a_batch_stride * 2; g.lda_bytes = a->lda * 2; g.ldc = a->ldc;
+    g.M = a->M; g.N = a->N; g.K = a->K; g.flags = a->flags; g.stats_parts = a->stats_parts;
+    g.inv_ln_dim = a->ln_dim > 0 ? 1.f / a->ln_dim : 0.f; g.ln_eps = a->ln_eps;
+    g.groups = 1; g.tile = a->tile;
+    return gemm_launch(a->dtype, g, (hipStream_t)stream);
+}
+
+static int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3], const void* x_multi,
+                        const int64_t xm_strides[3], const void* packed_weights, void* out, void* workspace,
+                        size_t workspace_bytes, void* stream_, void* const* stage_events) {
+    TP_TRY(validate_desc(desc));
+    TP_TRY(check_strides("x", x, x_strides));
+    TP_TRY(check_strides("x_multi", x_multi, xm_strides));
+    if (!packed_weights || !out || !workspace) { set_error("tp_forward: NULL argument"); return TP_ERR_INVALID_ARG; }
+    const int B = desc->batch, g = desc->raw_grid, s = desc->scale_factor, D = desc->hidden_size, dt = desc->dtype;
+    const int N = g * g, G = g / s, M = G * G, E = kEmbed;
+    const int rows_kv = B * N, rows_q = B * M;
+    const PackedLayout P = packed_layout(D);
+    const WorkspaceLayout W = workspace_layout(B, g, s, D);
+    if (workspace_bytes < W.total) {
+        set_error("tp_forward: workspace %zu B < required %zu B", workspace_bytes, W.total);
+        return TP_ERR_WORKSPACE;
+    }
+    if (((uintptr_t)workspace & 255) || ((uintptr_t)packed_weights & 255) || ((uintptr_t)out & 15)) {
+        set_error("tp_forward: workspace/packed buffers must be 256-byte aligned, out 16-byte aligned");
+        return TP_ERR_INVALID_ARG;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    const char* pw = (const char*)packed_weights;
+    char* ws = (char*)workspace;
+    const long long kvE = (long long)rows_kv * E;      // elements per K/V group slab
+
+    int stage_idx = 0;
+    auto mark = [&]() -> int {
+        if (stage_events) {
+            hipError_t e = hipEventRecord((hipEvent_t)stage_events[stage_idx], stream);
+            if (e != hipSuccess) { set_error("hipEventRecord(stage %d): %s", stage_idx, hipGetErrorString(e)); return TP_ERR_LAUNCH; }
+        }
+        ++stage_idx;
+        return TP_OK;
+    };
+    TP_TRY(mark());
+    // 1. coarse point queries
+    TP_TRY(point_queries_launch(dt, x, x_strides, ws + W.q0, B, g, s, stream));
+
+    TP_TRY(mark());
+    // 2. Hkv = GELU(x_multi · [Wk0;Wv0]^T + b): strided A (tower hands over [:,1:] slices)
+    {
+        GemmArgs a = plain_gemm(x_multi, xm_strides[1], pw + P.w_kv0, ws + W.hkv, 2 * E, rows_kv, 2 * E, kMulti,
+                                (const float*)(pw + P.b_kv0), TP_LINEAR_GELU);
+        a.rows_per_batch = N; a.a_batch_stride_bytes = xm_strides[0] * 2;
+        TP_TRY(gemm_launch(dt, a, stream));
+    }
+    // 3. H2[g] = Hkv[:, g*1024:(g+1)*1024] · W{k,v}2^T + b, and LayerNorm partials of H2
+    TP_TRY(mark());
+    const int parts_kv = gemm_stats_parts(rows_kv, E, 0);
+    {
+        GemmArgs a = plain_gemm(ws + W.hkv, 2 * E, pw + P.w_kv2, ws + W.h2, E, rows_kv, E, E,
+                                (const float*)(pw + P.b_kv2), TP_LINEAR_ROW_STATS);
+        a.groups = 2; a.a_gs = E * 2; a.w_gs = (long long)E * E * 2; a.c_gs = kvE * 2; a.bias_gs = E;
+        a.stats_out = (float*)(ws + W.stats_kv); a.stats_out_gs = (long long)parts_kv * rows_kv * 2;
+        TP_TRY(gemm_launch(dt, a, stream));
+    }
+    TP_TRY(mark());
+    // 4. {K,V} = LN(H2[g]) · Win{k,v}^T + b   (LayerNorm folded into the epilogue)
+    {
+        GemmArgs a = plain_gemm(ws + W.h2, E, pw + P.w_in_kv, ws + W.kv, E, rows_kv, E, E,
+                                (const float*)(pw + P.b_in_kv), TP_LINEAR_LN_FOLD);
+        a.groups = 2; a.a_gs = kvE * 2; a.w_gs = (long long)E * E * 2; a.c_gs = kvE * 2; a.bias_gs = E;
+        a.stats_in = (const float*)(ws + W.stats_kv); a.stats_in_gs = (long long)parts_kv * rows_kv * 2;
+        a.stats_parts = parts_kv; a.colsum = (const float*)(pw + P.c_in_kv); a.colsum_gs = E;
+        a.ln_eps = desc->ln_eps;
+        TP_TRY(gemm_launch(dt, a, stream));
+    }
+    TP_TRY(mark());
+    // 5. Q1pre = q0 · Wq1^T (no bias), LayerNorm partials
+    const int parts_q = gemm_stats_parts(rows_q, E, 0);
+    {
+        GemmArgs a = plain_gemm(ws + W.q0, E, pw + P.w_q1, ws + W.q1pre, E, rows_q, E, E, nullptr, TP_LINEAR_ROW_STATS);
+        a.stats_out = (float*)(ws + W.stats_q);
+        TP_TRY(gemm_launch(dt, a, stream));
+    }
+    TP_TRY(mark());
+    // 6. Q = LN(Q1pre) · Winq^T + b
+    {
+        GemmArgs a = plain_gemm(ws + W.q1pre, E, pw + P.w_in_q, ws + W.q, E, rows_q, E, E,
+                                (const float*)(pw + P.b_in_q), TP_LINEAR_LN_FOLD);
+        a.stats_in = (const float*)(ws + W.stats_q); a.stats_parts = parts_q;
+        a.colsum = (const float*)(pw + P.c_in_q); a.ln_eps = desc->ln_eps;
+        TP_TRY(gemm_launch(dt, a, stream));
+    }
+    TP_TRY(mark());
+    // 7. region-to-point attention
+    TP_TRY(region_attention_launch(dt, ws + W.q, ws + W.kv, ws + W.kv + kvE * 2, ws + W.o, B, g, s, stream));
+    TP_TRY(mark());
+    // 8. out_proj
+    {
+        GemmArgs a = plain_gemm(ws + W.o, E, pw + P.w_out, ws + W.a1, E, rows_q, E, E, (const float*)(pw + P.b_out), 0);
+        TP_TRY(gemm_launch(dt, a, stream));
+    }
+    TP_TRY(mark());
+    // 9. mlp[0] + GELU
+    {
+        GemmArgs a = plain_gemm(ws + W.a1, E, pw + P.w_m0, ws + W.a2, D, rows_q, D, E, (const float*)(pw + P.b_m0), TP_LINEAR_GELU);
+        TP_TRY(gemm_launch(dt, a, stream));
+    }
+    TP_TRY(mark());
+    // 10. mlp[2] -> out
+    {
+        GemmArgs a = plain_gemm(ws + W.a2, D, pw + P.w_m2, out, D, rows_q, D, D, (const float*)(pw + P.b_m2),
+                                desc->out_dtype == TP_F32 ? TP_LINEAR_OUT_F32 : 0);
+        TP_TRY(gemm_launch(dt, a, stream));
+    }
+    TP_TRY(mark());
+    return TP_OK;
+}
+
+int tp_forward(const tp_desc* desc, const void* x, const int64_t x_strides[3], const void* x_multi,
+               const int64_t xm_strides[3], const void* packed_weights, void* out, void* workspace,
+               size_t workspace_bytes, void* stream) {
+    return forward_impl(desc, x, x_strides, x_multi, xm_strides, packed_weights, out, workspace, workspace_bytes,
+                        stream, nullptr);
+}
+
+int tp_forward_staged(const tp_desc* desc, const void* x, const int64_t x_strides[3], const void* x_multi,
+                      const int64_t xm_strides[3], const void* packed_weights, void* out, void* workspace,
+                      size_t workspace_bytes, void* stream, void* const* stage_events, int n_events) {
+    if (!stage_events || n_events != TP_NUM_STAGES + 1) {
+        set_error("tp_forward_staged: need %d events, got %d", TP_NUM_STAGES + 1, n_events);
+        return TP_ERR_INVALID_ARG;
+    }
+    for (int i = 0; i < n_events; ++i)
+        if (!stage_events[i]) { set_error("tp_forward_staged: event %d is NULL", i); return TP_ERR_INVALID_ARG; }
+    return forward_impl(desc, x, x_strides, x_multi, xm_strides, packed_weights, out, workspace, workspace_bytes,
+                        stream, stage_events);
+}
+
+}  // extern "C"

@@ -1,0 +1,304 @@
+// tp_gemm.hip — the dense contractions of the TokenPacker path (99.98 % of its FLOPs)
+// as one hand-written MFMA kernel family for gfx950 (MI355X, CDNA4).
+//
+//   C[M,N] = epilogue( A[M,K] · W[N,K]^T )          A, W: bf16/fp16, K-contiguous (nn.Linear layout)
+//
+// Replaces the 11 nn.Linear / F.linear calls of reference
+// llava/model/multimodal_projector/builder.py:112,113,120,126-130,136 together with the GELU,
+// LayerNorm and dtype-cast kernels between them (fused into the epilogue).
+//
+// Structure (CDNA4-first, not a CUDA warp tiling):
+//   * 64-wide wavefronts, v_mfma_f32_16x16x32_{bf16,f16}, fp32 accumulate.
+//   * block tile BMxBNx64; A and W K-slabs are DMA'd HBM->LDS with global_load_lds_dwordx4
+//     (1 KiB per wave instruction = 8 rows x 128 B), double buffered, one barrier per K-slab.
+//   * LDS image is lane-linear (a DMA constraint), so the bank-conflict swizzle
+//     slot' = slot ^ (row & 7) is applied on the per-lane SOURCE address and again on the
+//     ds_read_b128 fragment address (same involution on both sides).
+//   * operands are swapped into the MFMA (W rows as the "A" fragment) so each lane ends up with
+//     4 CONSECUTIVE output columns of one row -> 8-byte packed stores, float4 bias loads.
+//   * XCD-aware tile order: the 8 XCDs own contiguous ranges of the tile list so that the tiles
+//     sharing an A row-panel hit the same private L2.
+//   * epilogue: LayerNorm-fold (a LayerNorm in front of the linear applied as
+//     rstd·(acc − mu·colsum) from per-row (sum, sumsq) partials), bias, exact-erf GELU,
+//     per-row (sum, sumsq) partials of the rounded output for the NEXT LayerNorm, cast.
+#include "tp_internal.h"
+#include <mutex>
+
+namespace tp {
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static __device__ __forceinline__ f32x4 run(bf16x8 a, bf16x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<f16_t> {
+    static __device__ __forceinline__ f32x4 run(f16x8 a, f16x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ float gelu_erf(float v) {
+    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+
+constexpr int BK = 64;             // K-slab in elements
+constexpr int ROW_BYTES = BK * 2;  // 128 B of K per tile row
+
+template <int BM, int BN>
+constexpr int gemm_lds_bytes() { return 2 * (BM + BN) * ROW_BYTES; }
+
+// STRIDED_A: A rows live in batches of rows_per_batch rows with a batch stride (the CLIP tower's
+// [:,1:] slices) — only the first K/V layer needs it, which also gives that launch (45 % of the path's
+// FLOPs) its own kernel symbol in profiles.
+template <typename T, int BM, int BN, int WM, int WN, bool STRIDED_A>
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
+gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
+    using X8 = typename Vec<T>::x8;
+    using X4 = typename Vec<T>::x4;
+    constexpr int NWM = BM / WM, NWN = BN / WN, NW = NWM * NWN;
+    constexpr int FM = WM / 16, FN = WN / 16;          // 16x16 fragments per wave
+    constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES, STAGE = A_BYTES + B_BYTES;
+    constexpr int CHUNKS = (BM + BN) / 8;              // 1 KiB DMA pieces per K-slab
+    constexpr int CPW = CHUNKS / NW;                   // pieces per wave
+    static_assert(CHUNKS % NW == 0, "DMA pieces must divide over the waves");
+    static_assert((BM / 8) % CPW == 0, "a wave's pieces must not straddle the A/W boundary");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+
+    // ---- tile assignment -----------------------------------------------------------------------
+    int bid = blockIdx.x;
+    if (xcd_swizzle) {   // bijective remap: XCD x (= bid % 8 by dispatch order) owns a contiguous range
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int g = blockIdx.y;
+
+    const char* __restrict__ Ag = p.A + g * p.a_gs;
+    const char* __restrict__ Wg = p.W + g * p.w_gs;
+
+    // ---- per-lane DMA source pointers ------------------------------------------------------------
+    // piece c covers tile rows 8c..8c+7 (A rows first, then W rows); lane -> row 8c + lane/8,
+    // LDS slot' = lane%8, logical K slot = slot' ^ (row & 7) = (lane%8) ^ (lane/8).
+    const int kslot = (lane & 7) ^ (lane >> 3);
+    const char* src[CPW];
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+        const int c = wave * CPW + i;
+        if (c < BM / 8) {
+            int row = m0 + c * 8 + (lane >> 3);
+            row = row < p.M ? row : p.M - 1;
+            if constexpr (STRIDED_A) {
+                const int b = row / p.rows_per_batch;
+                const int t = row - b * p.rows_per_batch;
+                src[i] = Ag + (long long)b * p.a_batch_stride_bytes + (long long)t * p.lda_bytes + kslot * 16;
+            } else {
+                src[i] = Ag + (long long)row * p.lda_bytes + kslot * 16;
+            }
+        } else {
+            const int n = n0 + (c - BM / 8) * 8 + (lane >> 3);
+            src[i] = Wg + (long long)n * p.K * 2 + kslot * 16;
+        }
+    }
+
+    auto issue = [&](int kt, int stage) {
+        char* dst = smem + stage * STAGE + wave * CPW * 1024;
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) {
+            __builtin_amdgcn_global_load_lds((gbl_void*)(src[i] + (long long)kt * ROW_BYTES),
+                                             (lds_void*)(dst + i * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets (swizzled) ---------------------------------------------------------
+    // fragment rows are 16-aligned, so row & 7 == lane & 7.
+    const int frag_off0 = (lane & 15) * ROW_BYTES + ((((lane >> 4)) ^ (lane & 7)) << 4);
+    const int frag_off1 = (lane & 15) * ROW_BYTES + (((4 + (lane >> 4)) ^ (lane & 7)) << 4);
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        // slab kt has landed for every wave; every wave is done reading the other buffer
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+
+        const char* sA = smem + (kt & 1) * STAGE + wm * WM * ROW_BYTES;
+        const char* sB = smem + (kt & 1) * STAGE + A_BYTES + wn * WN * ROW_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int off = ks ? frag_off1 : frag_off0;
+            X8 a[FM], b[FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) b[j] = *(const X8*)(sB + j * 16 * ROW_BYTES + off);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) a[i] = *(const X8*)(sA + i * 16 * ROW_BYTES + off);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = Mma<T>::run(b[j], a[i], acc[i][j]);   // swapped: lane gets 4 consecutive n
+        }
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------------
+    // acc[i][j][r] = C[m0 + wm*WM + i*16 + (lane&15)][n0 + wn*WN + j*16 + (lane>>4)*4 + r]
+    const int flags = p.flags;
+    const int col_base = n0 + wn * WN + (lane >> 4) * 4;
+    const float* __restrict__ bias = p.bias ? p.bias + g * p.bias_gs : nullptr;
+    const float* __restrict__ colsum = p.colsum ? p.colsum + g * p.colsum_gs : nullptr;
+    const float* __restrict__ stats_in = p.stats_in ? p.stats_in + g * p.stats_in_gs : nullptr;
+    char* __restrict__ Cg = p.C + g * p.c_gs;
+
+    f32x4 bias_v[FN], csum_v[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        bias_v[j] = bias ? *(const f32x4*)(bias + col_base + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+        csum_v[j] = (flags & TP_LINEAR_LN_FOLD) ? *(const f32x4*)(colsum + col_base + j * 16)
+                                                : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    float rs1[FM], rs2[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * WM + i * 16 + (lane & 15);
+        const bool row_ok = m < p.M;
+        float mu = 0.f, rstd = 1.f;
+        if (flags & TP_LINEAR_LN_FOLD) {
+            const int mc = row_ok ? m : p.M - 1;
+            float s1 = 0.f, s2 = 0.f;
+            for (int pp = 0; pp < p.stats_parts; ++pp) {
+                const float2 st = *(const float2*)(stats_in + ((long long)pp * p.M + mc) * 2);
+                s1 += st.x; s2 += st.y;
+            }
+            mu = s1 * p.inv_ln_dim;
+            const float var = fmaxf(s2 * p.inv_ln_dim - mu * mu, 0.f);
+            rstd = 1.0f / sqrtf(var + p.ln_eps);
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            f32x4 v = acc[i][j];
+            if (flags & TP_LINEAR_LN_FOLD) v = rstd * (v - mu * csum_v[j]);
+            v += bias_v[j];
+            if (flags & TP_LINEAR_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            }
+            const long long coff = (long long)m * p.ldc + col_base + j * 16;
+            if (flags & TP_LINEAR_OUT_F32) {
+                if (row_ok) *(f32x4*)((float*)Cg + coff) = v;
+            } else {
+                const X4 o = __builtin_convertvector(v, X4);
+                if (row_ok) *(X4*)((T*)Cg + coff) = o;
+                if (flags & TP_LINEAR_ROW_STATS) v = __builtin_convertvector(o, f32x4);  // stats of the ROUNDED values
+            }
+            if (flags & TP_LINEAR_ROW_STATS) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s1 += v[r]; s2 += v[r] * v[r]; }
+            }
+        }
+        rs1[i] = s1; rs2[i] = s2;
+    }
+
+    if (flags & TP_LINEAR_ROW_STATS) {
+        // reduce over the 4 lane groups that share a row, then over the NWN waves through LDS
+        float* red = (float*)smem;                 // [NWN][BM][2]
+        __syncthreads();                           // everyone is done with the K-slab buffers
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            float s1 = rs1[i], s2 = rs2[i];
+            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            if (lane < 16) {
+                const int rr = wm * WM + i * 16 + lane;
+                red[(wn * BM + rr) * 2 + 0] = s1;
+                red[(wn * BM + rr) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();
+        for (int rr = tid; rr < BM; rr += NW * 64) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWN; ++w) { s1 += red[(w * BM + rr) * 2]; s2 += red[(w * BM + rr) * 2 + 1]; }
+            const int m = m0 + rr;
+            if (m < p.M) {
+                float* so = p.stats_out + g * p.stats_out_gs + ((long long)tile_n * p.M + m) * 2;
+                *(float2*)so = make_float2(s1, s2);
+            }
+        }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------
+int gemm_pick_tile(int M, int N, int forced) {
+    if (forced == 0) forced = tuning(TP_TUNE_GEMM_TILE);
+    if (forced == 128) return 128;
+    if (forced == 256 && N % 256 == 0) return 256;
+    if (N % 256 != 0) return 128;
+    const long long tiles256 = (long long)((M + 255) / 256) * (N / 256);
+    return tiles256 >= 512 ? 256 : 128;     // >= 2 full waves of the 256 CUs, else finer tiles
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool STRIDED_A>
+static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
+    constexpr int lds = gemm_lds_bytes<BM, BN>();
+    constexpr int threads = (BM / WM) * (BN / WN) * 64;
+    auto kern = gemm_kernel<T, BM, BN, WM, WN, STRIDED_A>;
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [&] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    });
+    if (attr_err != hipSuccess) {
+        set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", lds, hipGetErrorString(attr_err));
+        return TP_ERR_LAUNCH;
+    }
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
+    dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)a.groups, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(threads), lds, stream, a, tiles_n, tuning(TP_TUNE_XCD_SWIZZLE));
+    return check_launch("gemm_kernel");
+}
+
+int gemm_launch(int dtype, const GemmArgs& a, hipStream_t stream) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.N % 128 != 0 || a.K % BK != 0) {
+        set_error("tp gemm: unsupported shape M=%d N=%d K=%d (need N%%128==0, K%%64==0)", a.M, a.N, a.K);
+        return TP_ERR_INVALID_ARG;
+    }
+    if ((a.flags & TP_LINEAR_ROW_STATS) && (a.flags & TP_LINEAR_OUT_F32)) {
+        set_error("tp gemm: ROW_STATS with OUT_F32 is not supported");
+        return TP_ERR_INVALID_ARG;
+    }
+    const int tile = gemm_pick_tile(a.M, a.N, a.tile);
+    const bool strided = a.rows_per_batch < a.M;
+    if (dtype != TP_BF16 && dtype != TP_F16) {
+        set_error("tp gemm: unsupported dtype %d", dtype);
+        return TP_ERR_INVALID_ARG;
+    }
+#define TP_GEMM_DISPATCH(T)                                                                        \
+    (tile == 256 ? (strided ? launch_cfg<T, 256, 256, 128, 64, true>(a, stream)                    \
+                            : launch_cfg<T, 256, 256, 128, 64, false>(a, stream))                  \
+                 : (strided ? launch_cfg<T, 128, 128, 64, 64, true>(a, stream)                     \
+                            : launch_cfg<T, 128, 128, 64, 64, false>(a, stream)))
+    return dtype == TP_BF16 ? TP_GEMM_DISPATCH(bf16_t) : TP_GEMM_DISPATCH(f16_t);
+#undef TP_GEMM_DISPATCH
+}
+
+}  // namespace tp

@@ -1,0 +1,88 @@
+// Internal declarations shared by the HIP translation units of libtokenpacker_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/tokenpacker.h"
+
+namespace tp {
+
+// ---- fixed geometry of the path (reference builder.py:40-49, 61, 67) --------------------------
+constexpr int kEmbed = 1024;     // embed_dim == kv_dim == CLIP width
+constexpr int kMulti = 4096;     // 4 CLIP layers concatenated
+constexpr int kHeads = 8;
+constexpr int kHeadDim = 128;
+
+using bf16_t = __bf16;
+using f16_t = _Float16;
+using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
+using bf16x4 = __bf16 __attribute__((ext_vector_type(4)));
+using f16x8 = _Float16 __attribute__((ext_vector_type(8)));
+using f16x4 = _Float16 __attribute__((ext_vector_type(4)));
+using f32x4 = float __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Vec;
+template <> struct Vec<bf16_t> { using x8 = bf16x8; using x4 = bf16x4; };
+template <> struct Vec<f16_t> { using x8 = f16x8; using x4 = f16x4; };
+
+// ---- error plumbing ---------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);      // hipGetLastError -> TP_ERR_LAUNCH
+
+// ---- tuning table (tp_set_tuning) -------------------------------------------------------------
+int tuning(int key);
+
+// ---- GEMM (tp_gemm.hip) -----------------------------------------------------------------------
+// C[g][M,N] = epilogue(A[g][M,K] * W[g][N,K]^T) for g in [0, groups)
+struct GemmArgs {
+    const char* A; const char* W; char* C;
+    const float* bias; const float* stats_in; const float* colsum; float* stats_out;
+    long long a_batch_stride_bytes;   // between batches of rows_per_batch rows
+    long long lda_bytes;              // between rows inside a batch
+    long long ldc;                    // elements
+    // per-group strides (bytes for A/W/C, floats for the fp32 side arrays)
+    long long a_gs, w_gs, c_gs, bias_gs, stats_in_gs, colsum_gs, stats_out_gs;
+    int M, N, K;
+    int rows_per_batch;
+    int flags;                        // TP_LINEAR_*
+    int stats_parts;
+    float inv_ln_dim, ln_eps;
+    int groups;
+    int tile;                         // 0 auto, 128, 256
+};
+int gemm_launch(int dtype, const GemmArgs& a, hipStream_t stream);
+int gemm_pick_tile(int M, int N, int forced);     // -> 128 or 256
+inline int gemm_stats_parts(int M, int N, int forced) { return N / gemm_pick_tile(M, N, forced); }
+
+// ---- small kernels (tp_kernels.hip) -----------------------------------------------------------
+int point_queries_launch(int dtype, const void* x, const int64_t st[3], void* q0, int B, int grid,
+                         int s, hipStream_t stream);
+int region_attention_launch(int dtype, const void* q, const void* k, const void* v, void* o, int B,
+                            int grid, int s, hipStream_t stream);
+int pack_cast_f32_launch(int dtype, const void* src, float* dst, int n, hipStream_t stream);
+int pack_ln_fold_launch(int dtype, const void* w, const void* bias, const void* gamma,
+                        const void* beta, void* w_out, float* colsum, float* bias_out, int n_out,
+                        int n_in, hipStream_t stream);
+
+// ---- packed-weight and workspace layouts (tp_api.hip) -----------------------------------------
+struct PackedLayout {
+    size_t w_kv0, b_kv0;          // [2048,4096] T, [2048] f32
+    size_t w_kv2, b_kv2;          // [2][1024,1024] T, [2][1024] f32
+    size_t w_q1;                  // [1024,1024] T
+    size_t w_in_kv, c_in_kv, b_in_kv;   // LN-folded in-proj for k, v: [2][1024,1024] T, [2][1024] f32 x2
+    size_t w_in_q, c_in_q, b_in_q;      // LN-folded in-proj for q
+    size_t w_out, b_out;          // [1024,1024] T, [1024] f32
+    size_t w_m0, b_m0;            // [D,1024] T, [D] f32
+    size_t w_m2, b_m2;            // [D,D] T, [D] f32
+    size_t total;
+};
+PackedLayout packed_layout(int D);
+
+struct WorkspaceLayout {
+    size_t q0, hkv, h2, stats_kv, kv, q1pre, stats_q, q, o, a1, a2;
+    size_t total;
+    int stats_parts_kv, stats_parts_q;
+};
+WorkspaceLayout workspace_layout(int B, int grid, int s, int D);
+
+}  // namespace tp

@@ -1,0 +1,244 @@
+// tp_kernels.hip — the HBM-bound pieces of the TokenPacker path for gfx950:
+//   * point_queries_kernel   : fp32 bilinear downsample -> coarse point queries  (builder.py:117-118)
+//   * region_attention_kernel: region gather + 8-head softmax(q·K^T/sqrt(d))·V with ONE query per
+//                              region (builder.py:96-105, 122-130)
+//   * pack_* kernels          : one-time weight preparation (LayerNorm fold, fp32 biases)
+// All loads/stores are 16 B per lane, 64-lane coalesced (1 KiB per wave instruction).
+#include "tp_internal.h"
+
+namespace tp {
+
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&f)[8]) {
+    using X8 = typename Vec<T>::x8;
+    const X8 v = *(const X8*)p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&f)[8]) {
+    using X8 = typename Vec<T>::x8;
+    X8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (T)f[i];
+    *(X8*)p = v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Coarse point queries.  F.interpolate(bilinear, align_corners=False) from g x g to G x G with the
+// integer ratio s = g/G: src = (i + 0.5)*s - 0.5, so for even s the two taps are rows s*i+s/2-1 and
+// s*i+s/2 with weights 0.5/0.5, for odd s the single tap s*i+(s-1)/2 with weight 1 (SURVEY.md §8a:
+// s=2 2x2 mean, s=3 centre pixel, s=4 inner 2x2 mean).  Arithmetic in fp32 in PyTorch's tap order,
+// result rounded once to T (builder.py:117-118).  One thread = 8 channels of one query.
+template <typename T>
+__global__ void __launch_bounds__(256)
+point_queries_kernel(const T* __restrict__ x, long long sb, long long st, T* __restrict__ q0,
+                     int B, int g, int s, int C) {
+    const int G = g / s, M = G * G, vecs = C / 8;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)B * M * vecs) return;
+    const int cv = (int)(gid % vecs);
+    const long long qm = gid / vecs;
+    const int m = (int)(qm % M), b = (int)(qm / M);
+    const int i = m / G, j = m % G;
+    const T* xb = x + b * sb + cv * 8;
+    float out[8];
+    if (s & 1) {
+        const int r = s * i + (s - 1) / 2, c = s * j + (s - 1) / 2;
+        load8(xb + (long long)(r * g + c) * st, out);
+    } else {
+        const int r = s * i + s / 2 - 1, c = s * j + s / 2 - 1;
+        float a00[8], a01[8], a10[8], a11[8];
+        load8(xb + (long long)(r * g + c) * st, a00);
+        load8(xb + (long long)(r * g + c + 1) * st, a01);
+        load8(xb + (long long)((r + 1) * g + c) * st, a10);
+        load8(xb + (long long)((r + 1) * g + c + 1) * st, a11);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            out[e] = 0.5f * (0.5f * a00[e] + 0.5f * a01[e]) + 0.5f * (0.5f * a10[e] + 0.5f * a11[e]);
+    }
+    store8(q0 + qm * C + cv * 8, out);
+}
+
+int point_queries_launch(int dtype, const void* x, const int64_t st[3], void* q0, int B, int grid,
+                         int s, hipStream_t stream) {
+    const int G = grid / s, M = G * G;
+    const long long total = (long long)B * M * (kEmbed / 8);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (dtype == TP_BF16)
+        hipLaunchKernelGGL(point_queries_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream,
+                           (const bf16_t*)x, (long long)st[0], (long long)st[1], (bf16_t*)q0, B, grid, s, kEmbed);
+    else
+        hipLaunchKernelGGL(point_queries_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream,
+                           (const f16_t*)x, (long long)st[0], (long long)st[1], (f16_t*)q0, B, grid, s, kEmbed);
+    return check_launch("point_queries_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Region-to-point attention.  One wavefront per coarse query (B*M of them), four per workgroup.
+// E = 1024 = 64 lanes x 16 elements: lane l owns elements [8l, 8l+8) (head l>>4) and
+// [512+8l, 512+8l+8) (head 4 + (l>>4)), so every global access is a fully coalesced 1 KiB wave
+// transaction and each head's 128-wide dot product is a 16-lane butterfly.  The s*s keys of the
+// region (token (i*s+a)*g + j*s+b — the reference's divide_feature order, builder.py:96-105; the
+// order is irrelevant to softmax·V) are streamed in groups of 4 straight into registers: every K/V
+// row is used by exactly one query, so staging it in LDS would be pure overhead (guide: operand
+// streamed once and not shared -> load straight to VGPRs).  Softmax is fp32, online across groups,
+// which makes the kernel valid for any s dividing the grid (s*s from 1 to 576 keys).
+template <typename T>
+__global__ void __launch_bounds__(256)
+region_attention_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                        T* __restrict__ o, int B, int g, int s, float scale) {
+    constexpr int E = kEmbed;
+    const int lane = threadIdx.x & 63;
+    const int G = g / s, M = G * G, N = g * g, S2 = s * s;
+    const long long qi = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= (long long)B * M) return;
+    const int b = (int)(qi / M), m = (int)(qi % M);
+    const int i = m / G, j = m % G;
+    const int ea = lane * 8, eb = 512 + lane * 8;
+
+    float qa[8], qb[8];
+    load8(q + qi * E + ea, qa);
+    load8(q + qi * E + eb, qb);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { qa[e] *= scale; qb[e] *= scale; }
+
+    const T* kb = k + (long long)b * N * E;
+    const T* vb = v + (long long)b * N * E;
+
+    float run_max_a = -INFINITY, run_max_b = -INFINITY, den_a = 0.f, den_b = 0.f;
+    float acc_a[8], acc_b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { acc_a[e] = 0.f; acc_b[e] = 0.f; }
+
+    constexpr int KU = 4;
+    for (int k0 = 0; k0 < S2; k0 += KU) {
+        float la[KU], lb[KU];
+        long long row[KU];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int kk = (k0 + u < S2) ? k0 + u : S2 - 1;     // clamp: masked below
+            const int a = kk / s, c = kk - a * s;
+            row[u] = (long long)((i * s + a) * g + j * s + c) * E;
+            float ka[8], kbv[8];
+            load8(kb + row[u] + ea, ka);
+            load8(kb + row[u] + eb, kbv);
+            float da = 0.f, db = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { da = fmaf(qa[e], ka[e], da); db = fmaf(qb[e], kbv[e], db); }
+            la[u] = da; lb[u] = db;
+        }
+        // 16-lane butterflies: every lane of a head group ends with the full 128-wide dot product
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                la[u] += __shfl_xor(la[u], off);
+                lb[u] += __shfl_xor(lb[u], off);
+            }
+        }
+        float gmax_a = run_max_a, gmax_b = run_max_b;
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            if (k0 + u < S2) { gmax_a = fmaxf(gmax_a, la[u]); gmax_b = fmaxf(gmax_b, lb[u]); }
+        }
+        const float resc_a = __expf(run_max_a - gmax_a), resc_b = __expf(run_max_b - gmax_b);  // exp(-inf)=0 first time
+        den_a *= resc_a; den_b *= resc_b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { acc_a[e] *= resc_a; acc_b[e] *= resc_b; }
+        run_max_a = gmax_a; run_max_b = gmax_b;
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            if (k0 + u < S2) {
+                const float pa = __expf(la[u] - run_max_a), pb = __expf(lb[u] - run_max_b);
+                den_a += pa; den_b += pb;
+                float va[8], vbv[8];
+                load8(vb + row[u] + ea, va);
+                load8(vb + row[u] + eb, vbv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { acc_a[e] = fmaf(pa, va[e], acc_a[e]); acc_b[e] = fmaf(pb, vbv[e], acc_b[e]); }
+            }
+        }
+    }
+    const float inv_a = 1.0f / den_a, inv_b = 1.0f / den_b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { acc_a[e] *= inv_a; acc_b[e] *= inv_b; }
+    store8(o + qi * E + ea, acc_a);
+    store8(o + qi * E + eb, acc_b);
+}
+
+int region_attention_launch(int dtype, const void* q, const void* k, const void* v, void* o, int B,
+                            int grid, int s, hipStream_t stream) {
+    const int G = grid / s, M = G * G;
+    const long long nq = (long long)B * M;
+    const unsigned blocks = (unsigned)((nq + 3) / 4);
+    const float scale = 0.08838834764831845f;   // 1/sqrt(128): q scaling of F.multi_head_attention_forward
+    if (dtype == TP_BF16)
+        hipLaunchKernelGGL(region_attention_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream,
+                           (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, B, grid, s, scale);
+    else
+        hipLaunchKernelGGL(region_attention_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream,
+                           (const f16_t*)q, (const f16_t*)k, (const f16_t*)v, (f16_t*)o, B, grid, s, scale);
+    return check_launch("region_attention_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// One-time weight preparation.
+template <typename T>
+__global__ void pack_cast_f32_kernel(const T* __restrict__ src, float* __restrict__ dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
+}
+
+int pack_cast_f32_launch(int dtype, const void* src, float* dst, int n, hipStream_t stream) {
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (dtype == TP_BF16)
+        hipLaunchKernelGGL(pack_cast_f32_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)src, dst, n);
+    else
+        hipLaunchKernelGGL(pack_cast_f32_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream, (const f16_t*)src, dst, n);
+    return check_launch("pack_cast_f32_kernel");
+}
+
+// LayerNorm folded into the linear that follows it.  For y = LN(h)·W^T + b with
+// LN(h) = (h − mu)·rstd·gamma + beta:
+//     y_n = rstd·( Σ_k h_k W'_nk − mu·c_n ) + b'_n,   W'_nk = W_nk·gamma_k (rounded to T),
+//     c_n = Σ_k W'_nk (of the ROUNDED W', so the mean term cancels exactly),  b'_n = Σ_k beta_k W_nk + b_n.
+// One workgroup per output row n.
+template <typename T>
+__global__ void __launch_bounds__(256)
+pack_ln_fold_kernel(const T* __restrict__ w, const T* __restrict__ bias, const T* __restrict__ gamma,
+                    const T* __restrict__ beta, T* __restrict__ w_out, float* __restrict__ colsum,
+                    float* __restrict__ bias_out, int n_in) {
+    const int n = blockIdx.x;
+    float cs = 0.f, bs = 0.f;
+    for (int kk = threadIdx.x; kk < n_in; kk += blockDim.x) {
+        const float wv = (float)w[(long long)n * n_in + kk];
+        const T wp = (T)(wv * (float)gamma[kk]);
+        w_out[(long long)n * n_in + kk] = wp;
+        cs += (float)wp;
+        bs = fmaf((float)beta[kk], wv, bs);
+    }
+    __shared__ float red[2][4];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { cs += __shfl_xor(cs, off); bs += __shfl_xor(bs, off); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = cs; red[1][threadIdx.x >> 6] = bs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        colsum[n] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        bias_out[n] = red[1][0] + red[1][1] + red[1][2] + red[1][3] + (float)bias[n];
+    }
+}
+
+int pack_ln_fold_launch(int dtype, const void* w, const void* bias, const void* gamma,
+                        const void* beta, void* w_out, float* colsum, float* bias_out, int n_out,
+                        int n_in, hipStream_t stream) {
+    if (dtype == TP_BF16)
+        hipLaunchKernelGGL(pack_ln_fold_kernel<bf16_t>, dim3(n_out), dim3(256), 0, stream,
+                           (const bf16_t*)w, (const bf16_t*)bias, (const bf16_t*)gamma, (const bf16_t*)beta,
+                           (bf16_t*)w_out, colsum, bias_out, n_in);
+    else
+        hipLaunchKernelGGL(pack_ln_fold_kernel<f16_t>, dim3(n_out), dim3(256), 0, stream,
+                           (const f16_t*)w, (const f16_t*)bias, (const f16_t*)gamma, (const f16_t*)beta,
+                           (f16_t*)w_out, colsum, bias_out, n_in);
+    return check_launch("pack_ln_fold_kernel");
+}
+
+}  // namespace tp

@@ -1,0 +1,215 @@
+"""Drop-in ``TokenPacker`` projector backed by hand-written HIP kernels for MI355X (gfx950).
+
+Boundary mirrored: reference
+``llava/model/multimodal_projector/builder.py:39-145`` —
+
+* same constructor signature and defaults as the reference ``TokenPacker`` (builder.py:40-49);
+* same 23 parameters under the same state-dict names (so ``load_state_dict`` of a reference
+  ``mm_projector.bin`` works unchanged, llava_arch.py:78-83) — the parameters live in ordinary
+  ``nn.Linear`` / ``nn.LayerNorm`` / ``nn.MultiheadAttention`` containers, which this module never
+  *calls*;
+* ``forward(x, attn_mask=None)`` takes the tuple ``(x, x_multi)`` the CLIP tower returns
+  (clip_encoder.py:62) and yields ``[B, (raw_grid//scale_factor)**2, hidden_size]`` in ``x[0]``'s
+  dtype on ``x[0]``'s device (builder.py:107-137), so it can sit behind the unmodified
+  ``encode_images()`` (llava_arch.py:95-98);
+* ``build_vision_projector(config)`` reads ``config.hidden_size`` / ``config.scale_factor``
+  exactly like builder.py:144-145.
+
+All arithmetic happens in ``libtokenpacker_hip.so`` through the C ABI of
+``include/tokenpacker.h``; torch only owns memory and the stream.  There is no eager / CPU
+fallback: CPU tensors, unsupported dtypes or a missing library raise.
+"""
+from __future__ import annotations
+
+import ctypes
+from functools import partial
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _capi
+
+_DTYPES = {torch.bfloat16: _capi.TP_BF16, torch.float16: _capi.TP_F16}
+
+
+class TokenPacker(nn.Module):
+    """Region-to-point visual projector (see module docstring)."""
+
+    MULTI_LEVEL_DIM = 4096      # builder.py:61,67 hard-code nn.Linear(4096, 1024)
+
+    def __init__(self, raw_grid: int = 24, embed_dim: int = 1024, num_heads: int = 1024 // 128,
+                 kv_dim: int = 1024, hidden_size: int = 4096, scale_factor: int = 2,
+                 norm_layer=partial(nn.LayerNorm, eps=1e-6)):
+        super().__init__()
+        if raw_grid % scale_factor != 0:
+            # same exception type and message as builder.py:51-52
+            raise ValueError("scale_factor must be divisible by grid size")
+        if embed_dim != 1024 or kv_dim != 1024 or num_heads != 8:
+            raise ValueError("the HIP kernels are specialised for embed_dim=kv_dim=1024, num_heads=8 "
+                             "(the only configuration the reference instantiates)")
+        if hidden_size % 128 != 0:
+            raise ValueError("hidden_size must be a multiple of 128")
+        self.raw_grid = raw_grid
+        self.grid_size = raw_grid // scale_factor
+        self.num_queries = self.grid_size ** 2
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.scale_factor = scale_factor
+        self.hidden_size = hidden_size
+
+        # ---- parameter containers (names/shapes are the state-dict contract) ----
+        self.q_proj_1 = nn.Linear(kv_dim, embed_dim, bias=False)
+        self.k_proj_1 = nn.Sequential(nn.Linear(self.MULTI_LEVEL_DIM, 1024), nn.GELU(), nn.Linear(1024, 1024))
+        self.v_proj_1 = nn.Sequential(nn.Linear(self.MULTI_LEVEL_DIM, 1024), nn.GELU(), nn.Linear(1024, 1024))
+        self.ln_q_1 = norm_layer(embed_dim)
+        self.ln_k_1 = norm_layer(embed_dim)
+        self.ln_v_1 = norm_layer(embed_dim)
+        self.clip_attn = nn.MultiheadAttention(embed_dim, num_heads)
+        self.mlp = nn.Sequential(nn.Linear(1024, hidden_size), nn.GELU(), nn.Linear(hidden_size, hidden_size))
+        self._reset_parameters()
+
+        #: set True to receive fp32 output straight from the last GEMM's accumulators
+        #: (validation mode of SURVEY.md §8c; default = input dtype like the reference)
+        self.output_fp32 = False
+        self._packed: Optional[torch.Tensor] = None
+        self._packed_key = None
+        self._workspaces: Dict[Tuple[int, int], torch.Tensor] = {}
+
+    # ------------------------------------------------------------------------------------------
+    def _reset_parameters(self) -> None:
+        """Same initial distribution as the reference (builder.py:87-94): truncated normal
+        (std 0.02) for every nn.Linear weight (out_proj included), zero biases, unit LayerNorm;
+        ``clip_attn.in_proj_weight`` keeps nn.MultiheadAttention's own xavier init."""
+        for mod in self.modules():
+            if isinstance(mod, nn.Linear):
+                nn.init.trunc_normal_(mod.weight, std=0.02)
+                if mod.bias is not None:
+                    nn.init.zeros_(mod.bias)
+            elif isinstance(mod, nn.LayerNorm):
+                nn.init.ones_(mod.weight)
+                nn.init.zeros_(mod.bias)
+
+    # ------------------------------------------------------------------------------------------
+    def _named_weights(self):
+        sd = dict(self.named_parameters())
+        return [sd[name] for name in _capi.WEIGHT_FIELDS]
+
+    def _ln_eps(self) -> float:
+        return float(self.ln_q_1.eps)
+
+    def _ensure_packed(self, dtype: torch.dtype, device: torch.device, stream_ptr: int) -> torch.Tensor:
+        """(Re)build the kernel-side weight image when any parameter storage or version changed
+        (optimizer step, load_state_dict, .to())."""
+        weights = self._named_weights()
+        key = (dtype, device, tuple((w.data_ptr(), w._version) for w in weights))
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        for name, w in zip(_capi.WEIGHT_FIELDS, weights):
+            if w.dtype != dtype or w.device != device:
+                raise TypeError(f"parameter {name} is {w.dtype} on {w.device}; inputs are {dtype} on {device} "
+                                f"(cast the module with .to(...) like the reference does)")
+        lib = _capi.load_library()
+        desc = _capi.make_desc(1, self.raw_grid, self.scale_factor, self.hidden_size, _DTYPES[dtype],
+                               ln_eps=self._ln_eps())
+        nbytes = lib.tp_packed_weight_bytes(ctypes.byref(desc))
+        if nbytes == 0:
+            raise RuntimeError(f"tp_packed_weight_bytes: {_capi.last_error()}")
+        packed = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        contiguous = [w.detach().contiguous() for w in weights]      # keeps temporaries alive until enqueued
+        raw = _capi.tp_weights(*[t.data_ptr() for t in contiguous])
+        _capi.check(lib.tp_pack_weights(ctypes.byref(desc), ctypes.byref(raw), packed.data_ptr(), nbytes,
+                                        stream_ptr), "tp_pack_weights")
+        self._packed, self._packed_key = packed, key
+        return packed
+
+    def _workspace(self, nbytes: int, device: torch.device, stream_ptr: int) -> torch.Tensor:
+        key = (device.index if device.index is not None else -1, stream_ptr)
+        ws = self._workspaces.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self._workspaces[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, x, attn_mask=None, _stage_events=None):
+        if attn_mask is not None:
+            raise NotImplementedError("attn_mask is always None on the reference path (llava_arch.py:97)")
+        x_multi = x[1]      # multi-level [B, N, 4096]
+        x = x[0]            # single-level [B, N, 1024]
+        if not (x.is_cuda and x_multi.is_cuda):
+            raise RuntimeError("tokenpacker_amd.TokenPacker runs only on an AMD GPU (HIP kernels); "
+                               "there is no CPU fallback")
+        if x.dtype not in _DTYPES or x_multi.dtype != x.dtype:
+            raise TypeError(f"supported dtypes: bfloat16 / float16 for both inputs (got {x.dtype}, {x_multi.dtype})")
+        N = self.raw_grid * self.raw_grid
+        if x.dim() != 3 or x_multi.dim() != 3 or x.shape[1] != N or x_multi.shape[1] != N \
+                or x.shape[2] != self.embed_dim or x_multi.shape[2] != self.MULTI_LEVEL_DIM \
+                or x.shape[0] != x_multi.shape[0]:
+            raise ValueError(f"expected x [B,{N},{self.embed_dim}] and x_multi [B,{N},{self.MULTI_LEVEL_DIM}], "
+                             f"got {tuple(x.shape)} and {tuple(x_multi.shape)}")
+        if torch.is_grad_enabled() and (x.requires_grad or x_multi.requires_grad
+                                        or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError(
+                "the HIP projector is forward-only for now (backward is the next scope row, SURVEY.md §8f-1): "
+                "call it under torch.no_grad()/inference_mode() or freeze it with requires_grad_(False)")
+
+        B = x.shape[0]
+        device = x.device
+        # the kernels take element strides (tower outputs are [:,1:] slices); only fix layouts they cannot address
+        x = self._addressable(x)
+        x_multi = self._addressable(x_multi)
+
+        with torch.cuda.device(device):
+            stream_ptr = torch.cuda.current_stream(device).cuda_stream
+            lib = _capi.load_library()
+            packed = self._ensure_packed(x.dtype, device, stream_ptr)
+            out_dtype = torch.float32 if self.output_fp32 else x.dtype
+            desc = _capi.make_desc(B, self.raw_grid, self.scale_factor, self.hidden_size, _DTYPES[x.dtype],
+                                   _capi.TP_F32 if self.output_fp32 else _DTYPES[x.dtype], self._ln_eps())
+            ws_bytes = lib.tp_workspace_bytes(ctypes.byref(desc))
+            if ws_bytes == 0:
+                raise RuntimeError(f"tp_workspace_bytes: {_capi.last_error()}")
+            ws = self._workspace(ws_bytes, device, stream_ptr)
+            out = torch.empty(B, self.num_queries, self.hidden_size, dtype=out_dtype, device=device)
+            if _stage_events is None:
+                _capi.check(lib.tp_forward(ctypes.byref(desc),
+                                           x.data_ptr(), _capi.strides3(x.stride()),
+                                           x_multi.data_ptr(), _capi.strides3(x_multi.stride()),
+                                           packed.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                           stream_ptr), "tp_forward")
+            else:
+                handles = (ctypes.c_void_p * len(_stage_events))(*[ev.cuda_event for ev in _stage_events])
+                _capi.check(lib.tp_forward_staged(ctypes.byref(desc),
+                                                  x.data_ptr(), _capi.strides3(x.stride()),
+                                                  x_multi.data_ptr(), _capi.strides3(x_multi.stride()),
+                                                  packed.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                  stream_ptr, handles, len(_stage_events)), "tp_forward_staged")
+        return out
+
+    def forward_staged(self, x):
+        """Forward that also times every kernel of the schedule with HIP events recorded by the
+        library on the launch stream (``tp_forward_staged``).  Returns ``(out, events)``; after a
+        synchronize, ``events[i].elapsed_time(events[i+1])`` is stage i's duration in ms
+        (names: ``_capi.STAGE_NAMES``).  Benchmark / profiling aid."""
+        events = [torch.cuda.Event(enable_timing=True) for _ in range(_capi.TP_NUM_STAGES + 1)]
+        stream = torch.cuda.current_stream(x[0].device)
+        for ev in events:            # force creation of the underlying hipEvent_t
+            ev.record(stream)
+        out = self.forward(x, _stage_events=events)
+        return out, events
+
+    @staticmethod
+    def _addressable(t: torch.Tensor) -> torch.Tensor:
+        ok = (t.stride(2) == 1 and t.stride(1) % 8 == 0 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0)
+        return t if ok else t.contiguous()
+
+    def extra_repr(self) -> str:
+        return (f"raw_grid={self.raw_grid}, scale_factor={self.scale_factor}, "
+                f"num_queries={self.num_queries}, hidden_size={self.hidden_size}, backend=hip/gfx950")
+
+
+def build_vision_projector(config, **kwargs):
+    """Twin of the reference factory (builder.py:144-145): reads ``hidden_size`` and
+    ``scale_factor`` only; ``mm_projector_type`` is ignored there too."""
+    return TokenPacker(hidden_size=config.hidden_size, scale_factor=config.scale_factor)

@@ -1,0 +1,106 @@
+"""Batch sharding of the projector across the GPUs of one MI355X node.
+
+The path is embarrassingly parallel over images / HD crops: no op mixes batch elements, weights
+(73 MB) are replicated.  One process per GPU (``torch.distributed``, backend ``nccl`` = RCCL over
+xGMI on ROCm; ``gloo`` in the CPU tests).  The ONLY data-path collective is one all-gather of the
+projected tokens ``[b_r, M, D]`` so that every rank holds ``[B, M, D]`` "before the LLM"
+(BASELINE.json north_star).  The reference has no counterpart (it never calls
+torch.distributed); this is new design.
+
+xGMI is a full mesh of point-to-point links (7 x ~153 GB/s per GPU), so the gather is issued as a
+single large ``all_gather_into_tensor`` (one RCCL call over all links) instead of per-rank
+broadcasts; ``overlap_chunks > 1`` splits the local batch so the gather of chunk i overlaps the
+kernels of chunk i+1 (RCCL runs on its own stream).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced slice [lo, hi) of ``total`` items for ``rank``: the first
+    ``total % world_size`` ranks get one extra item (HD crop lists are rarely divisible)."""
+    if world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError(f"bad rank {rank} / world_size {world_size}")
+    base, rem = divmod(total, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_sizes(total: int, world_size: int) -> List[int]:
+    return [shard_bounds(total, world_size, r)[1] - shard_bounds(total, world_size, r)[0]
+            for r in range(world_size)]
+
+
+def local_shard(t: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """This rank's slice of a replicated batch tensor (dim 0), as a view (no copy)."""
+    ws, rk = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = shard_bounds(t.shape[0], ws, rk)
+    return t[lo:hi]
+
+
+def all_gather_tokens(local: torch.Tensor, total: int, group: Optional[dist.ProcessGroup] = None,
+                      out: Optional[torch.Tensor] = None, async_op: bool = False):
+    """Gather ``local [b_r, M, D]`` from every rank into ``[total, M, D]`` (rank order = batch
+    order).  Equal shards use one ``all_gather_into_tensor`` straight into the output; ragged
+    shards are padded to the largest shard first and trimmed after (one collective either way).
+    Returns ``out`` (and the work handle when ``async_op``)."""
+    ws = dist.get_world_size(group)
+    sizes = shard_sizes(total, ws)
+    b_max = max(sizes)
+    tail = tuple(local.shape[1:])
+    if local.shape[0] != sizes[dist.get_rank(group)]:
+        raise ValueError(f"local batch {local.shape[0]} != expected shard {sizes[dist.get_rank(group)]}")
+    local = local.contiguous()
+    if min(sizes) == b_max:
+        if out is None:
+            out = torch.empty((total,) + tail, dtype=local.dtype, device=local.device)
+        work = dist.all_gather_into_tensor(out, local, group=group, async_op=async_op)
+        return (out, work) if async_op else out
+    # ragged: pad, gather, compact
+    padded = torch.zeros((b_max,) + tail, dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    buf = torch.empty((ws * b_max,) + tail, dtype=local.dtype, device=local.device)
+    work = dist.all_gather_into_tensor(buf, padded, group=group, async_op=False)
+    pieces = [buf[r * b_max: r * b_max + sizes[r]] for r in range(ws)]
+    gathered = torch.cat(pieces, dim=0)
+    if out is not None:
+        out.copy_(gathered)
+        gathered = out
+    return (gathered, work) if async_op else gathered
+
+
+def project_sharded(project: Callable[[Tuple[torch.Tensor, torch.Tensor]], torch.Tensor],
+                    x_local: torch.Tensor, xm_local: torch.Tensor, total: int,
+                    group: Optional[dist.ProcessGroup] = None, gather: bool = True,
+                    overlap_chunks: int = 1) -> torch.Tensor:
+    """Run ``project((x, x_multi))`` on this rank's shard and (optionally) all-gather.
+
+    ``project`` is any callable with the projector's forward contract (the HIP ``TokenPacker``
+    in production; the CPU tests inject a stand-in).  With ``overlap_chunks > 1`` and equal
+    shards, the local shard is processed in chunks and each chunk's gather is launched
+    asynchronously so it overlaps the next chunk's kernels."""
+    ws = dist.get_world_size(group) if dist.is_initialized() else 1
+    if not gather or ws == 1:
+        return project((x_local, xm_local))
+    sizes = shard_sizes(total, ws)
+    b = x_local.shape[0]
+    equal = min(sizes) == max(sizes)
+    if overlap_chunks <= 1 or not equal or b % overlap_chunks != 0:
+        return all_gather_tokens(project((x_local, xm_local)), total, group)
+    cb = b // overlap_chunks
+    outs, works = [], []
+    for c in range(overlap_chunks):
+        y = project((x_local[c * cb:(c + 1) * cb], xm_local[c * cb:(c + 1) * cb]))
+        o, w = all_gather_tokens(y, cb * ws, group, async_op=True)
+        outs.append(o)
+        works.append(w)
+    for w in works:
+        w.wait()
+    # outs[c] is [ws*cb, M, D] in rank order; interleave back to batch order
+    M, D = outs[0].shape[1:]
+    stacked = torch.stack([o.view(ws, cb, M, D) for o in outs], dim=1)      # [ws, chunks, cb, M, D]
+    return stacked.reshape(total, M, D)
