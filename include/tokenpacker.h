@@ -142,12 +142,17 @@ int tp_forward_staged(const tp_desc* desc,
 
 /* ---- per-kernel entry points (used by the parity tests; same kernels tp_forward launches) ---- */
 
-/* Coarse point queries: fp32 bilinear (align_corners=False) g*g -> (g/s)^2, cast back to dtype.
- * Replaces builder.py:117-118.  q0 is [B, M, 1024] contiguous. */
+/* NUMERICS NOTE for the per-kernel entry points: activations BETWEEN kernels are always fp16,
+ * whatever desc.dtype is (bf16 models: weights/inputs widen to fp16 exactly; keeping fp16
+ * intermediates is what brings the bf16 path within 1e-3 of exact math, DESIGN.md "Numerics").
+ *
+ * Coarse point queries: fp32 bilinear (align_corners=False) g*g -> (g/s)^2, rounded once to
+ * desc.dtype (the reference's cast, builder.py:117-118) and stored as fp16.
+ * x has element type desc.dtype; q0 is fp16 [B, M, 1024] contiguous. */
 int tp_point_queries(const tp_desc* desc, const void* x, const int64_t x_strides[3], void* q0,
                      void* stream);
 
-/* Region-to-point attention core on projected tensors (post in-proj, pre out-proj):
+/* Region-to-point attention core on projected tensors (post in-proj, pre out-proj), all fp16:
  *   q [B, M, 1024], k and v [B, g*g, 1024] contiguous; o [B, M, 1024].
  * 8 heads x d=128, logits scaled by 1/sqrt(128), softmax over the s*s tokens of the query's own
  * region.  Replaces divide_feature (builder.py:96-105, 122-124) + the bmm/softmax/bmm of
@@ -158,21 +163,23 @@ int tp_region_attention(const tp_desc* desc, const void* q, const void* k, const
 /* Generic fused linear used for every dense contraction of the path (11 nn.Linear calls of
  * builder.py:112,113,120,126-130,136):  C[M,N] = epilogue(A[M,K] · W[N,K]^T).
  * flags: TP_LINEAR_* below.  `bias` fp32 [N] or NULL.  With TP_LINEAR_LN_FOLD the epilogue applies
- * a LayerNorm that precedes the linear: C = rstd_m·(acc − mu_m·colsum_n) + bias_n, (mu, rstd) taken
- * from `row_stats_in` = [stats_parts][M][2] partial (sum, sum of squares) over ln_dim columns.
- * With TP_LINEAR_ROW_STATS the kernel writes such partials of ITS output to `row_stats_out`
- * ([N/stats_tile_n][M][2]; query the tile with tp_linear_stats_parts()). */
+ * a LayerNorm that precedes the linear: C = rstd_m·(acc − mu_m·colsum_n) + bias_n, with
+ * `row_mean_rstd` = fp32 [M][2] (mean, rstd) per row of A, produced by tp_ln_finalize().
+ * With TP_LINEAR_ROW_STATS the kernel writes partial (sum, sum of squares) of ITS rounded output to `row_stats_out`
+ * ([N/128][M][2]: one slab per 128 output columns; tp_linear_stats_parts() returns N/128). */
 enum {
     TP_LINEAR_GELU = 1,        /* exact erf GELU after bias (nn.GELU(), builder.py:63,69,81)      */
     TP_LINEAR_LN_FOLD = 2,
     TP_LINEAR_ROW_STATS = 4,
-    TP_LINEAR_OUT_F32 = 8
+    TP_LINEAR_OUT_F32 = 8      /* retired: use tp_linear_args.out_dtype = TP_F32                    */
 };
 typedef struct tp_linear_args {
     int32_t M, N, K;           /* N % 128 == 0, K % 64 == 0                                        */
-    int32_t dtype;             /* TP_BF16 / TP_F16                                                 */
+    int32_t dtype;             /* element type of A and W: TP_BF16 / TP_F16                        */
+    int32_t out_dtype;         /* element type of C: TP_BF16 / TP_F16 / TP_F32                     */
     int32_t flags;
     int32_t rows_per_batch;    /* A row r lives at A + (r / rpb)*a_batch_stride + (r % rpb)*lda   */
+    int32_t reserved0;
     int64_t a_batch_stride;    /* elements; ignored when rows_per_batch >= M                       */
     int64_t lda;               /* elements between consecutive rows of A                           */
     int64_t ldc;               /* elements between consecutive rows of C                           */
@@ -180,15 +187,17 @@ typedef struct tp_linear_args {
     const void* W;             /* [N,K] contiguous                                                 */
     const float* bias;
     void* C;
-    const float* row_stats_in; /* LN_FOLD                                                          */
+    const float* row_mean_rstd;/* LN_FOLD: fp32 [M][2]                                             */
     const float* colsum;       /* LN_FOLD: fp32 [N]                                                */
-    int32_t stats_parts;       /* LN_FOLD: number of partial slabs in row_stats_in                 */
-    int32_t ln_dim;            /* LN_FOLD: normalised width (1024)                                 */
-    float   ln_eps;
     int32_t tile;              /* 0 = auto, 128 or 256: force the block tile                       */
+    int32_t reserved1;
     float*  row_stats_out;     /* ROW_STATS                                                        */
 } tp_linear_args;
 int tp_linear(const tp_linear_args* args, void* stream);
+/* (sum, sumsq) slabs [parts][M][2] written by a TP_LINEAR_ROW_STATS call -> per-row (mean, rstd)
+ * [M][2] of nn.LayerNorm(ln_dim, eps) (biased variance), for a TP_LINEAR_LN_FOLD call. */
+int tp_ln_finalize(const float* row_stats, int parts, int64_t M, int ln_dim, float eps,
+                   float* row_mean_rstd, void* stream);
 /* Number of row-stat slabs a TP_LINEAR_ROW_STATS call with these M,N (and args->tile) writes. */
 int tp_linear_stats_parts(const tp_linear_args* args);
 

@@ -7,7 +7,7 @@ import torch
 
 from tokenpacker_amd import _capi
 
-DT = {torch.bfloat16: _capi.TP_BF16, torch.float16: _capi.TP_F16}
+DT = {torch.bfloat16: _capi.TP_BF16, torch.float16: _capi.TP_F16, torch.float32: _capi.TP_F32}
 
 
 def stream_ptr():
@@ -15,7 +15,7 @@ def stream_ptr():
 
 
 def linear(A, W, bias=None, flags=0, tile=0, rows_per_batch=0, a_batch_stride=0, lda=None, M=None,
-           stats_in=None, colsum=None, stats_parts=0, ln_dim=1024, ln_eps=1e-6, want_stats=False):
+           mean_rstd=None, colsum=None, want_stats=False, out_dtype=None):
     """C = epilogue(A · W^T) through tp_linear.  A may be a 2-D tensor or a raw (ptr-bearing) tensor
     with explicit M / lda / batch strides."""
     lib = _capi.load_library()
@@ -24,20 +24,21 @@ def linear(A, W, bias=None, flags=0, tile=0, rows_per_batch=0, a_batch_stride=0,
         M = A.shape[0]
     if lda is None:
         lda = A.stride(0)
-    out_f32 = bool(flags & _capi.TP_LINEAR_OUT_F32)
-    C = torch.empty(M, N, dtype=torch.float32 if out_f32 else W.dtype, device=W.device)
+    out_dtype = W.dtype if out_dtype is None else out_dtype
+    C = torch.empty(M, N, dtype=out_dtype, device=W.device)
     args = _capi.tp_linear_args()
     args.M, args.N, args.K = M, N, K
     args.dtype = DT[W.dtype]
+    args.out_dtype = DT[out_dtype]
     args.flags = flags | (_capi.TP_LINEAR_ROW_STATS if want_stats else 0)
     args.rows_per_batch = rows_per_batch
     args.a_batch_stride = a_batch_stride
     args.lda, args.ldc = lda, N
     args.A, args.W, args.C = A.data_ptr(), W.data_ptr(), C.data_ptr()
     args.bias = bias.data_ptr() if bias is not None else None
-    args.row_stats_in = stats_in.data_ptr() if stats_in is not None else None
+    args.row_mean_rstd = mean_rstd.data_ptr() if mean_rstd is not None else None
     args.colsum = colsum.data_ptr() if colsum is not None else None
-    args.stats_parts, args.ln_dim, args.ln_eps, args.tile = stats_parts, ln_dim, ln_eps, tile
+    args.tile = tile
     stats = None
     if want_stats:
         parts = lib.tp_linear_stats_parts(ctypes.byref(args))
@@ -47,6 +48,16 @@ def linear(A, W, bias=None, flags=0, tile=0, rows_per_batch=0, a_batch_stride=0,
     _capi.check(lib.tp_linear(ctypes.byref(args), stream_ptr()), "tp_linear")
     torch.cuda.synchronize()
     return (C, stats) if want_stats else C
+
+
+def ln_finalize(stats, ln_dim=1024, eps=1e-6):
+    lib = _capi.load_library()
+    parts, M, _ = stats.shape
+    out = torch.empty(M, 2, dtype=torch.float32, device=stats.device)
+    _capi.check(lib.tp_ln_finalize(stats.data_ptr(), parts, M, ln_dim, eps, out.data_ptr(), stream_ptr()),
+                "tp_ln_finalize")
+    torch.cuda.synchronize()
+    return out
 
 
 def describe_mismatch(got: torch.Tensor, want: torch.Tensor, name: str, tol: float) -> str:

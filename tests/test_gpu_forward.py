@@ -17,8 +17,9 @@ GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.n
 IDS = [os.path.basename(p)[:-4] for p in GOLDEN]
 
 # Gates.  Metric: max|y - y_ref| / max|y_ref|, y_ref = exact (fp64) math on the SAME
-# rounded weights/inputs.  fp16 and fp32-output mode: <= 1e-3 (north_star).  bf16 output: <= 2^-8,
-# i.e. no worse than the reference's own bf16 module (~5e-3) — bf16's half-ulp alone is 2e-3.
+# rounded weights/inputs.  fp16 and fp32-output mode: <= 1e-3 (north_star).  bf16 output: <= 2^-8
+# (bf16's half-ulp alone is 2e-3; the reference's own bf16 module sits at 5e-3..7e-3 on this metric).
+# The bf16 path meets them because activations between kernels are fp16 (DESIGN.md "Numerics").
 GATE = {(torch.float16, False): 1e-3, (torch.float16, True): 1e-3,
         (torch.bfloat16, True): 1e-3, (torch.bfloat16, False): 2.0 ** -8}
 
@@ -124,13 +125,15 @@ def test_odd_batch_and_single_image():
 def test_weight_update_invalidates_packed_cache():
     dtype, D, s = torch.bfloat16, 256, 2
     m = _module(synth.make_params(5, D), s, D, dtype)
+    m.output_fp32 = True
     x, xm = synth.make_inputs(9, 1, dtype)
     with torch.no_grad():
         y0 = m((x.cuda(), xm.cuda()))
         m.mlp[2].bias.add_(1.0)                       # in-place update, like an optimizer step
         y1 = m((x.cuda(), xm.cuda()))
     d = (y1.float() - y0.float())
-    assert torch.allclose(d, torch.ones_like(d), atol=0.05), "bias change must reach the kernels"
+    # the bias is a bf16 parameter: bf16(b + 1) - b is 1 up to bf16 spacing at ~1 (2^-8)
+    assert torch.allclose(d, torch.ones_like(d), atol=5e-3), "bias change must reach the kernels"
     m.load_state_dict(synth.make_params(5, D))
     with torch.no_grad():
         y2 = m((x.cuda(), xm.cuda()))

@@ -14,7 +14,7 @@ from ctypes import (POINTER, Structure, byref, c_char_p, c_float, c_int, c_int32
 TP_ABI_VERSION = 1
 TP_BF16, TP_F16, TP_F32 = 0, 1, 2
 TP_OK, TP_ERR_INVALID_ARG, TP_ERR_BAD_SCALE, TP_ERR_WORKSPACE, TP_ERR_LAUNCH = 0, -1, -2, -3, -4
-TP_LINEAR_GELU, TP_LINEAR_LN_FOLD, TP_LINEAR_ROW_STATS, TP_LINEAR_OUT_F32 = 1, 2, 4, 8
+TP_LINEAR_GELU, TP_LINEAR_LN_FOLD, TP_LINEAR_ROW_STATS = 1, 2, 4
 TP_TUNE_GEMM_TILE, TP_TUNE_XCD_SWIZZLE = 0, 1
 TP_NUM_STAGES = 10
 STAGE_NAMES = ("point_queries", "kv_layer0_gelu", "kv_layer2_stats", "kv_inproj_lnfold", "q_proj_1_stats",
@@ -27,7 +27,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 EXPORTED_SYMBOLS = (
     "tp_version", "tp_last_error", "tp_packed_weight_bytes", "tp_workspace_bytes",
     "tp_pack_weights", "tp_forward", "tp_forward_staged", "tp_point_queries", "tp_region_attention", "tp_linear",
-    "tp_linear_stats_parts", "tp_set_tuning",
+    "tp_ln_finalize", "tp_linear_stats_parts", "tp_set_tuning",
 )
 
 # state-dict name -> tp_weights field order (include/tokenpacker.h)
@@ -57,13 +57,12 @@ class tp_weights(Structure):
 
 
 class tp_linear_args(Structure):
-    _fields_ = [("M", c_int32), ("N", c_int32), ("K", c_int32), ("dtype", c_int32),
-                ("flags", c_int32), ("rows_per_batch", c_int32),
+    _fields_ = [("M", c_int32), ("N", c_int32), ("K", c_int32), ("dtype", c_int32), ("out_dtype", c_int32),
+                ("flags", c_int32), ("rows_per_batch", c_int32), ("reserved0", c_int32),
                 ("a_batch_stride", c_int64), ("lda", c_int64), ("ldc", c_int64),
                 ("A", c_void_p), ("W", c_void_p), ("bias", c_void_p), ("C", c_void_p),
-                ("row_stats_in", c_void_p), ("colsum", c_void_p),
-                ("stats_parts", c_int32), ("ln_dim", c_int32), ("ln_eps", c_float),
-                ("tile", c_int32), ("row_stats_out", c_void_p)]
+                ("row_mean_rstd", c_void_p), ("colsum", c_void_p),
+                ("tile", c_int32), ("reserved1", c_int32), ("row_stats_out", c_void_p)]
 
 
 _lib = None
@@ -110,6 +109,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.tp_region_attention.argtypes = [POINTER(tp_desc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.tp_linear.restype = c_int
     lib.tp_linear.argtypes = [POINTER(tp_linear_args), c_void_p]
+    lib.tp_ln_finalize.restype = c_int
+    lib.tp_ln_finalize.argtypes = [c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_void_p]
     lib.tp_linear_stats_parts.restype = c_int
     lib.tp_linear_stats_parts.argtypes = [POINTER(tp_linear_args)]
     lib.tp_set_tuning.restype = c_int

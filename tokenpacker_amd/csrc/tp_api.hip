@@ -63,17 +63,19 @@ WorkspaceLayout workspace_layout(int B, int grid, int s, int D) {
     WorkspaceLayout L{};
     const size_t N = (size_t)grid * grid, G = grid / s, M = G * G, E = kEmbed;
     const size_t rows_kv = (size_t)B * N, rows_q = (size_t)B * M;
-    L.stats_parts_kv = gemm_stats_parts((int)rows_kv, kEmbed, 0);
-    L.stats_parts_q = gemm_stats_parts((int)rows_q, kEmbed, 0);
+    L.stats_parts_kv = gemm_stats_parts(kEmbed);
+    L.stats_parts_q = gemm_stats_parts(kEmbed);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
     L.q0 = take(rows_q * E * 2);
     L.hkv = take(rows_kv * 2 * E * 2);
     L.h2 = take(2 * rows_kv * E * 2);
     L.stats_kv = take(2 * (size_t)8 * rows_kv * 2 * 4);     // up to 8 slabs (tile 128) per group
+    L.mr_kv = take(2 * rows_kv * 2 * 4);                    // per-row (mean, rstd), 2 groups
     L.kv = take(2 * rows_kv * E * 2);
     L.q1pre = take(rows_q * E * 2);
     L.stats_q = take((size_t)8 * rows_q * 2 * 4);
+    L.mr_q = take(rows_q * 2 * 4);
     L.q = take(rows_q * E * 2);
     L.o = take(rows_q * E * 2);
     L.a1 = take(rows_q * E * 2);
@@ -120,7 +122,6 @@ static GemmArgs plain_gemm(const void* A, long long lda_elems, const void* W, vo
     a.bias = bias;
     a.lda_bytes = lda_elems * 2; a.a_batch_stride_bytes = 0; a.rows_per_batch = M;
     a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.flags = flags; a.groups = 1;
-    a.inv_ln_dim = 1.f / kEmbed; a.ln_eps = 1e-6f;
     return a;
 }
 
@@ -178,11 +179,13 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
     TP_TRY(copy(L.w_kv0 + E * kMulti * 2, raw->v_proj_1_0_weight, E * kMulti * 2));
     TP_TRY(pack_cast_f32_launch(dt, raw->k_proj_1_0_bias, (float*)(P + L.b_kv0), (int)E, stream));
     TP_TRY(pack_cast_f32_launch(dt, raw->v_proj_1_0_bias, (float*)(P + L.b_kv0) + E, (int)E, stream));
-    TP_TRY(copy(L.w_kv2, raw->k_proj_1_2_weight, E * E * 2));
-    TP_TRY(copy(L.w_kv2 + E * E * 2, raw->v_proj_1_2_weight, E * E * 2));
+    // everything after the first layer runs on fp16 activations: widen those weights to fp16 (exact for
+    // in-range bf16 values; identity for fp16 models)
+    TP_TRY(pack_cast_f16_launch(dt, raw->k_proj_1_2_weight, P + L.w_kv2, (long long)(E * E), stream));
+    TP_TRY(pack_cast_f16_launch(dt, raw->v_proj_1_2_weight, P + L.w_kv2 + E * E * 2, (long long)(E * E), stream));
     TP_TRY(pack_cast_f32_launch(dt, raw->k_proj_1_2_bias, (float*)(P + L.b_kv2), (int)E, stream));
     TP_TRY(pack_cast_f32_launch(dt, raw->v_proj_1_2_bias, (float*)(P + L.b_kv2) + E, (int)E, stream));
-    TP_TRY(copy(L.w_q1, raw->q_proj_1_weight, E * E * 2));
+    TP_TRY(pack_cast_f16_launch(dt, raw->q_proj_1_weight, P + L.w_q1, (long long)(E * E), stream));
     // LayerNorm affines folded into the q/k/v in-projections (in_proj rows: q | k | v)
     const char* inw = (const char*)raw->clip_attn_in_proj_weight;
     const char* inb = (const char*)raw->clip_attn_in_proj_bias;
@@ -193,11 +196,11 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
     TP_TRY(pack_ln_fold_launch(dt, inw + 2 * E * E * 2, inb + 2 * E * 2, raw->ln_v_1_weight, raw->ln_v_1_bias,
                                P + L.w_in_kv + E * E * 2, (float*)(P + L.c_in_kv) + E, (float*)(P + L.b_in_kv) + E,
                                (int)E, (int)E, stream));
-    TP_TRY(copy(L.w_out, raw->clip_attn_out_proj_weight, E * E * 2));
+    TP_TRY(pack_cast_f16_launch(dt, raw->clip_attn_out_proj_weight, P + L.w_out, (long long)(E * E), stream));
     TP_TRY(pack_cast_f32_launch(dt, raw->clip_attn_out_proj_bias, (float*)(P + L.b_out), (int)E, stream));
-    TP_TRY(copy(L.w_m0, raw->mlp_0_weight, (size_t)D * E * 2));
+    TP_TRY(pack_cast_f16_launch(dt, raw->mlp_0_weight, P + L.w_m0, (long long)D * E, stream));
     TP_TRY(pack_cast_f32_launch(dt, raw->mlp_0_bias, (float*)(P + L.b_m0), D, stream));
-    TP_TRY(copy(L.w_m2, raw->mlp_2_weight, (size_t)D * D * 2));
+    TP_TRY(pack_cast_f16_launch(dt, raw->mlp_2_weight, P + L.w_m2, (long long)D * D, stream));
     TP_TRY(pack_cast_f32_launch(dt, raw->mlp_2_bias, (float*)(P + L.b_m2), D, stream));
     return TP_OK;
 }
@@ -223,19 +226,26 @@ int tp_point_queries(const tp_desc* desc, const void* x, const int64_t x_strides
 int tp_region_attention(const tp_desc* desc, const void* q, const void* k, const void* v, void* o, void* stream) {
     TP_TRY(validate_desc(desc));
     if (!q || !k || !v || !o) { set_error("tp_region_attention: NULL pointer"); return TP_ERR_INVALID_ARG; }
-    return region_attention_launch(desc->dtype, q, k, v, o, desc->batch, desc->raw_grid,
-                                   desc->scale_factor, (hipStream_t)stream);
+    return region_attention_launch(q, k, v, o, desc->batch, desc->raw_grid, desc->scale_factor, (hipStream_t)stream);
+}
+
+int tp_ln_finalize(const float* row_stats, int parts, int64_t M, int ln_dim, float eps, float* row_mean_rstd, void* stream) {
+    if (!row_stats || !row_mean_rstd || parts <= 0 || M <= 0 || ln_dim <= 0 || !(eps > 0.f)) {
+        set_error("tp_ln_finalize: invalid argument");
+        return TP_ERR_INVALID_ARG;
+    }
+    return ln_finalize_launch(row_stats, row_mean_rstd, M, parts, 1, ln_dim, eps, (hipStream_t)stream);
 }
 
 int tp_linear_stats_parts(const tp_linear_args* a) {
     if (!a || a->N <= 0 || a->N % 128 != 0) return 0;
-    return gemm_stats_parts(a->M, a->N, a->tile);
+    return gemm_stats_parts(a->N);
 }
 
 int tp_linear(const tp_linear_args* a, void* stream) {
     if (!a || !a->A || !a->W || !a->C) { set_error("tp_linear: NULL argument"); return TP_ERR_INVALID_ARG; }
-    if ((a->flags & TP_LINEAR_LN_FOLD) && (!a->row_stats_in || !a->colsum || a->stats_parts <= 0 || a->ln_dim <= 0)) {
-        set_error("tp_linear: LN_FOLD needs row_stats_in, colsum, stats_parts, ln_dim");
+    if ((a->flags & TP_LINEAR_LN_FOLD) && (!a->row_mean_rstd || !a->colsum)) {
+        set_error("tp_linear: LN_FOLD needs row_mean_rstd and colsum");
         return TP_ERR_INVALID_ARG;
     }
     if ((a->flags & TP_LINEAR_ROW_STATS) && !a->row_stats_out) {
@@ -249,13 +259,13 @@ int tp_linear(const tp_linear_args* a, void* stream) {
     }
     GemmArgs g{};
     g.A = (const char*)a->A; g.W = (const char*)a->W; g.C = (char*)a->C;
-    g.bias = a->bias; g.stats_in = a->row_stats_in; g.colsum = a->colsum; g.stats_out = a->row_stats_out;
+    g.bias = a->bias; g.stats_in = a->row_mean_rstd; g.colsum = a->colsum; g.stats_out = a->row_stats_out;
     g.rows_per_batch = (a->rows_per_batch > 0 && a->rows_per_batch < a->M) ? a->rows_per_batch : a->M;
     g.a_batch_stride_bytes = a->a_batch_stride * 2; g.lda_bytes = a->lda * 2; g.ldc = a->ldc;
-    g.M = a->M; g.N = a->N; g.K = a->K; g.flags = a->flags; g.stats_parts = a->stats_parts;
-    g.inv_ln_dim = a->ln_dim > 0 ? 1.f / a->ln_dim : 0.f; g.ln_eps = a->ln_eps;
+    g.M = a->M; g.N = a->N; g.K = a->K; g.flags = a->flags;
     g.groups = 1; g.tile = a->tile;
-    return gemm_launch(a->dtype, g, (hipStream_t)stream);
+    if (a->flags & TP_LINEAR_OUT_F32) { set_error("tp_linear: TP_LINEAR_OUT_F32 was replaced by out_dtype = TP_F32"); return TP_ERR_INVALID_ARG; }
+    return gemm_launch(a->dtype, a->out_dtype, g, (hipStream_t)stream);
 }
 
 static int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3], const void* x_multi,
@@ -302,67 +312,70 @@ static int forward_impl(const tp_desc* desc, const void* x, const int64_t x_stri
         GemmArgs a = plain_gemm(x_multi, xm_strides[1], pw + P.w_kv0, ws + W.hkv, 2 * E, rows_kv, 2 * E, kMulti,
                                 (const float*)(pw + P.b_kv0), TP_LINEAR_GELU);
         a.rows_per_batch = N; a.a_batch_stride_bytes = xm_strides[0] * 2;
-        TP_TRY(gemm_launch(dt, a, stream));
+        TP_TRY(gemm_launch(dt, TP_F16, a, stream));      // raw operands in the io dtype, fp16 activations out
     }
     // 3. H2[g] = Hkv[:, g*1024:(g+1)*1024] · W{k,v}2^T + b, and LayerNorm partials of H2
     TP_TRY(mark());
-    const int parts_kv = gemm_stats_parts(rows_kv, E, 0);
+    const int parts_kv = gemm_stats_parts(E);
     {
         GemmArgs a = plain_gemm(ws + W.hkv, 2 * E, pw + P.w_kv2, ws + W.h2, E, rows_kv, E, E,
                                 (const float*)(pw + P.b_kv2), TP_LINEAR_ROW_STATS);
         a.groups = 2; a.a_gs = E * 2; a.w_gs = (long long)E * E * 2; a.c_gs = kvE * 2; a.bias_gs = E;
         a.stats_out = (float*)(ws + W.stats_kv); a.stats_out_gs = (long long)parts_kv * rows_kv * 2;
-        TP_TRY(gemm_launch(dt, a, stream));
+        TP_TRY(gemm_launch(TP_F16, TP_F16, a, stream));
     }
     TP_TRY(mark());
+    TP_TRY(ln_finalize_launch((const float*)(ws + W.stats_kv), (float*)(ws + W.mr_kv), rows_kv, parts_kv, 2, E,
+                              desc->ln_eps, stream));
     // 4. {K,V} = LN(H2[g]) · Win{k,v}^T + b   (LayerNorm folded into the epilogue)
     {
         GemmArgs a = plain_gemm(ws + W.h2, E, pw + P.w_in_kv, ws + W.kv, E, rows_kv, E, E,
                                 (const float*)(pw + P.b_in_kv), TP_LINEAR_LN_FOLD);
         a.groups = 2; a.a_gs = kvE * 2; a.w_gs = (long long)E * E * 2; a.c_gs = kvE * 2; a.bias_gs = E;
-        a.stats_in = (const float*)(ws + W.stats_kv); a.stats_in_gs = (long long)parts_kv * rows_kv * 2;
-        a.stats_parts = parts_kv; a.colsum = (const float*)(pw + P.c_in_kv); a.colsum_gs = E;
-        a.ln_eps = desc->ln_eps;
-        TP_TRY(gemm_launch(dt, a, stream));
+        a.stats_in = (const float*)(ws + W.mr_kv); a.stats_in_gs = (long long)rows_kv * 2;
+        a.colsum = (const float*)(pw + P.c_in_kv); a.colsum_gs = E;
+        TP_TRY(gemm_launch(TP_F16, TP_F16, a, stream));
     }
     TP_TRY(mark());
     // 5. Q1pre = q0 · Wq1^T (no bias), LayerNorm partials
-    const int parts_q = gemm_stats_parts(rows_q, E, 0);
+    const int parts_q = gemm_stats_parts(E);
     {
         GemmArgs a = plain_gemm(ws + W.q0, E, pw + P.w_q1, ws + W.q1pre, E, rows_q, E, E, nullptr, TP_LINEAR_ROW_STATS);
         a.stats_out = (float*)(ws + W.stats_q);
-        TP_TRY(gemm_launch(dt, a, stream));
+        TP_TRY(gemm_launch(TP_F16, TP_F16, a, stream));
     }
     TP_TRY(mark());
+    TP_TRY(ln_finalize_launch((const float*)(ws + W.stats_q), (float*)(ws + W.mr_q), rows_q, parts_q, 1, E,
+                              desc->ln_eps, stream));
     // 6. Q = LN(Q1pre) · Winq^T + b
     {
         GemmArgs a = plain_gemm(ws + W.q1pre, E, pw + P.w_in_q, ws + W.q, E, rows_q, E, E,
                                 (const float*)(pw + P.b_in_q), TP_LINEAR_LN_FOLD);
-        a.stats_in = (const float*)(ws + W.stats_q); a.stats_parts = parts_q;
-        a.colsum = (const float*)(pw + P.c_in_q); a.ln_eps = desc->ln_eps;
-        TP_TRY(gemm_launch(dt, a, stream));
+        a.stats_in = (const float*)(ws + W.mr_q);
+        a.colsum = (const float*)(pw + P.c_in_q);
+        TP_TRY(gemm_launch(TP_F16, TP_F16, a, stream));
     }
     TP_TRY(mark());
     // 7. region-to-point attention
-    TP_TRY(region_attention_launch(dt, ws + W.q, ws + W.kv, ws + W.kv + kvE * 2, ws + W.o, B, g, s, stream));
+    TP_TRY(region_attention_launch(ws + W.q, ws + W.kv, ws + W.kv + kvE * 2, ws + W.o, B, g, s, stream));
     TP_TRY(mark());
     // 8. out_proj
     {
         GemmArgs a = plain_gemm(ws + W.o, E, pw + P.w_out, ws + W.a1, E, rows_q, E, E, (const float*)(pw + P.b_out), 0);
-        TP_TRY(gemm_launch(dt, a, stream));
+        TP_TRY(gemm_launch(TP_F16, TP_F16, a, stream));
     }
     TP_TRY(mark());
     // 9. mlp[0] + GELU
     {
         GemmArgs a = plain_gemm(ws + W.a1, E, pw + P.w_m0, ws + W.a2, D, rows_q, D, E, (const float*)(pw + P.b_m0), TP_LINEAR_GELU);
-        TP_TRY(gemm_launch(dt, a, stream));
+        TP_TRY(gemm_launch(TP_F16, TP_F16, a, stream));
     }
     TP_TRY(mark());
     // 10. mlp[2] -> out
     {
         GemmArgs a = plain_gemm(ws + W.a2, D, pw + P.w_m2, out, D, rows_q, D, D, (const float*)(pw + P.b_m2),
-                                desc->out_dtype == TP_F32 ? TP_LINEAR_OUT_F32 : 0);
-        TP_TRY(gemm_launch(dt, a, stream));
+                                0);
+        TP_TRY(gemm_launch(TP_F16, desc->out_dtype, a, stream));
     }
     TP_TRY(mark());
     return TP_OK;

@@ -19,10 +19,11 @@
 //   * XCD-aware tile order: the 8 XCDs own contiguous ranges of the tile list so that the tiles
 //     sharing an A row-panel hit the same private L2.
 //   * epilogue: LayerNorm-fold (a LayerNorm in front of the linear applied as
-//     rstd·(acc − mu·colsum) from per-row (sum, sumsq) partials), bias, exact-erf GELU,
+//     rstd·(acc − mu·colsum) from per-row (mean, rstd)), bias, erf-form GELU,
 //     per-row (sum, sumsq) partials of the rounded output for the NEXT LayerNorm, cast.
 #include "tp_internal.h"
 #include <mutex>
+#include <type_traits>
 
 namespace tp {
 
@@ -41,8 +42,22 @@ template <> struct Mma<f16_t> {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
+// erf-form GELU (nn.GELU() default).  erf by Abramowitz–Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32
+// round-off class next to the 1.0 it is added to): 1 rcp + 1 exp + ~12 FMA-class ops per element instead
+// of ocml erff's ~45 with divergent branches — the epilogue runs with the matrix pipe idle, so its VALU
+// time is pure cost (measured: ~0.1 ms per GELU layer at B=256 with erff).
 __device__ __forceinline__ float gelu_erf(float v) {
-    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    const float x = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    poly *= t;
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);      // exp(-x^2)
+    const float erf_abs = fmaf(-poly, e, 1.0f);                                  // erf(|v|/sqrt2)
+    const float half_v = 0.5f * v;
+    return fmaf(half_v, copysignf(erf_abs, v), half_v);                          // 0.5 v (1 + erf)
 }
 
 constexpr int BK = 64;             // K-slab in elements
@@ -54,11 +69,13 @@ constexpr int gemm_lds_bytes() { return 2 * (BM + BN) * ROW_BYTES; }
 // STRIDED_A: A rows live in batches of rows_per_batch rows with a batch stride (the CLIP tower's
 // [:,1:] slices) — only the first K/V layer needs it, which also gives that launch (45 % of the path's
 // FLOPs) its own kernel symbol in profiles.
-template <typename T, int BM, int BN, int WM, int WN, bool STRIDED_A>
+// TI: operand element type (bf16 / fp16) — selects the MFMA;  TO: output element type (bf16 / fp16 / float).
+template <typename TI, typename TO, int BM, int BN, int WM, int WN, bool STRIDED_A>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
-    using X8 = typename Vec<T>::x8;
-    using X4 = typename Vec<T>::x4;
+    using T = TI;
+    using X8 = typename Vec<TI>::x8;
+    constexpr bool OUT_F32 = std::is_same<TO, float>::value;
     constexpr int NWM = BM / WM, NWN = BN / WN, NW = NWM * NWN;
     constexpr int FM = WM / 16, FN = WN / 16;          // 16x16 fragments per wave
     constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES, STAGE = A_BYTES + B_BYTES;
@@ -131,6 +148,19 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // LayerNorm-fold operands (per-row mean, rstd) do not depend on the contraction: fetch them now so
+    // their latency hides under the whole K loop instead of serialising the epilogue.
+    float2 mean_rstd[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        mean_rstd[i] = make_float2(0.f, 1.f);
+        if (p.flags & TP_LINEAR_LN_FOLD) {
+            int m = m0 + wm * WM + i * 16 + (lane & 15);
+            m = m < p.M ? m : p.M - 1;
+            mean_rstd[i] = *(const float2*)(p.stats_in + g * p.stats_in_gs + (long long)m * 2);
+        }
+    }
+
     const int nk = p.K / BK;
     issue(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -163,7 +193,6 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
     const int col_base = n0 + wn * WN + (lane >> 4) * 4;
     const float* __restrict__ bias = p.bias ? p.bias + g * p.bias_gs : nullptr;
     const float* __restrict__ colsum = p.colsum ? p.colsum + g * p.colsum_gs : nullptr;
-    const float* __restrict__ stats_in = p.stats_in ? p.stats_in + g * p.stats_in_gs : nullptr;
     char* __restrict__ Cg = p.C + g * p.c_gs;
 
     f32x4 bias_v[FN], csum_v[FN];
@@ -179,18 +208,7 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * WM + i * 16 + (lane & 15);
         const bool row_ok = m < p.M;
-        float mu = 0.f, rstd = 1.f;
-        if (flags & TP_LINEAR_LN_FOLD) {
-            const int mc = row_ok ? m : p.M - 1;
-            float s1 = 0.f, s2 = 0.f;
-            for (int pp = 0; pp < p.stats_parts; ++pp) {
-                const float2 st = *(const float2*)(stats_in + ((long long)pp * p.M + mc) * 2);
-                s1 += st.x; s2 += st.y;
-            }
-            mu = s1 * p.inv_ln_dim;
-            const float var = fmaxf(s2 * p.inv_ln_dim - mu * mu, 0.f);
-            rstd = 1.0f / sqrtf(var + p.ln_eps);
-        }
+        const float mu = mean_rstd[i].x, rstd = mean_rstd[i].y;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
@@ -202,11 +220,16 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
                 for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
             }
             const long long coff = (long long)m * p.ldc + col_base + j * 16;
-            if (flags & TP_LINEAR_OUT_F32) {
+            if constexpr (OUT_F32) {
                 if (row_ok) *(f32x4*)((float*)Cg + coff) = v;
             } else {
-                const X4 o = __builtin_convertvector(v, X4);
-                if (row_ok) *(X4*)((T*)Cg + coff) = o;
+                using O4 = typename Vec<TO>::x4;
+                if constexpr (std::is_same<TO, f16_t>::value) {     // saturate instead of producing inf
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r], -65504.f), 65504.f);
+                }
+                const O4 o = __builtin_convertvector(v, O4);
+                if (row_ok) *(O4*)((TO*)Cg + coff) = o;
                 if (flags & TP_LINEAR_ROW_STATS) v = __builtin_convertvector(o, f32x4);  // stats of the ROUNDED values
             }
             if (flags & TP_LINEAR_ROW_STATS) {
@@ -233,13 +256,21 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
             }
         }
         __syncthreads();
-        for (int rr = tid; rr < BM; rr += NW * 64) {
+        // one slab per 128 output columns, whatever the tile: the partial-sum tree (lane -> 4 lane groups ->
+        // the 128/WN waves of a slab) is identical for every tile shape, so results do not depend on the
+        // tile the batch size selects (bit-exact batch invariance).
+        constexpr int SLABS = BN / 128, WPS = 128 / WN;
+        for (int idx = tid; idx < BM * SLABS; idx += NW * 64) {
+            const int rr = idx % BM, sl = idx / BM;
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int w = 0; w < NWN; ++w) { s1 += red[(w * BM + rr) * 2]; s2 += red[(w * BM + rr) * 2 + 1]; }
+            for (int w = 0; w < WPS; ++w) {
+                s1 += red[((sl * WPS + w) * BM + rr) * 2];
+                s2 += red[((sl * WPS + w) * BM + rr) * 2 + 1];
+            }
             const int m = m0 + rr;
             if (m < p.M) {
-                float* so = p.stats_out + g * p.stats_out_gs + ((long long)tile_n * p.M + m) * 2;
+                float* so = p.stats_out + g * p.stats_out_gs + ((long long)(tile_n * SLABS + sl) * p.M + m) * 2;
                 *(float2*)so = make_float2(s1, s2);
             }
         }
@@ -256,11 +287,11 @@ int gemm_pick_tile(int M, int N, int forced) {
     return tiles256 >= 512 ? 256 : 128;     // >= 2 full waves of the 256 CUs, else finer tiles
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool STRIDED_A>
+template <typename TI, typename TO, int BM, int BN, int WM, int WN, bool STRIDED_A>
 static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     constexpr int lds = gemm_lds_bytes<BM, BN>();
     constexpr int threads = (BM / WM) * (BN / WN) * 64;
-    auto kern = gemm_kernel<T, BM, BN, WM, WN, STRIDED_A>;
+    auto kern = gemm_kernel<TI, TO, BM, BN, WM, WN, STRIDED_A>;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [&] {
@@ -277,28 +308,37 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     return check_launch("gemm_kernel");
 }
 
-int gemm_launch(int dtype, const GemmArgs& a, hipStream_t stream) {
+template <typename TI, typename TO>
+static int launch_types(const GemmArgs& a, hipStream_t stream) {
+    const int tile = gemm_pick_tile(a.M, a.N, a.tile);
+    const bool strided = a.rows_per_batch < a.M;
+    if (tile == 256)
+        return strided ? launch_cfg<TI, TO, 256, 256, 128, 64, true>(a, stream)
+                       : launch_cfg<TI, TO, 256, 256, 128, 64, false>(a, stream);
+    return strided ? launch_cfg<TI, TO, 128, 128, 64, 64, true>(a, stream)
+                   : launch_cfg<TI, TO, 128, 128, 64, 64, false>(a, stream);
+}
+
+int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.N % 128 != 0 || a.K % BK != 0) {
         set_error("tp gemm: unsupported shape M=%d N=%d K=%d (need N%%128==0, K%%64==0)", a.M, a.N, a.K);
         return TP_ERR_INVALID_ARG;
     }
-    if ((a.flags & TP_LINEAR_ROW_STATS) && (a.flags & TP_LINEAR_OUT_F32)) {
-        set_error("tp gemm: ROW_STATS with OUT_F32 is not supported");
+    if ((a.flags & TP_LINEAR_ROW_STATS) && out_dtype == TP_F32) {
+        set_error("tp gemm: ROW_STATS with fp32 output is not supported");
         return TP_ERR_INVALID_ARG;
     }
-    const int tile = gemm_pick_tile(a.M, a.N, a.tile);
-    const bool strided = a.rows_per_batch < a.M;
-    if (dtype != TP_BF16 && dtype != TP_F16) {
-        set_error("tp gemm: unsupported dtype %d", dtype);
-        return TP_ERR_INVALID_ARG;
+    if (in_dtype == TP_BF16) {
+        if (out_dtype == TP_BF16) return launch_types<bf16_t, bf16_t>(a, stream);
+        if (out_dtype == TP_F16) return launch_types<bf16_t, f16_t>(a, stream);
+        if (out_dtype == TP_F32) return launch_types<bf16_t, float>(a, stream);
+    } else if (in_dtype == TP_F16) {
+        if (out_dtype == TP_BF16) return launch_types<f16_t, bf16_t>(a, stream);
+        if (out_dtype == TP_F16) return launch_types<f16_t, f16_t>(a, stream);
+        if (out_dtype == TP_F32) return launch_types<f16_t, float>(a, stream);
     }
-#define TP_GEMM_DISPATCH(T)                                                                        \
-    (tile == 256 ? (strided ? launch_cfg<T, 256, 256, 128, 64, true>(a, stream)                    \
-                            : launch_cfg<T, 256, 256, 128, 64, false>(a, stream))                  \
-                 : (strided ? launch_cfg<T, 128, 128, 64, 64, true>(a, stream)                     \
-                            : launch_cfg<T, 128, 128, 64, 64, false>(a, stream)))
-    return dtype == TP_BF16 ? TP_GEMM_DISPATCH(bf16_t) : TP_GEMM_DISPATCH(f16_t);
-#undef TP_GEMM_DISPATCH
+    set_error("tp gemm: unsupported dtypes in=%d out=%d", in_dtype, out_dtype);
+    return TP_ERR_INVALID_ARG;
 }
 
 }  // namespace tp

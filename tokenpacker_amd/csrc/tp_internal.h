@@ -36,7 +36,9 @@ int tuning(int key);
 // C[g][M,N] = epilogue(A[g][M,K] * W[g][N,K]^T) for g in [0, groups)
 struct GemmArgs {
     const char* A; const char* W; char* C;
-    const float* bias; const float* stats_in; const float* colsum; float* stats_out;
+    const float* bias;
+    const float* stats_in;            // LN_FOLD: per-row (mean, rstd) [M][2]
+    const float* colsum; float* stats_out;
     long long a_batch_stride_bytes;   // between batches of rows_per_batch rows
     long long lda_bytes;              // between rows inside a batch
     long long ldc;                    // elements
@@ -45,41 +47,44 @@ struct GemmArgs {
     int M, N, K;
     int rows_per_batch;
     int flags;                        // TP_LINEAR_*
-    int stats_parts;
-    float inv_ln_dim, ln_eps;
     int groups;
     int tile;                         // 0 auto, 128, 256
 };
-int gemm_launch(int dtype, const GemmArgs& a, hipStream_t stream);
+int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream);
 int gemm_pick_tile(int M, int N, int forced);     // -> 128 or 256
-inline int gemm_stats_parts(int M, int N, int forced) { return N / gemm_pick_tile(M, N, forced); }
+inline int gemm_stats_parts(int N) { return N / 128; }   // one (sum, sumsq) slab per 128 output columns
 
 // ---- small kernels (tp_kernels.hip) -----------------------------------------------------------
-int point_queries_launch(int dtype, const void* x, const int64_t st[3], void* q0, int B, int grid,
+// Activations between kernels are ALWAYS fp16 (see DESIGN.md "numerics"): `dtype` below is the
+// element type of the caller's tensors (x, weights), outputs are fp16.
+int point_queries_launch(int dtype, const void* x, const int64_t st[3], void* q0_f16, int B, int grid,
                          int s, hipStream_t stream);
-int region_attention_launch(int dtype, const void* q, const void* k, const void* v, void* o, int B,
-                            int grid, int s, hipStream_t stream);
+int region_attention_launch(const void* q, const void* k, const void* v, void* o, int B,
+                            int grid, int s, hipStream_t stream);      // fp16 in / fp16 out
+int ln_finalize_launch(const float* parts, float* mean_rstd, long long M, int nparts, int groups, int ln_dim,
+                       float eps, hipStream_t stream);
 int pack_cast_f32_launch(int dtype, const void* src, float* dst, int n, hipStream_t stream);
+int pack_cast_f16_launch(int dtype, const void* src, void* dst_f16, long long n, hipStream_t stream);
 int pack_ln_fold_launch(int dtype, const void* w, const void* bias, const void* gamma,
                         const void* beta, void* w_out, float* colsum, float* bias_out, int n_out,
                         int n_in, hipStream_t stream);
 
 // ---- packed-weight and workspace layouts (tp_api.hip) -----------------------------------------
 struct PackedLayout {
-    size_t w_kv0, b_kv0;          // [2048,4096] T, [2048] f32
-    size_t w_kv2, b_kv2;          // [2][1024,1024] T, [2][1024] f32
-    size_t w_q1;                  // [1024,1024] T
-    size_t w_in_kv, c_in_kv, b_in_kv;   // LN-folded in-proj for k, v: [2][1024,1024] T, [2][1024] f32 x2
+    size_t w_kv0, b_kv0;          // [2048,4096] io dtype (consumed with the raw inputs), [2048] f32
+    size_t w_kv2, b_kv2;          // [2][1024,1024] f16, [2][1024] f32
+    size_t w_q1;                  // [1024,1024] f16
+    size_t w_in_kv, c_in_kv, b_in_kv;   // LN-folded in-proj for k, v: [2][1024,1024] f16, [2][1024] f32 x2
     size_t w_in_q, c_in_q, b_in_q;      // LN-folded in-proj for q
-    size_t w_out, b_out;          // [1024,1024] T, [1024] f32
-    size_t w_m0, b_m0;            // [D,1024] T, [D] f32
-    size_t w_m2, b_m2;            // [D,D] T, [D] f32
+    size_t w_out, b_out;          // [1024,1024] f16, [1024] f32
+    size_t w_m0, b_m0;            // [D,1024] f16, [D] f32
+    size_t w_m2, b_m2;            // [D,D] f16, [D] f32
     size_t total;
 };
 PackedLayout packed_layout(int D);
 
 struct WorkspaceLayout {
-    size_t q0, hkv, h2, stats_kv, kv, q1pre, stats_q, q, o, a1, a2;
+    size_t q0, hkv, h2, stats_kv, mr_kv, kv, q1pre, stats_q, mr_q, q, o, a1, a2;
     size_t total;
     int stats_parts_kv, stats_parts_q;
 };

@@ -30,7 +30,7 @@ template <typename T> __device__ __forceinline__ void store8(T* p, const float (
 // result rounded once to T (builder.py:117-118).  One thread = 8 channels of one query.
 template <typename T>
 __global__ void __launch_bounds__(256)
-point_queries_kernel(const T* __restrict__ x, long long sb, long long st, T* __restrict__ q0,
+point_queries_kernel(const T* __restrict__ x, long long sb, long long st, f16_t* __restrict__ q0,
                      int B, int g, int s, int C) {
     const int G = g / s, M = G * G, vecs = C / 8;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -55,17 +55,21 @@ point_queries_kernel(const T* __restrict__ x, long long sb, long long st, T* __r
         for (int e = 0; e < 8; ++e)
             out[e] = 0.5f * (0.5f * a00[e] + 0.5f * a01[e]) + 0.5f * (0.5f * a10[e] + 0.5f * a11[e]);
     }
+    // round once to the INPUT dtype (the reference's `.to(x.dtype)`), then widen exactly to the fp16
+    // activation type (saturating: a bf16 value can exceed the fp16 range)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] = fminf(fmaxf((float)(T)out[e], -65504.f), 65504.f);
     store8(q0 + qm * C + cv * 8, out);
 }
 
 int point_queries_launch(int dtype, const void* x, const int64_t st[3], void* q0, int B, int grid,
-                         int s, hipStream_t stream) {
+                         int s, hipStream_t stream) {   // q0 is fp16
     const int G = grid / s, M = G * G;
     const long long total = (long long)B * M * (kEmbed / 8);
     const unsigned blocks = (unsigned)((total + 255) / 256);
     if (dtype == TP_BF16)
         hipLaunchKernelGGL(point_queries_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream,
-                           (const bf16_t*)x, (long long)st[0], (long long)st[1], (bf16_t*)q0, B, grid, s, kEmbed);
+                           (const bf16_t*)x, (long long)st[0], (long long)st[1], (f16_t*)q0, B, grid, s, kEmbed);
     else
         hipLaunchKernelGGL(point_queries_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream,
                            (const f16_t*)x, (long long)st[0], (long long)st[1], (f16_t*)q0, B, grid, s, kEmbed);
@@ -165,19 +169,43 @@ region_attention_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
     store8(o + qi * E + eb, acc_b);
 }
 
-int region_attention_launch(int dtype, const void* q, const void* k, const void* v, void* o, int B,
+int region_attention_launch(const void* q, const void* k, const void* v, void* o, int B,
                             int grid, int s, hipStream_t stream) {
     const int G = grid / s, M = G * G;
     const long long nq = (long long)B * M;
     const unsigned blocks = (unsigned)((nq + 3) / 4);
     const float scale = 0.08838834764831845f;   // 1/sqrt(128): q scaling of F.multi_head_attention_forward
-    if (dtype == TP_BF16)
-        hipLaunchKernelGGL(region_attention_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream,
-                           (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, B, grid, s, scale);
-    else
-        hipLaunchKernelGGL(region_attention_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream,
-                           (const f16_t*)q, (const f16_t*)k, (const f16_t*)v, (f16_t*)o, B, grid, s, scale);
+    hipLaunchKernelGGL(region_attention_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream,
+                       (const f16_t*)q, (const f16_t*)k, (const f16_t*)v, (f16_t*)o, B, grid, s, scale);
     return check_launch("region_attention_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm statistics: the producing GEMM leaves one (sum, sumsq) slab per 128 output columns
+// ([parts][M][2]); this turns them into per-row (mean, rstd) for the consuming GEMM's epilogue.
+// The slabs are summed in slab order -> deterministic.  ~10 MB of traffic at B=256: noise.
+__global__ void __launch_bounds__(256)
+ln_finalize_kernel(const float* __restrict__ parts, float* __restrict__ mean_rstd, long long M, int nparts,
+                   float inv_dim, float eps) {
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.y;
+    if (m >= M) return;
+    const float* pg = parts + (long long)g * nparts * M * 2;
+    float s1 = 0.f, s2 = 0.f;
+    for (int pp = 0; pp < nparts; ++pp) {
+        const float2 st = *(const float2*)(pg + ((long long)pp * M + m) * 2);
+        s1 += st.x; s2 += st.y;
+    }
+    const float mu = s1 * inv_dim;
+    const float var = fmaxf(s2 * inv_dim - mu * mu, 0.f);      // biased variance (nn.LayerNorm)
+    *(float2*)(mean_rstd + ((long long)g * M + m) * 2) = make_float2(mu, 1.0f / sqrtf(var + eps));
+}
+
+int ln_finalize_launch(const float* parts, float* mean_rstd, long long M, int nparts, int groups, int ln_dim,
+                       float eps, hipStream_t stream) {
+    dim3 grid((unsigned)((M + 255) / 256), (unsigned)groups);
+    hipLaunchKernelGGL(ln_finalize_kernel, grid, dim3(256), 0, stream, parts, mean_rstd, M, nparts, 1.0f / ln_dim, eps);
+    return check_launch("ln_finalize_kernel");
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -197,21 +225,36 @@ int pack_cast_f32_launch(int dtype, const void* src, float* dst, int n, hipStrea
     return check_launch("pack_cast_f32_kernel");
 }
 
+template <typename T>
+__global__ void pack_cast_f16_kernel(const T* __restrict__ src, f16_t* __restrict__ dst, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (f16_t)fminf(fmaxf((float)src[i], -65504.f), 65504.f);   // exact for in-range bf16
+}
+
+int pack_cast_f16_launch(int dtype, const void* src, void* dst, long long n, hipStream_t stream) {
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (dtype == TP_BF16)
+        hipLaunchKernelGGL(pack_cast_f16_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)src, (f16_t*)dst, n);
+    else
+        hipLaunchKernelGGL(pack_cast_f16_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream, (const f16_t*)src, (f16_t*)dst, n);
+    return check_launch("pack_cast_f16_kernel");
+}
+
 // LayerNorm folded into the linear that follows it.  For y = LN(h)·W^T + b with
 // LN(h) = (h − mu)·rstd·gamma + beta:
-//     y_n = rstd·( Σ_k h_k W'_nk − mu·c_n ) + b'_n,   W'_nk = W_nk·gamma_k (rounded to T),
+//     y_n = rstd·( Σ_k h_k W'_nk − mu·c_n ) + b'_n,   W'_nk = W_nk·gamma_k (rounded to fp16),
 //     c_n = Σ_k W'_nk (of the ROUNDED W', so the mean term cancels exactly),  b'_n = Σ_k beta_k W_nk + b_n.
 // One workgroup per output row n.
 template <typename T>
 __global__ void __launch_bounds__(256)
 pack_ln_fold_kernel(const T* __restrict__ w, const T* __restrict__ bias, const T* __restrict__ gamma,
-                    const T* __restrict__ beta, T* __restrict__ w_out, float* __restrict__ colsum,
+                    const T* __restrict__ beta, f16_t* __restrict__ w_out, float* __restrict__ colsum,
                     float* __restrict__ bias_out, int n_in) {
     const int n = blockIdx.x;
     float cs = 0.f, bs = 0.f;
     for (int kk = threadIdx.x; kk < n_in; kk += blockDim.x) {
         const float wv = (float)w[(long long)n * n_in + kk];
-        const T wp = (T)(wv * (float)gamma[kk]);
+        const f16_t wp = (f16_t)fminf(fmaxf(wv * (float)gamma[kk], -65504.f), 65504.f);
         w_out[(long long)n * n_in + kk] = wp;
         cs += (float)wp;
         bs = fmaf((float)beta[kk], wv, bs);
@@ -233,7 +276,7 @@ int pack_ln_fold_launch(int dtype, const void* w, const void* bias, const void* 
     if (dtype == TP_BF16)
         hipLaunchKernelGGL(pack_ln_fold_kernel<bf16_t>, dim3(n_out), dim3(256), 0, stream,
                            (const bf16_t*)w, (const bf16_t*)bias, (const bf16_t*)gamma, (const bf16_t*)beta,
-                           (bf16_t*)w_out, colsum, bias_out, n_in);
+                           (f16_t*)w_out, colsum, bias_out, n_in);
     else
         hipLaunchKernelGGL(pack_ln_fold_kernel<f16_t>, dim3(n_out), dim3(256), 0, stream,
                            (const f16_t*)w, (const f16_t*)bias, (const f16_t*)gamma, (const f16_t*)beta,
