@@ -193,11 +193,12 @@ def main():
         kv0_flops = 2.0 * B * 576 * 4096 * 2048                 # algorithmic FLOPs of the dominant launch
         kv0_ms = stage_ms[1]
         achieved = kv0_flops / (kv0_ms * 1e-3) / 1e12
-        traffic = None
+        traffic, traffic_detail = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, if collected
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(f"kv_layer0_B{B}_{args.dtype}")
+                traffic_detail = json.load(open(tfile)).get(f"kv_layer0_B{B}_{args.dtype}")
+                traffic = traffic_detail["total"] if (traffic_detail and args.layout == "tower") else None
             except Exception:
                 traffic = None
         out = {
@@ -223,11 +224,12 @@ def main():
                            "algorithmic_gflop_per_image": round(fl_img / 1e9, 3),
                            "algorithmic_io_mb_per_image": round(bytes_per_image(s, D) / 1e6, 3),
                            "io_gbps": round(bytes_per_image(s, D) * B / (ms_per_step * 1e-3) / 1e9, 1)},
-            "roofline": {"kernel": "gemm_kernel<T,256,256,128,64,STRIDED_A> (kv_layer0: x_multi·[Wk0;Wv0]^T + bias + GELU)",
+            "roofline": {"kernel": "tp::gemm8_kernel<T, f16, STRIDED_A> 256x256x64 ping-pong (kv_layer0: x_multi·[Wk0;Wv0]^T + bias + GELU)",
                          "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                          "flops_per_launch": kv0_flops, "avg_launch_ms": round(kv0_ms, 4),
-                         "traffic": traffic},
+                         "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/traffic.json)",
+                         "algorithmic_bytes": float(B * 576 * 4096 * 2 + 2048 * 4096 * 2 + B * 576 * 2048 * 2)},
             "stages_ms": {n: round(v, 4) for n, v in zip(_capi.STAGE_NAMES, stage_ms)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -204,6 +204,7 @@ int tp_linear_stats_parts(const tp_linear_args* args);
 /* ---- tuning knobs (benchmarks only; defaults are what tp_forward ships with) ------------------ */
 enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto | 128 | 256                                              */
        TP_TUNE_XCD_SWIZZLE = 1, /* 1 (default) | 0                                                 */
+       TP_TUNE_GEMM_KERNEL = 2, /* 256-tile main loop: 0 ping-pong 8-wave (default) | 1 two-phase   */
        TP_TUNE_COUNT_ = 8 };
 int tp_set_tuning(int key, int value);
 

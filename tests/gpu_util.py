@@ -15,9 +15,12 @@ def stream_ptr():
 
 
 def linear(A, W, bias=None, flags=0, tile=0, rows_per_batch=0, a_batch_stride=0, lda=None, M=None,
-           mean_rstd=None, colsum=None, want_stats=False, out_dtype=None):
+           mean_rstd=None, colsum=None, want_stats=False, out_dtype=None, kern=0, sync=True):
     """C = epilogue(A · W^T) through tp_linear.  A may be a 2-D tensor or a raw (ptr-bearing) tensor
-    with explicit M / lda / batch strides."""
+    with explicit M / lda / batch strides.  tile: 0 auto | 128 | 256; a NEGATIVE tile (-256) or kern=1
+    selects the two-phase 256-tile main loop instead of the default ping-pong kernel (tp_gemm8.hip)."""
+    if tile < 0:
+        tile, kern = -tile, 1
     lib = _capi.load_library()
     N, K = W.shape
     if M is None:
@@ -45,8 +48,13 @@ def linear(A, W, bias=None, flags=0, tile=0, rows_per_batch=0, a_batch_stride=0,
         assert parts > 0
         stats = torch.full((parts, M, 2), float("nan"), dtype=torch.float32, device=W.device)
         args.row_stats_out = stats.data_ptr()
-    _capi.check(lib.tp_linear(ctypes.byref(args), stream_ptr()), "tp_linear")
-    torch.cuda.synchronize()
+    _capi.set_tuning(_capi.TP_TUNE_GEMM_KERNEL, kern)
+    try:
+        _capi.check(lib.tp_linear(ctypes.byref(args), stream_ptr()), "tp_linear")
+    finally:
+        _capi.set_tuning(_capi.TP_TUNE_GEMM_KERNEL, 0)
+    if sync:
+        torch.cuda.synchronize()
     return (C, stats) if want_stats else C
 
 

@@ -19,6 +19,10 @@ TOL_F32OUT = 2e-5
 TOL_ROUND = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
 
 
+# block-tile variants of the MFMA kernel: 128 (two-phase), 256 (ping-pong 8-wave, tp_gemm8.hip), -256 (two-phase 256)
+TILES = [128, 256, -256]
+
+
 def _rand(shape, dtype, seed, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return (torch.randn(shape, generator=g) * scale).to(dtype).cuda()
@@ -30,10 +34,10 @@ def _ref_linear(A, W, bias=None):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("tile", TILES)
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 512, 256), (300, 256, 128), (1000, 1024, 1024), (77, 128, 4096)])
 def test_linear_plain(dtype, tile, M, N, K):
-    if tile == 256 and N % 256:
+    if abs(tile) == 256 and N % 256:
         pytest.skip("tile 256 needs N % 256 == 0")
     A = _rand((M, K), dtype, 1)
     W = _rand((N, K), dtype, 2, K ** -0.5)      # asymmetric, non-square data: catches transposes
@@ -52,7 +56,7 @@ def test_linear_plain(dtype, tile, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("tile", TILES)
 def test_linear_bias_gelu(dtype, tile):
     M, N, K = 640, 512, 256
     A = _rand((M, K), dtype, 3)
@@ -64,7 +68,7 @@ def test_linear_bias_gelu(dtype, tile):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("tile", TILES)
 def test_linear_strided_batch_rows(dtype, tile):
     """A given as the tower's [:,1:] slice of a CLS-prefixed [B,577,K] buffer (clip_encoder.py:37-38)."""
     B, T, K, N = 3, 576, 256, 256
@@ -79,7 +83,7 @@ def test_linear_strided_batch_rows(dtype, tile):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("tile", TILES)
 def test_linear_row_stats_and_ln_fold(dtype, tile):
     """GEMM#1 emits per-row (sum, sumsq) partials of its ROUNDED output; GEMM#2 consumes them to apply
     LayerNorm folded into its epilogue.  Reference: LN then linear in fp64 (builder.py:112,120 + in-proj)."""
@@ -121,7 +125,51 @@ def test_row_stats_do_not_depend_on_tile(dtype):
     W = _rand((1024, 256), dtype, 13, 256 ** -0.5)
     H1, s1 = gu.linear(A, W, tile=128, want_stats=True)
     H2, s2 = gu.linear(A, W, tile=256, want_stats=True)
+    H3, s3 = gu.linear(A, W, tile=-256, want_stats=True)
     assert torch.equal(H1, H2) and torch.equal(s1, s2)
+    assert torch.equal(H1, H3) and torch.equal(s1, s3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("K", [64, 128, 192, 256, 320, 1024])
+def test_pingpong_short_and_odd_k(dtype, K):
+    """K-tile counts 1..5 and 16 walk every prologue / tail variant of the ping-pong main loop."""
+    M, N = 700, 512
+    A = _rand((M, K), dtype, 50 + K)
+    W = _rand((N, K), dtype, 51 + K, K ** -0.5)
+    ref = _ref_linear(A, W)
+    C32 = gu.linear(A, W, out_dtype=torch.float32, tile=256)
+    gu.assert_close(C32, ref, f"pingpong K={K} {dtype}", TOL_F32OUT)
+    assert torch.equal(C32, gu.linear(A, W, out_dtype=torch.float32, tile=-256))
+
+
+@pytest.mark.parametrize("M,N,K,flags", [(36864, 4096, 4096, 0), (147456, 1024, 1024, _capi.TP_LINEAR_ROW_STATS),
+                                         (36864, 4096, 1024, _capi.TP_LINEAR_GELU), (20000, 2048, 4096, _capi.TP_LINEAR_GELU)])
+def test_pingpong_full_size_race_screen(M, N, K, flags):
+    """Full-size shapes of the B=256 path, random data, every CU busy for many rounds: the
+    ping-pong kernel must reproduce the two-phase kernel BIT FOR BIT (both accumulate each K-slab in the same
+    order), on every one of several back-to-back launches — a DMA/LDS race shows up as a differing tile."""
+    dtype = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(77)
+    A = torch.randn(M, K, generator=g, device="cuda").to(dtype)
+    W = (torch.randn(N, K, generator=g, device="cuda") * K ** -0.5).to(dtype)
+    bias = torch.randn(N, generator=g, device="cuda")
+    want_stats = bool(flags & _capi.TP_LINEAR_ROW_STATS)
+    fl = flags & ~_capi.TP_LINEAR_ROW_STATS
+    ref = gu.linear(A, W, bias=bias, flags=fl, tile=-256, want_stats=want_stats, out_dtype=torch.float16)
+    for rep in range(4):
+        got = gu.linear(A, W, bias=bias, flags=fl, tile=256, want_stats=want_stats, out_dtype=torch.float16, sync=False)
+        if want_stats:
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), f"launch {rep}"
+        else:
+            assert torch.equal(got, ref), f"launch {rep}: {(got.float() - ref.float()).abs().max().item()}"
+    # and the two-phase kernel itself against fp32 math on a row sample (transposition-detecting: N != K or random)
+    rows = torch.randint(0, M, (64,), generator=torch.Generator().manual_seed(1)).cuda()
+    y = A[rows].float() @ W.float().t() + bias
+    if fl & _capi.TP_LINEAR_GELU:
+        y = torch.nn.functional.gelu(y)
+    c = (ref[0] if want_stats else ref)[rows].float()
+    assert (c - y).abs().max() <= 2e-3 * y.abs().max()
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -1,0 +1,298 @@
+// tp_gemm8.hip — the 256x256x64 "ping-pong" MFMA kernel that carries the large contractions of the
+// TokenPacker path on gfx950 (MI355X):   C[M,N] = epilogue( A[M,K] · W[N,K]^T ),  N % 256 == 0.
+//
+// Same operands, fragment layout and fused epilogue as tp_gemm.hip (reference builder.py:112,113,120,
+// 126-130,136); what differs is the main loop, built for how a CDNA4 CU actually issues:
+//
+//   * 8 waves (2 along M x 4 along N), one workgroup per CU, 128 KiB of LDS = 2 K-tile buffers.  A SIMD
+//     hosts one wave of each M-half; the two halves run ONE BARRIER APART, so while one wave of a SIMD is
+//     in its MFMA segment (16 x v_mfma_f32_16x16x32, s_setprio 1) its partner is in its memory segment
+//     (ds_read_b128 fragment reads + the LDS-DMA issue for a later K-tile) — matrix beside memory on every
+//     SIMD, every segment, by construction instead of by luck of the scheduler.
+//   * A K-tile is consumed in 4 phases, one 64x32 quadrant of the wave's 128x64 output each, in the order
+//     (a0,b0) (a0,b1) (a1,b1) (a1,b0): fragment reads per phase are 12 / 4 / 8 / 0 ds_read_b128.
+//   * HBM/L2 -> LDS by buffer_load_dwordx4 ... lds (1 KiB per wave instruction) in FOUR 16-KiB groups per
+//     K-tile ordered by when they are first read: G0 = A rows of quadrant a0 (both M-halves), G1 = W rows of
+//     b0 (all four N-quarters), G2 = W rows of b1, G3 = A rows of a1.  One group is issued per phase (two DMA
+//     instructions per wave), up to two K-tiles ahead, and retired with a COUNTED s_waitcnt vmcnt(2*DEPTH):
+//     the queue is never drained inside the loop and the loads stay in flight across the barriers.
+//   * K advances through the buffer instruction's scalar offset: no per-iteration address VALU at all.
+//   * LDS image is lane-linear (a DMA constraint); the bank-conflict swizzle slot' = slot ^ (row & 7) is
+//     applied on the per-lane SOURCE address and again on the ds_read_b128 address (same involution).
+//
+// Hazard bookkeeping (phase g = 4*tile + p; group 0 = waves of M-half 0, group 1 runs one barrier later):
+//   RAW  a group whose covering vmcnt sits in phase g_w (before that phase's first barrier) may be read
+//        from phase g_w + 1 on:  every wave has passed its wait before any reader passes the barrier
+//        that opens its read segment.
+//   WAR  a region last read in phase g_r may be re-targeted by a DMA issued in phase >= g_r + 2 (the late
+//        group's reads retire at its lgkmcnt(0), one barrier before the early group's issue segment).
+//   Schedule: phase p of tile t issues   p=0: G2(t+1)  p=1: G3(t+1)  p=2: G0(t+2)  p=3: G1(t+2)
+//   (re-target distance 3,3,2,3 phases) and waits vmcnt(2*DEPTH), DEPTH = 3: the group issued 3 phases
+//   ago has landed; it is first read 1..2 phases after that.
+#include "tp_gemm_common.h"
+#include <mutex>
+
+namespace tp {
+
+namespace {
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N == 0 || N == 2 || N == 4 || N == 6 || N == 8 || N == 12, "unsupported count");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+
+constexpr int G8_BM = 256, G8_BN = 256, G8_WM = 128, G8_WN = 64;
+constexpr int G8_GROUP = 128 * ROW_BYTES;          // 16 KiB: one DMA group (128 rows x 128 B)
+constexpr int G8_BUF = 4 * G8_GROUP;               // 64 KiB: one K-tile (G0 | G1 | G2 | G3)
+constexpr int G8_LDS = 2 * G8_BUF;                 // 128 KiB
+constexpr int G8_DEPTH = 3;                        // DMA groups left in flight by the in-loop wait
+
+}  // namespace
+
+template <typename TI, typename TO, bool STRIDED_A>
+__global__ void __launch_bounds__(512, 2)
+gemm8_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
+    using X8 = typename Vec<TI>::x8;
+    constexpr int BM = G8_BM, BN = G8_BN, WM = G8_WM, WN = G8_WN;
+    constexpr int FM = WM / 16, FN = WN / 16;          // 8 x 4 accumulator fragments per wave
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    int bid = blockIdx.x;
+    if (xcd_swizzle) bid = xcd_remap(bid, gridDim.x);
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int g = blockIdx.y;
+
+    // ---- buffer descriptors (wave-uniform by construction: kernel arguments and blockIdx only) -----------
+    // A is addressed relative to the tile's first row, W relative to the tile's first output column, so the
+    // 32-bit per-lane offsets stay tiny whatever the batch.
+    auto a_row_off = [&](int row) __attribute__((always_inline)) -> long long {       // byte offset of A row `row` from the group base
+        if constexpr (STRIDED_A) {
+            const int b = row / p.rows_per_batch;
+            const int t = row - b * p.rows_per_batch;
+            return (long long)b * p.a_batch_stride_bytes + (long long)t * p.lda_bytes;
+        } else {
+            return (long long)row * p.lda_bytes;
+        }
+    };
+    const long long a_tile_off = a_row_off(m0);
+    const char* a_base = p.A + g * p.a_gs + a_tile_off;
+    const char* w_base = p.W + g * p.w_gs + (long long)n0 * p.K * 2;
+    const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, 0x7fffffff, 0x00020000);
+    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, 0, 0x7fffffff, 0x00020000);
+
+    // ---- per-lane DMA source offsets ---------------------------------------------------------------------
+    // A group holds 128 rows; wave w fills rows 16w..16w+15 with two 1-KiB instructions (q = 0, 1):
+    // lane -> group row rho = 16w + 8q + lane/8, 16-B slot' = lane%8 holding logical slot (lane%8)^(lane/8).
+    //   A groups: rho -> tile row  (rho / 64) * 128 + sub * 64 + rho % 64     (sub = 0: G0, 1: G3)
+    //   W groups: rho -> tile col  (rho / 32) *  64 + sub * 32 + rho % 32     (sub = 0: G1, 1: G2)
+    const int kslot = (lane & 7) ^ (lane >> 3);
+    int voff_a[2][2], voff_w[2][2];                    // [sub][q]
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int rho = 16 * wave + 8 * q + (lane >> 3);
+            int row = m0 + (rho >> 6) * 128 + sub * 64 + (rho & 63);
+            row = row < p.M ? row : p.M - 1;
+            voff_a[sub][q] = (int)(a_row_off(row) - a_tile_off) + kslot * 16;
+            const int col = (rho >> 5) * 64 + sub * 32 + (rho & 31);
+            voff_w[sub][q] = col * p.K * 2 + kslot * 16;
+        }
+
+    // issue DMA group G<grp> of K-tile `kt` into the buffer of that tile's parity
+    auto issue = [&](auto grp_, int kt) __attribute__((always_inline)) {
+        constexpr int grp = decltype(grp_)::value;
+        constexpr bool is_a = (grp == 0 || grp == 3);
+        constexpr int sub = (grp == 2 || grp == 3) ? 1 : 0;
+        char* dst = smem + (kt & 1) * G8_BUF + grp * G8_GROUP + wave * 2048;
+        const int soff = kt * ROW_BYTES;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if constexpr (is_a)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)(dst + q * 1024), 16, voff_a[sub][q], soff, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void*)(dst + q * 1024), 16, voff_w[sub][q], soff, 0, 0);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+
+    // ---- fragment read offsets (swizzled; fragment rows are 16-aligned inside a group, so row & 7 == lane & 7)
+    const int slot0 = (((lane >> 4)) ^ (lane & 7)) << 4, slot1 = (((4 + (lane >> 4))) ^ (lane & 7)) << 4;
+    const int rd_a = (wm * 64 + (lane & 15)) * ROW_BYTES;     // + i * 2048, i = 0..3
+    const int rd_w = (wn * 32 + (lane & 15)) * ROW_BYTES;     // + j * 2048, j = 0..1
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    X8 fa[4][2];            // A fragments of the current M-quadrant  [i][k-half]
+    X8 fb[2][2][2];         // W fragments                            [b][j][k-half]
+
+    // One phase.  P: 0..3;  ISSUE: whether this phase's DMA group exists;  WAIT: vmcnt to leave in flight
+    // (-1: no wait).  The DMA target of phase P in tile t is fixed by the schedule in the file header.
+    auto phase = [&](auto P_, auto ISSUE_, auto WAIT_, const int t) __attribute__((always_inline)) {
+        constexpr int P = decltype(P_)::value;
+        constexpr bool ISSUE = decltype(ISSUE_)::value;
+        constexpr int WAIT = decltype(WAIT_)::value;
+        const char* sb = smem + (t & 1) * G8_BUF;
+        // -- memory segment ---------------------------------------------------------------------------
+        if constexpr (P == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                fb[0][j][0] = *(const X8*)(sb + 1 * G8_GROUP + rd_w + j * 2048 + slot0);
+                fb[0][j][1] = *(const X8*)(sb + 1 * G8_GROUP + rd_w + j * 2048 + slot1);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i][0] = *(const X8*)(sb + 0 * G8_GROUP + rd_a + i * 2048 + slot0);
+                fa[i][1] = *(const X8*)(sb + 0 * G8_GROUP + rd_a + i * 2048 + slot1);
+            }
+        } else if constexpr (P == 1) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                fb[1][j][0] = *(const X8*)(sb + 2 * G8_GROUP + rd_w + j * 2048 + slot0);
+                fb[1][j][1] = *(const X8*)(sb + 2 * G8_GROUP + rd_w + j * 2048 + slot1);
+            }
+        } else if constexpr (P == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i][0] = *(const X8*)(sb + 3 * G8_GROUP + rd_a + i * 2048 + slot0);
+                fa[i][1] = *(const X8*)(sb + 3 * G8_GROUP + rd_a + i * 2048 + slot1);
+            }
+        }
+        if constexpr (ISSUE) {
+            if constexpr (P == 0) issue(I2{}, t + 1);
+            if constexpr (P == 1) issue(I3{}, t + 1);
+            if constexpr (P == 2) issue(I0{}, t + 2);
+            if constexpr (P == 3) issue(I1{}, t + 2);
+        }
+        if constexpr (WAIT >= 0) wait_vmcnt<WAIT>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // -- matrix segment ---------------------------------------------------------------------------
+        constexpr int a = (P >= 2) ? 1 : 0, b = (P == 1 || P == 2) ? 1 : 0;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[4 * a + i][2 * b + j] = Mma<TI>::run(fb[b][j][ks], fa[i][ks], acc[4 * a + i][2 * b + j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+    using W6 = std::integral_constant<int, 2 * G8_DEPTH>; using W4 = std::integral_constant<int, 4>;
+    using W2 = std::integral_constant<int, 2>; using W0 = std::integral_constant<int, 0>;
+    using WN_ = std::integral_constant<int, -1>;
+
+    // ---- prologue: K-tile 0 complete + G0, G1 of K-tile 1 in flight; G0(0), G1(0) landed --------------------
+    const int nk = p.K / BK;
+    issue(I0{}, 0); issue(I1{}, 0); issue(I2{}, 0); issue(I3{}, 0);
+    if (nk >= 2) {
+        issue(I0{}, 1); issue(I1{}, 1);
+        wait_vmcnt<8>();
+    } else {
+        wait_vmcnt<4>();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();         // the late half runs one barrier behind
+    __builtin_amdgcn_sched_barrier(0);
+
+    int t = 0;
+    for (; t < nk - 2; ++t) {                           // steady state: every phase issues, 3 groups stay in flight
+        phase(I0{}, T_{}, W6{}, t);
+        phase(I1{}, T_{}, W6{}, t);
+        phase(I2{}, T_{}, W6{}, t);
+        phase(I3{}, T_{}, W6{}, t);
+    }
+    if (nk >= 2) {                                      // tile nk-2: nothing beyond tile nk-1 to fetch
+        phase(I0{}, T_{}, W6{}, t);
+        phase(I1{}, T_{}, W6{}, t);
+        phase(I2{}, F_{}, W4{}, t);
+        phase(I3{}, F_{}, W2{}, t);
+        ++t;
+    }
+    phase(I0{}, F_{}, W0{}, t);                         // tile nk-1: drain
+    phase(I1{}, F_{}, WN_{}, t);
+    phase(I2{}, F_{}, WN_{}, t);
+    phase(I3{}, F_{}, WN_{}, t);
+    if (wm == 0) __builtin_amdgcn_s_barrier();         // re-join: equal barrier counts for both halves
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue ---------------------------------------------------------------------------------------
+    float2 mean_rstd[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        mean_rstd[i] = make_float2(0.f, 1.f);
+        if (p.flags & TP_LINEAR_LN_FOLD) {
+            int m = m0 + wm * WM + i * 16 + (lane & 15);
+            m = m < p.M ? m : p.M - 1;
+            mean_rstd[i] = *(const float2*)(p.stats_in + g * p.stats_in_gs + (long long)m * 2);
+        }
+    }
+    gemm_epilogue<TO, BM, BN, WM, WN>(acc, p, g, m0, n0, tile_n, wm, wn, lane, tid, mean_rstd, smem);
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+template <typename TI, typename TO, bool STRIDED_A>
+static int launch8_cfg(const GemmArgs& a, hipStream_t stream) {
+    auto kern = gemm8_kernel<TI, TO, STRIDED_A>;
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [&] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
+    });
+    if (attr_err != hipSuccess) {
+        set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", G8_LDS, hipGetErrorString(attr_err));
+        return TP_ERR_LAUNCH;
+    }
+    const int tiles_m = (a.M + G8_BM - 1) / G8_BM, tiles_n = a.N / G8_BN;
+    dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)a.groups, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(512), G8_LDS, stream, a, tiles_n, tuning(TP_TUNE_XCD_SWIZZLE));
+    return check_launch("gemm8_kernel");
+}
+
+template <typename TI, typename TO>
+static int launch8_types(const GemmArgs& a, hipStream_t stream) {
+    return a.rows_per_batch < a.M ? launch8_cfg<TI, TO, true>(a, stream) : launch8_cfg<TI, TO, false>(a, stream);
+}
+
+// Preconditions (checked by gemm_launch): N % 256 == 0, K % 64 == 0, (long long)N_tile_rows * K * 2 < 2^31.
+int gemm8_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream) {
+    if (in_dtype == TP_BF16) {
+        if (out_dtype == TP_BF16) return launch8_types<bf16_t, bf16_t>(a, stream);
+        if (out_dtype == TP_F16) return launch8_types<bf16_t, f16_t>(a, stream);
+        if (out_dtype == TP_F32) return launch8_types<bf16_t, float>(a, stream);
+    } else if (in_dtype == TP_F16) {
+        if (out_dtype == TP_BF16) return launch8_types<f16_t, bf16_t>(a, stream);
+        if (out_dtype == TP_F16) return launch8_types<f16_t, f16_t>(a, stream);
+        if (out_dtype == TP_F32) return launch8_types<f16_t, float>(a, stream);
+    }
+    set_error("tp gemm8: unsupported dtypes in=%d out=%d", in_dtype, out_dtype);
+    return TP_ERR_INVALID_ARG;
+}
+
+}  // namespace tp

@@ -52,6 +52,8 @@ struct GemmArgs {
 };
 int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream);
 int gemm_pick_tile(int M, int N, int forced);     // -> 128 or 256
+// 256x256x64 ping-pong kernel (tp_gemm8.hip); gemm_launch routes tile-256 problems to it
+int gemm8_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream);
 inline int gemm_stats_parts(int N) { return N / 128; }   // one (sum, sumsq) slab per 128 output columns
 
 // ---- small kernels (tp_kernels.hip) -----------------------------------------------------------

@@ -1,10 +1,16 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the tp_linear MFMA kernel on the GEMM shapes of the TokenPacker path at
-B=256 (run on the GPU box).  Prints TFLOP/s per (shape, tile, xcd-swizzle) and, as a yard-stick,
-torch.matmul (hipBLASLt/rocBLAS) on the same operands.  Random normal data (guide §5.4 rule 25)."""
+"""Micro-benchmark of the tp_linear MFMA kernels on the GEMM shapes of the TokenPacker path (run on the
+GPU box).  Variants are interleaved round-robin inside ONE process (guide §5.4 rule 24) on random normal
+data (rule 25); prints median TFLOP/s per (shape, variant) and, as a yard-stick, torch.matmul
+(hipBLASLt/rocBLAS) on the same operands.
+
+    python tools/gemm_bench.py [--batch 256] [--scale-factor 2] [--rounds 7]
+"""
+import argparse
 import ctypes
 import json
 import os
+import statistics
 import sys
 
 import torch
@@ -12,63 +18,84 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tokenpacker_amd import _capi  # noqa: E402
 
-SHAPES = [  # name, M, N, K, flags
-    ("kv_layer0", 256 * 576, 2048, 4096, _capi.TP_LINEAR_GELU),
-    ("kv_layer2", 256 * 576, 1024, 1024, _capi.TP_LINEAR_ROW_STATS),
-    ("q_side", 256 * 144, 1024, 1024, 0),
-    ("mlp0", 256 * 144, 4096, 1024, _capi.TP_LINEAR_GELU),
-    ("mlp2", 256 * 144, 4096, 4096, 0),
-]
+G, S, F = _capi.TP_LINEAR_GELU, _capi.TP_LINEAR_ROW_STATS, _capi.TP_LINEAR_LN_FOLD
+VARIANTS = [("tile128", 128, 0), ("pingpong256", 256, 0), ("twophase256", 256, 1)]
 
 
-def time_ms(fn, iters=10, warm=3):
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(iters):
-        fn()
-    b.record()
-    torch.cuda.synchronize()
-    return a.elapsed_time(b) / iters
+def shapes(B, s, D):
+    N, M = 576, (24 // s) ** 2
+    return [  # name, M, N, K, flags, in dtype, out dtype
+        ("kv_layer0", B * N, 2048, 4096, G, torch.bfloat16, _capi.TP_F16),
+        ("kv_layer2", B * N, 1024, 1024, S, torch.float16, _capi.TP_F16),
+        ("kv_inproj", B * N, 1024, 1024, F, torch.float16, _capi.TP_F16),
+        ("q_side", B * M, 1024, 1024, 0, torch.float16, _capi.TP_F16),
+        ("mlp0", B * M, D, 1024, G, torch.float16, _capi.TP_F16),
+        ("mlp2", B * M, D, D, 0, torch.float16, _capi.TP_BF16),
+    ]
 
 
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--scale-factor", type=int, default=2)
+    ap.add_argument("--hidden-size", type=int, default=4096)
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--out", default="gpurun_out/gemm_bench.json")
+    args = ap.parse_args()
     lib = _capi.load_library()
-    dtype = torch.bfloat16
+    st = torch.cuda.current_stream().cuda_stream
     results = []
-    for name, M, N, K, flags in SHAPES:
-        A = torch.randn(M, K, device="cuda", dtype=torch.float32).to(dtype)
-        W = (torch.randn(N, K, device="cuda", dtype=torch.float32) * K ** -0.5).to(dtype)
+    for name, M, N, K, flags, dt, odt in shapes(args.batch, args.scale_factor, args.hidden_size):
+        A = torch.randn(M, K, device="cuda", dtype=torch.float32).to(dt)
+        W = (torch.randn(N, K, device="cuda", dtype=torch.float32) * K ** -0.5).to(dt)
         bias = torch.randn(N, device="cuda")
-        C = torch.empty(M, N, device="cuda", dtype=dtype)
+        colsum = torch.randn(N, device="cuda")
+        mr = torch.rand(M, 2, device="cuda") + 0.5
+        C = torch.empty(M, N, device="cuda", dtype=torch.float16)
         stats = torch.empty(8 * M * 2, device="cuda")
         fl = 2.0 * M * N * K
-        for tile in (128, 256):
-            for swz in (1, 0):
-                _capi.set_tuning(_capi.TP_TUNE_XCD_SWIZZLE, swz)
-                args = _capi.tp_linear_args()
-                args.M, args.N, args.K, args.dtype, args.flags = M, N, K, _capi.TP_BF16, flags
-                args.lda, args.ldc, args.tile = K, N, tile
-                args.A, args.W, args.C, args.bias = A.data_ptr(), W.data_ptr(), C.data_ptr(), bias.data_ptr()
-                args.row_stats_out = stats.data_ptr()
-                st = torch.cuda.current_stream().cuda_stream
 
-                def run():
-                    rc = lib.tp_linear(ctypes.byref(args), st)
-                    assert rc == 0, _capi.last_error()
-                ms = time_ms(run)
-                results.append(dict(shape=name, M=M, N=N, K=K, tile=tile, swizzle=swz, ms=round(ms, 4),
-                                    tflops=round(fl / ms / 1e9, 1)))
-                print(results[-1], flush=True)
-        _capi.set_tuning(_capi.TP_TUNE_XCD_SWIZZLE, 1)
-        ms = time_ms(lambda: torch.matmul(A, W.t()))
-        results.append(dict(shape=name, M=M, N=N, K=K, tile="torch.matmul", ms=round(ms, 4), tflops=round(fl / ms / 1e9, 1)))
-        print(results[-1], flush=True)
-        del A, W, C
-    os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(results, open("gpurun_out/gemm_bench.json", "w"), indent=1)
+        def make(tile, kern):
+            a = _capi.tp_linear_args()
+            a.M, a.N, a.K, a.flags = M, N, K, flags
+            a.dtype = _capi.TP_BF16 if dt == torch.bfloat16 else _capi.TP_F16
+            a.out_dtype = odt
+            a.lda, a.ldc, a.tile = K, N, tile
+            a.A, a.W, a.C, a.bias = A.data_ptr(), W.data_ptr(), C.data_ptr(), bias.data_ptr()
+            a.row_stats_out, a.row_mean_rstd, a.colsum = stats.data_ptr(), mr.data_ptr(), colsum.data_ptr()
+
+            def run():
+                _capi.set_tuning(_capi.TP_TUNE_GEMM_KERNEL, kern)
+                rc = lib.tp_linear(ctypes.byref(a), st)
+                assert rc == 0, _capi.last_error()
+            return run
+
+        runs = [(v, make(t, k)) for v, t, k in VARIANTS if N % t == 0]
+        runs.append(("torch.matmul", lambda: torch.matmul(A, W.t())))
+        times = {v: [] for v, _ in runs}
+        for v, fn in runs:                       # warm-up
+            fn()
+        torch.cuda.synchronize()
+        for _ in range(args.rounds):
+            for v, fn in runs:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.iters):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                times[v].append(e0.elapsed_time(e1) / args.iters)
+        for v, _ in runs:
+            ms = statistics.median(times[v])
+            rec = dict(shape=name, M=M, N=N, K=K, variant=v, ms=round(ms, 4), ms_min=round(min(times[v]), 4),
+                       tflops=round(fl / ms / 1e9, 1))
+            results.append(rec)
+            print(rec, flush=True)
+        _capi.set_tuning(_capi.TP_TUNE_GEMM_KERNEL, 0)
+        del A, W, C, mr, stats
+    os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+    json.dump(results, open(args.out, "w"), indent=1)
 
 
 if __name__ == "__main__":

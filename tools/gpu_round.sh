@@ -1,19 +1,55 @@
 #!/bin/bash
-# One GPU-box session: smoke, parity tests, bench, micro-bench, rocprof kernel trace.
-# Usage (from the repo root on the GPU box): bash tools/gpu_round.sh [tag]
-TAG=${1:-r01}
+# One GPU-box session.  Usage (from the repo root on the GPU box): bash tools/gpu_round.sh <tag> [steps...]
+# steps (default: all): smoke tests gemm bench sweep prof pmc
+# Every step runs under its own `timeout`, so a hung kernel cannot eat the whole box allowance.
+TAG=${1:-r01}; shift
+STEPS=${*:-smoke tests gemm bench sweep prof pmc}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-echo "== rocminfo ==" ; /opt/rocm/bin/rocminfo 2>/dev/null | grep -E "Marketing Name|gfx9|Compute Unit" | head -6
-echo "== smoke ==" ; timeout 600 python __graft_entry__.py smoke 2>&1 | tail -5
-echo "== pytest gpu ==" ; timeout 1500 python -m pytest tests -m gpu -q -s -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -40 $OUT/pytest_gpu.log
-echo "== bench ==" ; timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; cat $OUT/bench.json; tail -5 $OUT/bench.err
-echo "== gemm bench ==" ; timeout 600 python tools/gemm_bench.py > $OUT/gemm_bench.log 2>&1; echo "exit $?"; cat $OUT/gemm_bench.log | tail -40
-echo "== rocprof kernel trace ==" 
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/rocprof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1 ); echo "rocprof exit $?"
-find $OUT/rocprof -name "*stats*" | head; 
-F=$(find $OUT/rocprof -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && head -25 "$F"
-# keep the merged-back payload small: drop the raw per-dispatch trace
-find $OUT/rocprof -name "*kernel_trace.csv" -size +20M -delete
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+has() { [[ " $STEPS " == *" $1 "* ]]; }
+echo "== rocminfo =="; /opt/rocm/bin/rocminfo 2>/dev/null | grep -E "Marketing Name|gfx9|Compute Unit" | head -4; nproc
+
+if has smoke; then
+  echo "== smoke =="; timeout 600 python __graft_entry__.py smoke 2>&1 | tail -5
+fi
+if has ktests; then
+  echo "== pytest gpu (kernels only) =="
+  timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -p no:cacheprovider > $OUT/pytest_kernels.log 2>&1
+  echo "pytest exit $?"; tail -25 $OUT/pytest_kernels.log
+fi
+if has tests; then
+  echo "== pytest gpu =="
+  timeout 1500 python -m pytest tests -m gpu -q -s -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1
+  echo "pytest exit $?"; grep -E "passed|failed|error" $OUT/pytest_gpu.log | tail -5; grep -E "^\[parity\]|^\[eager" $OUT/pytest_gpu.log | tail -40
+  cp gpurun_out/eager_rocm_s*.json $OUT/ 2>/dev/null
+fi
+if has gemm; then
+  echo "== gemm bench =="; timeout 600 python tools/gemm_bench.py --out $OUT/gemm_bench.json > $OUT/gemm_bench.log 2>&1; echo "exit $?"; tail -30 $OUT/gemm_bench.log
+fi
+if has bench; then
+  echo "== bench =="; timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; cat $OUT/bench.json; tail -5 $OUT/bench.err
+fi
+if has sweep; then
+  echo "== sweep (scale_factor 3, 4; HD 36 crops/GPU; fp16) =="
+  for sf in 3 4; do timeout 300 python bench.py --scale-factor $sf --no-cpu-baseline > $OUT/bench_s$sf.json 2>> $OUT/bench.err; cat $OUT/bench_s$sf.json; done
+  timeout 300 python bench.py --batch 36 --no-cpu-baseline > $OUT/bench_hd36.json 2>> $OUT/bench.err; cat $OUT/bench_hd36.json
+  timeout 300 python bench.py --dtype fp16 --no-cpu-baseline > $OUT/bench_fp16.json 2>> $OUT/bench.err; cat $OUT/bench_fp16.json
+fi
+if has prof; then
+  echo "== rocprof kernel trace =="
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/rocprof -o bench -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/$OUT/rocprof_bench.log 2>&1 ); echo "rocprof exit $?"
+  F=$(find $OUT/rocprof -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && head -16 "$F"
+  find $OUT/rocprof -name "*kernel_trace.csv" -size +20M -delete
+fi
+if has pmc; then
+  echo "== rocprof PMC passes (own runs, kernel-trace only) =="
+  for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+    N=$(echo $C | tr ' ' '_' | cut -c1-24)
+    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/pmc_$N -o pmc -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $R/$OUT/pmc_$N.log 2>&1 ); echo "pmc $N exit $?"
+  done
+  python tools/pmc_summary.py $OUT > $OUT/pmc_summary.json 2> $OUT/pmc_summary.err; cat $OUT/pmc_summary.json | head -60; tail -3 $OUT/pmc_summary.err
+  find $OUT -name "*kernel_trace.csv" -size +20M -delete
+fi
 du -sh $OUT
