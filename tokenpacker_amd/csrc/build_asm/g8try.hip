@@ -38,7 +38,7 @@
 // with s_waitcnt vmcnt(0) and drain it).  Variants that did NOT pay on MI355X and were removed: 32-MFMA
 // segments (same wall time, the kernel is power-limited: fewer cycles came back as lower clock) and releasing the
 // partner wave a few MFMAs early (-10 %: matrix beside matrix on one SIMD); see profiles/r01c_gemm_bench.json.
-#include "tp_gemm_common.h"
+#include "../tp_gemm_common.h"
 #include <mutex>
 
 namespace tp {
@@ -397,7 +397,7 @@ static int launch8_types(const GemmArgs& a, hipStream_t stream) {
 }
 
 // Preconditions (checked by gemm_launch): N % 256 == 0, K % 64 == 0, (long long)N_tile_rows * K * 2 < 2^31.
-int gemm8_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream) {
+int gemm8_launch_unused(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream) {
     if (in_dtype == TP_BF16) {
         if (out_dtype == TP_BF16) return launch8_types<bf16_t, bf16_t>(a, stream);
         if (out_dtype == TP_F16) return launch8_types<bf16_t, f16_t>(a, stream);
@@ -412,3 +412,4 @@ int gemm8_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t str
 }
 
 }  // namespace tp
+namespace tp { template __global__ void gemm8_kernel<bf16_t, f16_t, true, true>(const GemmArgs, const int, const int, const int); }

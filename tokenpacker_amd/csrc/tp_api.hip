@@ -253,8 +253,8 @@ int tp_linear(const tp_linear_args* a, void* stream) {
         return TP_ERR_INVALID_ARG;
     }
     if (a->lda % 8 != 0 || a->a_batch_stride % 8 != 0 || ((uintptr_t)a->A & 15) || ((uintptr_t)a->W & 15) ||
-        ((uintptr_t)a->C & 15) || a->ldc % 4 != 0) {
-        set_error("tp_linear: A/W/C must be 16-byte aligned, lda and batch stride multiples of 8 elements");
+        ((uintptr_t)a->C & 15) || a->ldc % 8 != 0) {
+        set_error("tp_linear: A/W/C must be 16-byte aligned, lda, ldc and batch stride multiples of 8 elements");
         return TP_ERR_INVALID_ARG;
     }
     GemmArgs g{};

@@ -54,12 +54,22 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 //   acc[i][j][r] = C[m0 + wm*WM + i*16 + (lane&15)][n0 + wn*WN + j*16 + (lane>>4)*4 + r]
 // (operands are swapped into the MFMA, so a lane owns 4 CONSECUTIVE columns of one row).
 // mean_rstd[i] is the LayerNorm-fold (mean, rstd) of row i's fragment row (ignored without LN_FOLD).
-// `smem` must be free (no DMA in flight, nobody reading) — the ROW_STATS path re-uses it after a barrier.
-template <typename TO, int BM, int BN, int WM, int WN>
+// `smem`: 8 KiB of LDS scratch nobody else touches while the epilogue runs (ROW_STATS reduction).
+// `lds_par` (optional): the tile's epilogue parameters staged in LDS by the caller — fp32 bias[BN] at +0 and
+// colsum[BN] at +4*BN, indexed by the column INSIDE the tile — instead of global loads (persistent kernel: no
+// ordinary vector load may be outstanding next to the LDS-DMA queue, or hipcc drains it).
+// Barriers are raw s_barrier + lgkmcnt(0): a __syncthreads() would also drain vmcnt, i.e. the DMA of the NEXT tile.
+__device__ __forceinline__ void block_sync_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+template <typename TO, int BM, int BN, int WM, int WN, bool LDS_PARAMS = false>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], const GemmArgs& p, const int g,
                                               const int m0, const int n0, const int tile_n, const int wm,
                                               const int wn, const int lane, const int tid,
-                                              const float2 (&mean_rstd)[WM / 16], char* smem) {
+                                              const float2 (&mean_rstd)[WM / 16], char* smem,
+                                              const char* lds_par = nullptr) {
     constexpr bool OUT_F32 = std::is_same<TO, float>::value;
     constexpr int NWM = BM / WM, NWN = BN / WN, NW = NWM * NWN;
     constexpr int FM = WM / 16, FN = WN / 16;
@@ -70,70 +80,121 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
     char* __restrict__ Cg = p.C + g * p.c_gs;
 
     f32x4 bias_v[FN], csum_v[FN];
+    if constexpr (LDS_PARAMS) {
+        const int lc = wn * WN + (lane >> 4) * 4;      // column inside the tile
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-        bias_v[j] = bias ? *(const f32x4*)(bias + col_base + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
-        csum_v[j] = (flags & TP_LINEAR_LN_FOLD) ? *(const f32x4*)(colsum + col_base + j * 16)
-                                                : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FN; ++j) {
+            bias_v[j] = *(const f32x4*)(lds_par + (lc + j * 16) * 4);
+            csum_v[j] = *(const f32x4*)(lds_par + BN * 4 + (lc + j * 16) * 4);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            bias_v[j] = bias ? *(const f32x4*)(bias + col_base + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+            csum_v[j] = (flags & TP_LINEAR_LN_FOLD) ? *(const f32x4*)(colsum + col_base + j * 16)
+                                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
 
-    float rs1[FM], rs2[FM];
+    // Row statistics are accumulated per 64-column slice (VW slices per wave) and combined below in a fixed
+    // tree, so a wave that owns 128 columns produces bit-identical sums to two waves that own 64 each.
+    constexpr int VW = WN / 64;                    // 64-column slices per wave
+    constexpr int FNV = FN / VW;                   // fragments per slice (= 4)
+    static_assert(WN % 64 == 0, "wave tile must be a multiple of 64 columns");
+    float rs1[FM][VW], rs2[FM][VW];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * WM + i * 16 + (lane & 15);
         const bool row_ok = m < p.M;
         const float mu = mean_rstd[i].x, rstd = mean_rstd[i].y;
-        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            f32x4 v = acc[i][j];
-            if (flags & TP_LINEAR_LN_FOLD) v = rstd * (v - mu * csum_v[j]);
-            v += bias_v[j];
-            if (flags & TP_LINEAR_GELU) {
+        for (int vs = 0; vs < VW; ++vs) {
+            float s1 = 0.f, s2 = 0.f;
+            // fragments are finished in PAIRS (j, j+1): a lane owns 4 consecutive columns of each; one
+            // v_permlane16_swap per dword trades the odd 16-lane rows' fragment-j half against the even rows'
+            // fragment-(j+1) half, after which every lane holds 8 consecutive columns -> 16-byte stores, 64
+            // contiguous bytes per output row and instruction (the epilogue is store-ISSUE bound: measured 12.5 us
+            // per 256x256 tile with 8-byte stores, profiles/r01g_epilogue_probe.txt).
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-            }
-            const long long coff = (long long)m * p.ldc + col_base + j * 16;
-            if constexpr (OUT_F32) {
-                if (row_ok) *(f32x4*)((float*)Cg + coff) = v;
-            } else {
-                using O4 = typename Vec<TO>::x4;
-                if constexpr (std::is_same<TO, f16_t>::value) {     // saturate instead of producing inf
+            for (int jj = 0; jj < FNV; jj += 2) {
+                const int j0 = vs * FNV + jj, j1 = j0 + 1;
+                f32x4 v0 = acc[i][j0], v1 = acc[i][j1];
+                if (flags & TP_LINEAR_LN_FOLD) { v0 = rstd * (v0 - mu * csum_v[j0]); v1 = rstd * (v1 - mu * csum_v[j1]); }
+                v0 += bias_v[j0]; v1 += bias_v[j1];
+                if (flags & TP_LINEAR_GELU) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r], -65504.f), 65504.f);
+                    for (int r = 0; r < 4; ++r) { v0[r] = gelu_erf(v0[r]); v1[r] = gelu_erf(v1[r]); }
                 }
-                const O4 o = __builtin_convertvector(v, O4);
-                if (row_ok) *(O4*)((TO*)Cg + coff) = o;
-                if (flags & TP_LINEAR_ROW_STATS) v = __builtin_convertvector(o, f32x4);  // stats of the ROUNDED values
-            }
-            if (flags & TP_LINEAR_ROW_STATS) {
+                const long long coff = (long long)m * p.ldc + col_base;
+                if constexpr (OUT_F32) {
+                    if (row_ok) {
+                        *(f32x4*)((float*)Cg + coff + j0 * 16) = v0;
+                        *(f32x4*)((float*)Cg + coff + j1 * 16) = v1;
+                    }
+                } else {
+                    using O4 = typename Vec<TO>::x4;
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    if constexpr (std::is_same<TO, f16_t>::value) {     // saturate instead of producing inf
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { s1 += v[r]; s2 += v[r] * v[r]; }
+                        for (int r = 0; r < 4; ++r) {
+                            v0[r] = fminf(fmaxf(v0[r], -65504.f), 65504.f);
+                            v1[r] = fminf(fmaxf(v1[r], -65504.f), 65504.f);
+                        }
+                    }
+                    const O4 o0 = __builtin_convertvector(v0, O4), o1 = __builtin_convertvector(v1, O4);
+                    if (flags & TP_LINEAR_ROW_STATS) {                  // stats of the ROUNDED values, fragment order
+                        v0 = __builtin_convertvector(o0, f32x4);
+                        v1 = __builtin_convertvector(o1, f32x4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { s1 += v0[r]; s2 += v0[r] * v0[r]; }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { s1 += v1[r]; s2 += v1[r] * v1[r]; }
+                    }
+                    u32x2 a = __builtin_bit_cast(u32x2, o0), b = __builtin_bit_cast(u32x2, o1);
+                    const auto sx = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+                    const auto sy = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+                    // even 16-lane rows now hold columns g*4 .. g*4+7 of fragment j0 (own | upper neighbour's),
+                    // odd rows columns (g-1)*4 .. (g-1)*4+7 of fragment j1 (lower neighbour's | own)
+                    const int gq = lane >> 4;
+                    const int col = n0 + wn * WN + (j0 + (gq & 1)) * 16 + (gq >> 1) * 8;
+                    if (row_ok) *(u32x4*)((TO*)Cg + (long long)m * p.ldc + col) = u32x4{sx[0], sy[0], sx[1], sy[1]};
+                }
+                if constexpr (OUT_F32) {
+                    if (flags & TP_LINEAR_ROW_STATS) {                  // (rejected by gemm_launch; kept for completeness)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { s1 += v0[r]; s2 += v0[r] * v0[r]; }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { s1 += v1[r]; s2 += v1[r] * v1[r]; }
+                    }
+                }
             }
+            rs1[i][vs] = s1; rs2[i][vs] = s2;
         }
-        rs1[i] = s1; rs2[i] = s2;
     }
 
     if (flags & TP_LINEAR_ROW_STATS) {
-        // reduce over the 4 lane groups that share a row, then over the NWN waves through LDS
-        float* red = (float*)smem;                 // [NWN][BM][2]
-        __syncthreads();                           // everyone is done with the K-slab buffers
+        // reduce over the 4 lane groups that share a row, then over the 64-column slices through LDS
+        float* red = (float*)smem;                 // [BN/64][BM][2]
+        block_sync_lds();                          // everyone is done with the scratch / K-slab buffers
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            float s1 = rs1[i], s2 = rs2[i];
-            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-            if (lane < 16) {
-                const int rr = wm * WM + i * 16 + lane;
-                red[(wn * BM + rr) * 2 + 0] = s1;
-                red[(wn * BM + rr) * 2 + 1] = s2;
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int vs = 0; vs < VW; ++vs) {
+                float s1 = rs1[i][vs], s2 = rs2[i][vs];
+                s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                if (lane < 16) {
+                    const int rr = wm * WM + i * 16 + lane;
+                    red[((wn * VW + vs) * BM + rr) * 2 + 0] = s1;
+                    red[((wn * VW + vs) * BM + rr) * 2 + 1] = s2;
+                }
             }
-        }
-        __syncthreads();
+        block_sync_lds();
         // one slab per 128 output columns, whatever the tile: the partial-sum tree (lane -> 4 lane groups ->
-        // the 128/WN waves of a slab) is identical for every tile shape, so results do not depend on the
-        // tile the batch size selects (bit-exact batch invariance).
-        constexpr int SLABS = BN / 128, WPS = 128 / WN;
+        // the two 64-column slices of a slab) is identical for every tile / wave shape, so results do not depend
+        // on the kernel the batch size selects (bit-exact batch invariance).
+        constexpr int SLABS = BN / 128, WPS = 2;
         for (int idx = tid; idx < BM * SLABS; idx += NW * 64) {
             const int rr = idx % BM, sl = idx / BM;
             float s1 = 0.f, s2 = 0.f;

@@ -52,4 +52,15 @@ if has pmc; then
   python tools/pmc_summary.py $OUT > $OUT/pmc_summary.json 2> $OUT/pmc_summary.err; cat $OUT/pmc_summary.json | head -60; tail -3 $OUT/pmc_summary.err
   find $OUT -name "*kernel_trace.csv" -size +20M -delete
 fi
+if has gemmpmc; then
+  echo "== GEMM variants under PMC (two passes) =="
+  i=0
+  for C in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA GRBM_GUI_ACTIVE"; do
+    i=$((i+1))
+    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/pmc_gemm$i -o pmc -- python $R/tools/gemm_bench.py --rounds 1 --iters 2 --out $R/$OUT/gemm_bench_pmc.json > $R/$OUT/pmc_gemm$i.log 2>&1 ); echo "pmc gemm pass $i exit $?"
+  done
+  python tools/pmc_summary.py $OUT --all > $OUT/pmc_gemm_summary.json 2> $OUT/pmc_summary.err; tail -3 $OUT/pmc_summary.err
+  find $OUT -name "*kernel_trace.csv" -size +20M -delete
+fi
 du -sh $OUT

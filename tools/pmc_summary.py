@@ -29,7 +29,7 @@ def main(root: str) -> None:
             per_dispatch = defaultdict(float)
             names = {}
             for row in csv.DictReader(f):
-                k = short(row.get("Kernel_Name", "?"))
+                k = short(row.get("Kernel_Name", "?")) + (f" grid={row.get('Grid_Size')}" if ALL else "")
                 key = (row.get("Dispatch_Id"), k, row.get("Counter_Name"))
                 per_dispatch[key] += float(row.get("Counter_Value", 0) or 0)   # rows may be split per XCD/instance
                 per_dispatch[(row.get("Dispatch_Id"), k, "duration_ns")] = \
@@ -42,7 +42,7 @@ def main(root: str) -> None:
                                                   "Workgroup_Size", "Grid_Size")}
     out = {}
     for k, counters in sorted(acc.items()):
-        if not (k.startswith("tp::") or "gemm" in k):
+        if not (k.startswith("tp::") or "gemm" in k or (ALL and "Cijk" in k)):
             continue
         rec = {"dispatches": max(len(v) for v in counters.values()), **{m: meta[k][m] for m in meta.get(k, {})}}
         for c, vals in counters.items():
@@ -64,6 +64,8 @@ def main(root: str) -> None:
     json.dump(out, sys.stdout, indent=1)
     print()
 
+
+ALL = "--all" in sys.argv
 
 if __name__ == "__main__":
     main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out")
