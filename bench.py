@@ -63,6 +63,9 @@ def parse_args():
                     help="tower = non-contiguous [:,1:] slices as the CLIP tower hands them over")
     ap.add_argument("--no-gather", action="store_true", help="skip the all-gather of projected tokens (N>1)")
     ap.add_argument("--overlap-chunks", type=int, default=1)
+    ap.add_argument("--sync-gather", action="store_true",
+                    help="N>1: finish each step's all-gather before the next forward (default: the gather of step i "
+                         "overlaps the forward of step i+1, two rotating output buffers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     ap.add_argument("--tile", type=int, default=0, help="force GEMM tile (0 auto, 128, 256)")
@@ -148,12 +151,19 @@ def main():
     total = B * world
     gather = world > 1 and not args.no_gather
 
+    pipe = shard.TokenGatherPipeline(total, depth=2) if (gather and not args.sync_gather) else None
+
     def step():
+        if pipe is not None:                 # forward of this step overlaps the gather of the previous one
+            slot = pipe.submit(model((x, xm)))
+            return pipe._bufs[slot]
         if gather:
             return shard.project_sharded(model, x, xm, total, overlap_chunks=args.overlap_chunks)
         return model((x, xm))
 
     def fence():
+        if pipe is not None:
+            pipe.drain()                     # every gather issued so far is complete inside the timed region
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
@@ -217,7 +227,8 @@ def main():
                                    f"B={B} images/GPU, CLIP-L/14 336px grid 24x24, C=1024, Cmulti=4096, D={D}",
                        "global_batch": total, "per_gpu_batch": B, "scale_factor": s, "hidden_size": D,
                        "input_layout": args.layout,
-                       "parallelism": f"batch-shard x{world}" + (" + all_gather(tokens)" if gather else ""),
+                       "parallelism": f"batch-shard x{world}" + ((" + all_gather(tokens)" + (
+                           ", gather of step i overlapped with forward of step i+1" if pipe is not None else "")) if gather else ""),
                        "weights": "random init (reference distribution), synthetic unit-normal CLIP features"},
             "whole_path": {"achieved_tflops": round(fl_img * B / (ms_per_step * 1e-3) / 1e12, 1),
                            "frac_of_mfma_peak": round(fl_img * B / (ms_per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),

@@ -55,7 +55,20 @@ def _worker(rank, world, port, total, chunks, ret):
         y_loc = shard.project_sharded(project, xl, xml, total, gather=False)
         lo, hi = shard.shard_bounds(total, world, rank)
         ok_loc = torch.allclose(y_loc, y_ref[lo:hi], atol=1e-5)
-        ret[rank] = bool(ok and same and ok_loc)
+        # pipelined gather of a stream of batches: two batches in flight, results in rank order
+        pipe = shard.TokenGatherPipeline(total, depth=2) if total % world == 0 else None
+        ok_pipe = True
+        if pipe is not None:
+            outs = []
+            for k in range(3):
+                slot = pipe.submit(y_loc * (k + 1))
+                outs.append((slot, k))
+                if k >= 1:                       # consume the batch submitted one step earlier
+                    ps, pk = outs[k - 1]
+                    ok_pipe &= torch.equal(pipe.result(ps), y * (pk + 1))
+            pipe.drain()
+            ok_pipe &= torch.equal(pipe.result(outs[-1][0]), y * 3)
+        ret[rank] = bool(ok and same and ok_loc and ok_pipe)
     finally:
         dist.destroy_process_group()
 

@@ -73,6 +73,55 @@ def all_gather_tokens(local: torch.Tensor, total: int, group: Optional[dist.Proc
     return (gathered, work) if async_op else gathered
 
 
+class TokenGatherPipeline:
+    """Software-pipelined all-gather of projected tokens for a STREAM of batches (serving / eval: batch i+1 is
+    being projected while batch i's tokens travel).  Each ``submit(local)`` launches ONE asynchronous
+    ``all_gather_into_tensor`` into one of ``depth`` rotating ``[total, M, D]`` buffers and returns the slot;
+    ``result(slot)`` (or ``drain()``) makes the current stream wait for that gather.  The collective runs on the
+    communicator's own stream, so with ``depth >= 2`` it overlaps the next forward's kernels: on one MI355X node
+    the gather is per-link bound (every rank receives (P-1)/P of the output over its xGMI links, ~4 ms for
+    256 images/GPU) — about the time of the projection itself, i.e. it hides almost entirely.
+    Equal shards only (ragged crop lists: ``all_gather_tokens``)."""
+
+    def __init__(self, total: int, group: Optional[dist.ProcessGroup] = None, depth: int = 2):
+        ws = dist.get_world_size(group)
+        if total % ws != 0:
+            raise ValueError(f"TokenGatherPipeline needs equal shards (total {total}, world size {ws})")
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        self.total, self.group, self.depth = total, group, depth
+        self._bufs: List[Optional[torch.Tensor]] = [None] * depth
+        self._work = [None] * depth
+        self._keep = [None] * depth          # the local shard of an in-flight gather must stay alive
+        self._next = 0
+
+    def submit(self, local: torch.Tensor) -> int:
+        slot = self._next
+        self._next = (slot + 1) % self.depth
+        self.result(slot)                    # the buffer's previous gather must be complete before it is re-targeted
+        local = local.contiguous()
+        shape = (self.total,) + tuple(local.shape[1:])
+        buf = self._bufs[slot]
+        if buf is None or buf.shape != shape or buf.dtype != local.dtype or buf.device != local.device:
+            buf = torch.empty(shape, dtype=local.dtype, device=local.device)
+            self._bufs[slot] = buf
+        self._keep[slot] = local
+        self._work[slot] = dist.all_gather_into_tensor(buf, local, group=self.group, async_op=True)
+        return slot
+
+    def result(self, slot: int) -> Optional[torch.Tensor]:
+        w = self._work[slot]
+        if w is not None:
+            w.wait()
+            self._work[slot] = None
+            self._keep[slot] = None
+        return self._bufs[slot]
+
+    def drain(self) -> None:
+        for slot in range(self.depth):
+            self.result(slot)
+
+
 def project_sharded(project: Callable[[Tuple[torch.Tensor, torch.Tensor]], torch.Tensor],
                     x_local: torch.Tensor, xm_local: torch.Tensor, total: int,
                     group: Optional[dist.ProcessGroup] = None, gather: bool = True,
