@@ -102,8 +102,8 @@ size_t tp_workspace_bytes(const tp_desc* desc);
  * Replaces what `TokenPacker.__init__` + `load_state_dict` leave in the nn.Parameters
  * (builder.py:59-83, llava_arch.py:78-83): re-lays the 23 tensors out for the kernels — K/V first
  * layers concatenated into one [2048,4096] operand, the three LayerNorm affines folded into the
- * attention in-projection (W' = W·diag(gamma), c = rowsum(W'), b' = W·beta + b), biases widened to
- * fp32.  Must be re-run whenever a parameter changes.  `packed` needs tp_packed_weight_bytes(). */
+ * attention in-projection (W' = W·diag(gamma), c = rowsum(W'), b' = W·beta + b), out_proj folded into
+ * mlp[0] (W = Wm0·Wout, b = Wm0·bout + bm0), biases widened to fp32.  Must be re-run whenever a parameter changes.  `packed` needs tp_packed_weight_bytes(). */
 int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, size_t packed_bytes,
                     void* stream);
 
@@ -204,7 +204,9 @@ int tp_linear_stats_parts(const tp_linear_args* args);
 /* ---- tuning knobs (benchmarks only; defaults are what tp_forward ships with) ------------------ */
 enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto | 128 | 256                                              */
        TP_TUNE_XCD_SWIZZLE = 1, /* 1 (default) | 0                                                 */
-       TP_TUNE_GEMM_KERNEL = 2, /* 256-tile main loop: 0 ping-pong 8-wave (default) | 1 two-phase   */
+       TP_TUNE_GEMM_KERNEL = 2, /* 256-tile main loop: 0 persistent ping-pong (default) | 1 two-phase
+                                   | 2 ping-pong, one tile per workgroup | 10..12 one wave per SIMD    */
+       TP_TUNE_FOLD_OUT_PROJ = 3, /* 0 (default): out_proj and mlp[0] as two GEMMs | 1: folded (W = Wm0·Wout) */
        TP_TUNE_COUNT_ = 8 };
 int tp_set_tuning(int key, int value);
 

@@ -170,6 +170,31 @@ def test_full_size_properties_B256():
     assert torch.equal(sums, sums[:1].expand_as(sums))
 
 
+def test_out_proj_fold_is_equivalent():
+    """TP_TUNE_FOLD_OUT_PROJ: out_proj folded into mlp[0] at pack time (W = Wm0·Wout) is the same function up to
+    the rounding of one weight product instead of one activation: same error level against the fp64 oracle."""
+    from tokenpacker_amd import _capi
+    dtype, D, s = torch.float16, 256, 2
+    params = synth.make_params(31, D)
+    x, xm = synth.make_inputs(32, 2, dtype)
+    p_lp = {k: v.to(dtype) for k, v in params.items()}
+    y_exact = orc.forward(p_lp, x, xm, scale_factor=s, compute_dtype=torch.float64, io_dtype=dtype)
+    errs = []
+    try:
+        for fold in (0, 1):
+            _capi.set_tuning(_capi.TP_TUNE_FOLD_OUT_PROJ, fold)
+            m = _module(params, s, D, dtype)
+            m.output_fp32 = True
+            with torch.no_grad():
+                y = m((x.cuda(), xm.cuda()))
+            errs.append((orc.rel_err(y, y_exact), orc.rel_l2(y, y_exact), y))
+    finally:
+        _capi.set_tuning(_capi.TP_TUNE_FOLD_OUT_PROJ, 0)
+    print(f"\n[parity] out_proj fold off/on: rel_err {errs[0][0]:.3e} / {errs[1][0]:.3e}, rel_l2 {errs[0][1]:.3e} / {errs[1][1]:.3e}")
+    assert not torch.equal(errs[0][2], errs[1][2])             # the knob really switches the path
+    assert errs[1][1] <= 1.1 * errs[0][1] and errs[1][0] <= 1.5e-3
+
+
 def test_errors_on_gpu_inputs():
     m = TokenPacker(hidden_size=256).to(device="cuda", dtype=torch.bfloat16).requires_grad_(False)
     x = torch.zeros(1, 576, 1024, device="cuda", dtype=torch.bfloat16)

@@ -55,6 +55,8 @@ PackedLayout packed_layout(int D) {
     L.w_out = take(E * E * 2);           L.b_out = take(E * 4);
     L.w_m0 = take((size_t)D * E * 2);    L.b_m0 = take((size_t)D * 4);
     L.w_m2 = take((size_t)D * D * 2);    L.b_m2 = take((size_t)D * 4);
+    L.w_om = take((size_t)D * E * 2);    L.b_om = take((size_t)D * 4);
+    L.scratch_t = take(E * E * 2);       L.scratch_p = take((size_t)D * E * 4);
     L.total = off;
     return L;
 }
@@ -202,6 +204,17 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
     TP_TRY(pack_cast_f32_launch(dt, raw->mlp_0_bias, (float*)(P + L.b_m0), D, stream));
     TP_TRY(pack_cast_f16_launch(dt, raw->mlp_2_weight, P + L.w_m2, (long long)D * D, stream));
     TP_TRY(pack_cast_f32_launch(dt, raw->mlp_2_bias, (float*)(P + L.b_m2), D, stream));
+    // out_proj folded into mlp[0]:  W_om = Wm0·Wout (fp32 accumulate on the MFMA kernel, rounded once to fp16),
+    // b_om = Wm0·bout + bm0
+    TP_TRY(pack_transpose_f16_launch(P + L.w_out, P + L.scratch_t, (int)E, stream));
+    {
+        GemmArgs a = plain_gemm(P + L.w_m0, E, P + L.scratch_t, P + L.scratch_p, E, D, (int)E, (int)E, nullptr, 0);
+        a.tile = 128;
+        TP_TRY(gemm_launch(TP_F16, TP_F32, a, stream));
+    }
+    TP_TRY(pack_round_f16_launch((const float*)(P + L.scratch_p), P + L.w_om, (long long)D * E, stream));
+    TP_TRY(pack_bias_fold_launch(P + L.w_m0, (const float*)(P + L.b_out), (const float*)(P + L.b_m0),
+                                 (float*)(P + L.b_om), D, (int)E, stream));
     return TP_OK;
 }
 
@@ -359,15 +372,18 @@ static int forward_impl(const tp_desc* desc, const void* x, const int64_t x_stri
     // 7. region-to-point attention
     TP_TRY(region_attention_launch(ws + W.q, ws + W.kv, ws + W.kv + kvE * 2, ws + W.o, B, g, s, stream));
     TP_TRY(mark());
-    // 8. out_proj
-    {
+    // 8. out_proj — optionally folded into mlp[0] at pack time (TP_TUNE_FOLD_OUT_PROJ, default OFF): -2 % time, same
+    //    rel-L2 error, but the max-error metric of one golden case moved from 0.92e-3 to 1.09e-3 (gate 1e-3)
+    const bool fold = tuning(TP_TUNE_FOLD_OUT_PROJ) != 0;
+    if (!fold) {
         GemmArgs a = plain_gemm(ws + W.o, E, pw + P.w_out, ws + W.a1, E, rows_q, E, E, (const float*)(pw + P.b_out), 0);
         TP_TRY(gemm_launch(TP_F16, TP_F16, a, stream));
     }
     TP_TRY(mark());
-    // 9. mlp[0] + GELU
+    // 9. mlp[0] + GELU   (on O with W_om = Wm0·Wout when folded)
     {
-        GemmArgs a = plain_gemm(ws + W.a1, E, pw + P.w_m0, ws + W.a2, D, rows_q, D, E, (const float*)(pw + P.b_m0), TP_LINEAR_GELU);
+        GemmArgs a = fold ? plain_gemm(ws + W.o, E, pw + P.w_om, ws + W.a2, D, rows_q, D, E, (const float*)(pw + P.b_om), TP_LINEAR_GELU)
+                          : plain_gemm(ws + W.a1, E, pw + P.w_m0, ws + W.a2, D, rows_q, D, E, (const float*)(pw + P.b_m0), TP_LINEAR_GELU);
         TP_TRY(gemm_launch(TP_F16, TP_F16, a, stream));
     }
     TP_TRY(mark());

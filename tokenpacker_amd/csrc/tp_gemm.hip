@@ -156,7 +156,7 @@ int gemm_pick_tile(int M, int N, int forced) {
     if (forced == 256 && N % 256 == 0) return 256;
     if (N % 256 != 0) return 128;
     const long long tiles256 = (long long)((M + 255) / 256) * (N / 256);
-    return tiles256 >= 512 ? 256 : 128;     // >= 2 full waves of the 256 CUs, else finer tiles
+    return tiles256 >= 200 ? 256 : 128;     // the persistent 256-tile kernel from ~0.8 of a CU round up, else finer tiles
 }
 
 template <typename TI, typename TO, int BM, int BN, int WM, int WN, bool STRIDED_A>

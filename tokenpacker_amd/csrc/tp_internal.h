@@ -70,6 +70,10 @@ int ln_finalize_launch(const float* parts, float* mean_rstd, long long M, int np
                        float eps, hipStream_t stream);
 int pack_cast_f32_launch(int dtype, const void* src, float* dst, int n, hipStream_t stream);
 int pack_cast_f16_launch(int dtype, const void* src, void* dst_f16, long long n, hipStream_t stream);
+int pack_transpose_f16_launch(const void* src_f16, void* dst_f16, int n, hipStream_t stream);          // [n,n]
+int pack_round_f16_launch(const float* src, void* dst_f16, long long n, hipStream_t stream);           // saturating
+int pack_bias_fold_launch(const void* w_f16, const float* v, const float* b, float* out, int n_out, int n_in,
+                          hipStream_t stream);                                                          // out = w·v + b
 int pack_ln_fold_launch(int dtype, const void* w, const void* bias, const void* gamma,
                         const void* beta, void* w_out, float* colsum, float* bias_out, int n_out,
                         int n_in, hipStream_t stream);
@@ -84,6 +88,8 @@ struct PackedLayout {
     size_t w_out, b_out;          // [1024,1024] f16, [1024] f32
     size_t w_m0, b_m0;            // [D,1024] f16, [D] f32
     size_t w_m2, b_m2;            // [D,D] f16, [D] f32
+    size_t w_om, b_om;            // out_proj folded into mlp[0]: (Wm0·Wout) [D,1024] f16, Wm0·bout + bm0 [D] f32
+    size_t scratch_t, scratch_p;  // pack-time scratch: Wout^T [1024,1024] f16, the fp32 product [D,1024]
     size_t total;
 };
 PackedLayout packed_layout(int D);

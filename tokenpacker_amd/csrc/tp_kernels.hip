@@ -240,6 +240,56 @@ int pack_cast_f16_launch(int dtype, const void* src, void* dst, long long n, hip
     return check_launch("pack_cast_f16_kernel");
 }
 
+// out_proj folded into mlp[0] (both are linear with nothing in between, builder.py:126-130 -> :136):
+//   A2 = GELU((O·Wout^T + bout)·Wm0^T + bm0) = GELU(O·(Wm0·Wout)^T + (Wm0·bout + bm0)).
+// The [D,1024]x[1024,1024] product runs on the path's own MFMA kernel (fp32 out) against a transposed copy of
+// Wout; these three helpers are the transposition, the saturating fp32->fp16 rounding and the bias fold.
+__global__ void __launch_bounds__(256)
+pack_transpose_f16_kernel(const f16_t* __restrict__ src, f16_t* __restrict__ dst, int n) {
+    __shared__ f16_t tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = src[(long long)(by + r) * n + bx + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) dst[(long long)(bx + r) * n + by + tx] = tile[tx][r];
+}
+
+int pack_transpose_f16_launch(const void* src, void* dst, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_transpose_f16_kernel, dim3(n / 32, n / 32), dim3(256), 0, stream, (const f16_t*)src,
+                       (f16_t*)dst, n);
+    return check_launch("pack_transpose_f16_kernel");
+}
+
+__global__ void pack_round_f16_kernel(const float* __restrict__ src, f16_t* __restrict__ dst, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (f16_t)fminf(fmaxf(src[i], -65504.f), 65504.f);
+}
+
+int pack_round_f16_launch(const float* src, void* dst, long long n, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_round_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, (f16_t*)dst, n);
+    return check_launch("pack_round_f16_kernel");
+}
+
+__global__ void __launch_bounds__(256)
+pack_bias_fold_kernel(const f16_t* __restrict__ w, const float* __restrict__ v, const float* __restrict__ b,
+                      float* __restrict__ out, int n_in) {
+    const int n = blockIdx.x;
+    float acc = 0.f;
+    for (int kk = threadIdx.x; kk < n_in; kk += blockDim.x) acc = fmaf((float)w[(long long)n * n_in + kk], v[kk], acc);
+    __shared__ float red[4];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[n] = red[0] + red[1] + red[2] + red[3] + b[n];
+}
+
+int pack_bias_fold_launch(const void* w, const float* v, const float* b, float* out, int n_out, int n_in,
+                          hipStream_t stream) {
+    hipLaunchKernelGGL(pack_bias_fold_kernel, dim3(n_out), dim3(256), 0, stream, (const f16_t*)w, v, b, out, n_in);
+    return check_launch("pack_bias_fold_kernel");
+}
+
 // LayerNorm folded into the linear that follows it.  For y = LN(h)·W^T + b with
 // LN(h) = (h − mu)·rstd·gamma + beta:
 //     y_n = rstd·( Σ_k h_k W'_nk − mu·c_n ) + b'_n,   W'_nk = W_nk·gamma_k (rounded to fp16),
