@@ -37,9 +37,8 @@ constexpr int G4_BUF = 2 * G4_A_BYTES;             // 64 KiB: A rows | W rows of
 constexpr int G4_LDS = 2 * G4_BUF;                 // 128 KiB
 }  // namespace
 
-// ILV: 0 = leave the interleave to the compiler, 1 = sched_group_barrier hints, 2 = pinned by source order
-//      (fragment reads one per 2 MFMAs in the first half of a block so they have landed when the block ends,
-//      LDS-DMA one per 2 MFMAs in the second half)
+// ILV: 2 = LDS-DMA staging, 3 = register staging; both pin the MFMA / memory interleave by source order
+//      (leaving it to hipcc, with or without sched_group_barrier hints, measured 20 % slower: profiles/r01e)
 template <typename TI, typename TO, bool STRIDED_A, int ILV>
 __global__ void __launch_bounds__(256, 1)
 gemm4_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
@@ -121,9 +120,11 @@ gemm4_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
     };
 
     using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
-
+    using T_ = std::true_type; using F_ = std::false_type;
     const int nk = p.K / BK;
-    // ---- prologue ---------------------------------------------------------------------------------------------
+
+    if constexpr (ILV == 2) {
+    // ================= LDS-DMA staging, interleave pinned by source order ====================================
     static_for<16>(TP_LAMBDA(c) { issue_piece(c, 0); });
     if (nk > 1) {
         static_for<16>(TP_LAMBDA(c) { issue_piece(c, 1); });
@@ -141,62 +142,96 @@ gemm4_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
         const char* sb = smem + (t & 1) * G4_BUF;
         const char* sb_next = smem + ((t + 1) & 1) * G4_BUF;
         // ---- block A: k-half 0 of tile t, while k-half 1 streams into F1 --------------------------------------
-        if constexpr (ILV == 2) {
-            static_for<64>(TP_LAMBDA(n) {
-                constexpr int nn = decltype(n)::value;
-                if constexpr (nn < 32 && nn % 2 == 0) read_frag(S1{}, std::integral_constant<int, nn / 2>{}, sb);
-                mma(S0{}, n);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        } else {
-            static_for<16>(TP_LAMBDA(n) { read_frag(S1{}, n, sb); });
-            static_for<64>(TP_LAMBDA(n) { mma(S0{}, n); });
-            if constexpr (ILV == 1) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMA
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        static_for<64>(TP_LAMBDA(n) {
+            constexpr int nn = decltype(n)::value;
+            if constexpr (nn < 32 && nn % 2 == 0) read_frag(S1{}, std::integral_constant<int, nn / 2>{}, sb);
+            mma(S0{}, n);
+            __builtin_amdgcn_sched_barrier(0);
+        });
         if constexpr (MORE) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- block B: k-half 1 of tile t, while tile t+2 is requested and k-half 0 of tile t+1 streams into F0 ---
-        if constexpr (ILV == 2) {
-            static_for<64>(TP_LAMBDA(n) {
-                constexpr int nn = decltype(n)::value;
-                if constexpr (MORE && nn < 32 && nn % 2 == 0) read_frag(S0{}, std::integral_constant<int, nn / 2>{}, sb_next);
-                if constexpr (MORE2 && nn >= 32 && nn % 2 == 0) issue_piece(std::integral_constant<int, (nn - 32) / 2>{}, t + 2);
-                mma(S1{}, n);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        } else {
-            if constexpr (MORE2) static_for<16>(TP_LAMBDA(c) { issue_piece(c, t + 2); });
-            if constexpr (MORE) static_for<16>(TP_LAMBDA(n) { read_frag(S0{}, n, sb_next); });
-            static_for<64>(TP_LAMBDA(n) { mma(S1{}, n); });
-            if constexpr (ILV == 1) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if constexpr (MORE2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read (LDS-DMA)
-                    if constexpr (MORE) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // 1 DS read
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                        // 4 MFMA
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        static_for<64>(TP_LAMBDA(n) {
+            constexpr int nn = decltype(n)::value;
+            if constexpr (MORE && nn < 32 && nn % 2 == 0) read_frag(S0{}, std::integral_constant<int, nn / 2>{}, sb_next);
+            if constexpr (MORE2 && nn >= 32 && nn % 2 == 0) issue_piece(std::integral_constant<int, (nn - 32) / 2>{}, t + 2);
+            mma(S1{}, n);
+            __builtin_amdgcn_sched_barrier(0);
+        });
     };
-    using T_ = std::true_type; using F_ = std::false_type;
     int t = 0;
     for (; t < nk - 2; ++t) ktile(T_{}, T_{}, t);
     if (nk >= 2) { ktile(T_{}, F_{}, t); ++t; }
     ktile(F_{}, F_{}, t);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+    } else {
+    // ================= register staging (global -> VGPR -> ds_write_b128), hipBLASLt-style =====================
+    // A lone wave cannot hide the ~60-cycle issue cost of an LDS-DMA instruction behind a partner's MFMAs; plain
+    // buffer loads and ds_write_b128 issue in a few cycles each.  One staging set of 16 x 16 B per lane:
+    //   block A(t):  ds_write stage[c] -> LDS buffer of tile t+1 (c = 0..15), each followed (c < 8) by the load of
+    //                piece c of tile t+2 into the same registers;  16 ds_read of F1 = k-half 1 (t)
+    //   barrier      (tile t+1 written + visible, everyone done reading tile t-1's buffer)
+    //   block B(t):  16 ds_read of F0 = k-half 0 (t+1);  loads of pieces 8..15 of tile t+2
+    // so a global load has a whole K-tile (~2000 cycles) before its ds_write needs it.
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t stage[16];
+    auto gload = [&](auto c_, int kt) __attribute__((always_inline)) {
+        constexpr int c = decltype(c_)::value;
+        if constexpr (c < 8)
+            stage[c] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff_a, kt * ROW_BYTES + c * a_piece, 0));
+        else
+            stage[c] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, voff_w, kt * ROW_BYTES + (c - 8) * w_piece, 0));
+    };
+    auto lwrite = [&](auto c_, int kt) __attribute__((always_inline)) {
+        constexpr int c = decltype(c_)::value;
+        char* dst = smem + (kt & 1) * G4_BUF + (c < 8 ? 0 : G4_A_BYTES) + wave * 8192 + (c & 7) * 1024 + lane * 16;
+        *(u32x4_t*)dst = stage[c];
+    };
+    static_for<16>(TP_LAMBDA(c) { gload(c, 0); });
+    static_for<16>(TP_LAMBDA(c) { lwrite(c, 0); });
+    if (nk > 1) static_for<16>(TP_LAMBDA(c) { gload(c, 1); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<16>(TP_LAMBDA(n) { read_frag(S0{}, n, smem); });
+
+    auto ktile = [&](auto MORE_, auto MORE2_, const int t) __attribute__((always_inline)) {
+        constexpr bool MORE = decltype(MORE_)::value, MORE2 = decltype(MORE2_)::value;
+        const char* sb = smem + (t & 1) * G4_BUF;
+        const char* sb_next = smem + ((t + 1) & 1) * G4_BUF;
+        static_for<64>(TP_LAMBDA(n) {
+            constexpr int nn = decltype(n)::value;
+            if constexpr (MORE && nn % 4 == 0) lwrite(std::integral_constant<int, nn / 4>{}, t + 1);
+            if constexpr (MORE2 && nn % 4 == 1 && nn / 4 < 8) gload(std::integral_constant<int, nn / 4>{}, t + 2);
+            if constexpr (nn % 4 == 2) read_frag(S1{}, std::integral_constant<int, nn / 4>{}, sb);
+            mma(S0{}, n);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if constexpr (MORE) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        static_for<64>(TP_LAMBDA(n) {
+            constexpr int nn = decltype(n)::value;
+            if constexpr (MORE && nn < 32 && nn % 2 == 0) read_frag(S0{}, std::integral_constant<int, nn / 2>{}, sb_next);
+            if constexpr (MORE2 && nn >= 32 && nn % 4 == 0) gload(std::integral_constant<int, 8 + (nn - 32) / 4>{}, t + 2);
+            mma(S1{}, n);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    int t = 0;
+    for (; t < nk - 2; ++t) ktile(T_{}, T_{}, t);
+    if (nk >= 2) { ktile(T_{}, F_{}, t); ++t; }
+    ktile(F_{}, F_{}, t);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
 
     // ---- epilogue ---------------------------------------------------------------------------------------------
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     float2 mean_rstd[FM];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -239,9 +274,8 @@ static int launch4_var(const GemmArgs& a, hipStream_t stream) {
 template <typename TI, typename TO>
 static int launch4_types(const GemmArgs& a, hipStream_t stream) {
     switch (tuning(TP_TUNE_GEMM_KERNEL)) {
-        case 11: return launch4_var<TI, TO, 1>(a, stream);
-        case 12: return launch4_var<TI, TO, 2>(a, stream);
-        default: return launch4_var<TI, TO, 0>(a, stream);
+        case 13: return launch4_var<TI, TO, 3>(a, stream);
+        default: return launch4_var<TI, TO, 2>(a, stream);
     }
 }
 
