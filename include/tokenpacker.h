@@ -205,7 +205,7 @@ int tp_linear_stats_parts(const tp_linear_args* args);
 enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto | 128 | 256                                              */
        TP_TUNE_XCD_SWIZZLE = 1, /* 1 (default) | 0                                                 */
        TP_TUNE_GEMM_KERNEL = 2, /* 256-tile main loop: 0 persistent ping-pong (default) | 1 two-phase
-                                   | 2 ping-pong, one tile per workgroup | 10..12 one wave per SIMD    */
+                                   | 2 ping-pong, one tile per workgroup                              */
        TP_TUNE_FOLD_OUT_PROJ = 3, /* 0 (default): out_proj and mlp[0] as two GEMMs | 1: folded (W = Wm0·Wout) */
        TP_TUNE_COUNT_ = 8 };
 int tp_set_tuning(int key, int value);

@@ -200,10 +200,8 @@ int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stre
         set_error("tp gemm: ROW_STATS with fp32 output is not supported");
         return TP_ERR_INVALID_ARG;
     }
-    if (gemm_pick_tile(a.M, a.N, a.tile) == 256 && tuning(TP_TUNE_GEMM_KERNEL) != 1) {
-        if (tuning(TP_TUNE_GEMM_KERNEL) >= 10 && gemm4_supports(a)) return gemm4_launch(in_dtype, out_dtype, a, stream);
+    if (gemm_pick_tile(a.M, a.N, a.tile) == 256 && tuning(TP_TUNE_GEMM_KERNEL) != 1)
         return gemm8_launch(in_dtype, out_dtype, a, stream);
-    }
     if (in_dtype == TP_BF16) {
         if (out_dtype == TP_BF16) return launch_types<bf16_t, bf16_t>(a, stream);
         if (out_dtype == TP_F16) return launch_types<bf16_t, f16_t>(a, stream);

@@ -54,9 +54,6 @@ int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stre
 int gemm_pick_tile(int M, int N, int forced);     // -> 128 or 256
 // 256x256x64 ping-pong kernel (tp_gemm8.hip); gemm_launch routes tile-256 problems to it
 int gemm8_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream);
-// 256x256x64, one wave per SIMD, 128x128 wave tile (tp_gemm4.hip)
-int gemm4_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream);
-bool gemm4_supports(const GemmArgs& a);
 inline int gemm_stats_parts(int N) { return N / 128; }   // one (sum, sumsq) slab per 128 output columns
 
 // ---- small kernels (tp_kernels.hip) -----------------------------------------------------------

@@ -19,8 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tokenpacker_amd import _capi  # noqa: E402
 
 G, S, F = _capi.TP_LINEAR_GELU, _capi.TP_LINEAR_ROW_STATS, _capi.TP_LINEAR_LN_FOLD
-VARIANTS = [("tile128", 128, 0), ("twophase256", 256, 1), ("pp_persistent", 256, 0), ("pp_onetile", 256, 2),
-            ("w4_dma", 256, 12), ("w4_regstage", 256, 13)]
+VARIANTS = [("tile128", 128, 0), ("twophase256", 256, 1), ("pp_persistent", 256, 0), ("pp_onetile", 256, 2)]
 
 
 def shapes(B, s, D):
