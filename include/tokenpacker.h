@@ -201,6 +201,23 @@ int tp_ln_finalize(const float* row_stats, int parts, int64_t M, int ln_dim, flo
 /* Number of row-stat slabs a TP_LINEAR_ROW_STATS call with these M,N (and args->tile) writes. */
 int tp_linear_stats_parts(const tp_linear_args* args);
 
+/* ---- TokenPacker-HD token assembly (the step right after the projector) --------------------------------
+ * Replaces the Python loop + torch.cat of `prepare_inputs_labels_for_multimodal` in mode 'slice'
+ * (llava_arch.py:140-154): per image, the h_block x w_block crops in row-major order, the ',' embedding after
+ * every crop that is not the last of its row, the '\n' embedding after every row, then (more than one crop)
+ * the global-view crop and '\n'.  tokens [n_crops, M, D], sep / ret [D], out [rows, D]; all of `dtype`.
+ * Image i reads crops first_crop .. and writes rows out_row .. out_row + tp_hd_rows(h, w, M). */
+typedef struct tp_hd_image {
+    int32_t first_crop;
+    int32_t h_block;
+    int32_t w_block;
+    int32_t reserved;
+    int64_t out_row;
+} tp_hd_image;
+int64_t tp_hd_rows(int h_block, int w_block, int M);
+int tp_hd_assemble(const tp_hd_image* plan, int n_images, const void* tokens, const void* sep, const void* ret,
+                   void* out, int M, int D, int dtype, void* stream);
+
 /* ---- tuning knobs (benchmarks only; defaults are what tp_forward ships with) ------------------ */
 enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto | 128 | 256                                              */
        TP_TUNE_XCD_SWIZZLE = 1, /* 1 (default) | 0                                                 */

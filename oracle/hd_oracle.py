@@ -1,0 +1,43 @@
+"""CPU oracle for the TokenPacker-HD token assembly.  TEST INFRASTRUCTURE ONLY (see tokenpacker_oracle.py).
+
+Restates the ``mode == 'slice'`` branch of ``prepare_inputs_labels_for_multimodal``
+(reference ``llava/model/llava_arch.py:140-154``) for ONE image: crops in row-major order, the ``','`` embedding
+between crops of a row, the ``'\\n'`` embedding after every row, then — more than one crop — the global view
+and ``'\\n'``.  Parity pinned by construction: it is a concatenation, checked for length and content
+against the reference's own loop structure in ``tests/test_hd_cpu.py``.  The crop-grid choice
+(``Image_Patch.calculate``) is pinned by ``tests/golden/hd_grid.json``, minted from the real reference by
+``oracle/make_hd_golden.py``."""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import torch
+
+
+def assemble_one(image_features: torch.Tensor, first_crop: int, h_block: int, w_block: int,
+                 sep_embed: torch.Tensor, ret_embed: torch.Tensor):
+    """-> (cur_image_features [rows, D], next crop index)   (llava_arch.py:141-154)."""
+    pieces = []
+    idx = first_crop
+    for h in range(h_block):
+        for w in range(w_block):
+            pieces.append(image_features[idx])
+            idx += 1
+            if w < w_block - 1:
+                pieces.append(sep_embed.reshape(1, -1))
+        pieces.append(ret_embed.reshape(1, -1))
+    if h_block * w_block > 1:
+        pieces.append(image_features[idx])
+        pieces.append(ret_embed.reshape(1, -1))
+        idx += 1
+    return torch.cat(pieces, dim=0), idx
+
+
+def assemble_hd_tokens(image_features: torch.Tensor, h_block: Sequence[int], w_block: Sequence[int],
+                       sep_embed: torch.Tensor, ret_embed: torch.Tensor) -> List[torch.Tensor]:
+    out, idx = [], 0
+    for hb, wb in zip(h_block, w_block):
+        t, idx = assemble_one(image_features, idx, int(hb), int(wb), sep_embed, ret_embed)
+        out.append(t)
+    assert idx == image_features.shape[0]
+    return out

@@ -1,0 +1,48 @@
+"""TokenPacker-HD host logic on CPU: crop-grid selection against goldens minted from the reference's
+``Image_Patch.calculate`` (oracle/make_hd_golden.py), row bookkeeping against the oracle's concatenation, and
+the C ABI's row count."""
+import json
+import os
+
+import pytest
+import torch
+
+from oracle import hd_oracle
+from tokenpacker_amd import _capi, hd
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "hd_grid.json")
+
+
+@pytest.mark.parametrize("patch_num", [9, 16, 25])
+def test_select_grid_matches_reference_choices(patch_num):
+    z = json.load(open(GOLD))
+    assert len(hd._GRID_TABLES[patch_num]) == z["candidates"][str(patch_num)]
+    wrong = [(hw, got, want) for hw, want in zip(z["sizes"], z["choices"][str(patch_num)])
+             if (got := list(hd.select_grid(hw[0], hw[1], patch_num))) != want]
+    assert not wrong, wrong[:5]
+
+
+def test_select_grid_known_cases_and_errors():
+    assert hd.select_grid(1088, 1088, 9) == (3, 3)            # 1088x1088 -> 3x3 grid
+    assert hd.select_grid(336, 336, 9) == (1, 1)
+    with pytest.raises(NotImplementedError):                   # patch_divide.py:80
+        hd.select_grid(100, 100, 10)
+
+
+@pytest.mark.parametrize("h,w", [(1, 1), (1, 2), (2, 1), (3, 3), (1, 9), (9, 1), (2, 4), (5, 5)])
+@pytest.mark.parametrize("M", [36, 64, 144])
+def test_row_count_matches_oracle_and_abi(h, w, M):
+    D = 16
+    n = hd.hd_crop_count(h, w)
+    feats = torch.arange(n * M * D, dtype=torch.float32).reshape(n, M, D)
+    ref, nxt = hd_oracle.assemble_one(feats, 0, h, w, torch.full((D,), -1.0), torch.full((D,), -2.0))
+    assert nxt == n and ref.shape[0] == hd.hd_token_rows(h, w, M)
+    assert _capi.load_library().tp_hd_rows(h, w, M) == ref.shape[0]
+    # BASELINE config 4: a 3x3 grid + global view at s=2 is 10 crops and 1450 LLM tokens
+    if (h, w, M) == (3, 3, 144):
+        assert ref.shape[0] == 1450
+
+
+def test_assemble_rejects_cpu_tensors():
+    with pytest.raises(RuntimeError):
+        hd.assemble_hd_tokens(torch.zeros(1, 4, 8, dtype=torch.bfloat16), [1], [1], torch.zeros(8), torch.zeros(8))

@@ -27,7 +27,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 EXPORTED_SYMBOLS = (
     "tp_version", "tp_last_error", "tp_packed_weight_bytes", "tp_workspace_bytes",
     "tp_pack_weights", "tp_forward", "tp_forward_staged", "tp_point_queries", "tp_region_attention", "tp_linear",
-    "tp_ln_finalize", "tp_linear_stats_parts", "tp_set_tuning",
+    "tp_ln_finalize", "tp_linear_stats_parts", "tp_set_tuning", "tp_hd_rows", "tp_hd_assemble",
 )
 
 # state-dict name -> tp_weights field order (include/tokenpacker.h)
@@ -63,6 +63,11 @@ class tp_linear_args(Structure):
                 ("A", c_void_p), ("W", c_void_p), ("bias", c_void_p), ("C", c_void_p),
                 ("row_mean_rstd", c_void_p), ("colsum", c_void_p),
                 ("tile", c_int32), ("reserved1", c_int32), ("row_stats_out", c_void_p)]
+
+
+class tp_hd_image(Structure):
+    _fields_ = [("first_crop", c_int32), ("h_block", c_int32), ("w_block", c_int32), ("reserved", c_int32),
+                ("out_row", c_int64)]
 
 
 _lib = None
@@ -115,6 +120,11 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.tp_linear_stats_parts.argtypes = [POINTER(tp_linear_args)]
     lib.tp_set_tuning.restype = c_int
     lib.tp_set_tuning.argtypes = [c_int, c_int]
+    lib.tp_hd_rows.restype = c_int64
+    lib.tp_hd_rows.argtypes = [c_int, c_int, c_int]
+    lib.tp_hd_assemble.restype = c_int
+    lib.tp_hd_assemble.argtypes = [POINTER(tp_hd_image), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                   c_int, c_void_p]
 
     if lib.tp_version() != TP_ABI_VERSION:
         raise TokenPackerLibraryError(

@@ -242,6 +242,36 @@ int tp_region_attention(const tp_desc* desc, const void* q, const void* k, const
     return region_attention_launch(q, k, v, o, desc->batch, desc->raw_grid, desc->scale_factor, (hipStream_t)stream);
 }
 
+int64_t tp_hd_rows(int h_block, int w_block, int M) {
+    if (h_block < 1 || w_block < 1 || M < 1) return 0;
+    const int64_t n = (int64_t)h_block * w_block;
+    return n * (M + 1) + (n > 1 ? M + 1 : 0);
+}
+
+int tp_hd_assemble(const tp_hd_image* plan, int n_images, const void* tokens, const void* sep, const void* ret,
+                   void* out, int M, int D, int dtype, void* stream) {
+    if (!plan || !tokens || !sep || !ret || !out || n_images <= 0 || M <= 0) {
+        set_error("tp_hd_assemble: NULL / non-positive argument");
+        return TP_ERR_INVALID_ARG;
+    }
+    if (dtype != TP_BF16 && dtype != TP_F16) { set_error("tp_hd_assemble: dtype %d unsupported", dtype); return TP_ERR_INVALID_ARG; }
+    if (D <= 0 || D % 8 != 0 || ((uintptr_t)tokens & 15) || ((uintptr_t)sep & 15) || ((uintptr_t)ret & 15) || ((uintptr_t)out & 15)) {
+        set_error("tp_hd_assemble: D must be a multiple of 8 and every pointer 16-byte aligned");
+        return TP_ERR_INVALID_ARG;
+    }
+    int crop = 0;
+    int64_t row = plan[0].out_row;
+    for (int i = 0; i < n_images; ++i) {                  // images must tile the crop list and the output in order
+        if (plan[i].h_block < 1 || plan[i].w_block < 1 || plan[i].first_crop < crop || plan[i].out_row < row) {
+            set_error("tp_hd_assemble: plan entry %d is inconsistent", i);
+            return TP_ERR_INVALID_ARG;
+        }
+        crop = plan[i].first_crop + plan[i].h_block * plan[i].w_block + (plan[i].h_block * plan[i].w_block > 1 ? 1 : 0);
+        row = plan[i].out_row + tp_hd_rows(plan[i].h_block, plan[i].w_block, M);
+    }
+    return hd_assemble_launch(plan, n_images, tokens, sep, ret, out, M, D, (hipStream_t)stream);
+}
+
 int tp_ln_finalize(const float* row_stats, int parts, int64_t M, int ln_dim, float eps, float* row_mean_rstd, void* stream) {
     if (!row_stats || !row_mean_rstd || parts <= 0 || M <= 0 || ln_dim <= 0 || !(eps > 0.f)) {
         set_error("tp_ln_finalize: invalid argument");

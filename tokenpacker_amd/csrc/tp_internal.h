@@ -63,6 +63,8 @@ int point_queries_launch(int dtype, const void* x, const int64_t st[3], void* q0
                          int s, hipStream_t stream);
 int region_attention_launch(const void* q, const void* k, const void* v, void* o, int B,
                             int grid, int s, hipStream_t stream);      // fp16 in / fp16 out
+int hd_assemble_launch(const tp_hd_image* plan_dev_or_host, int n_images, const void* tokens, const void* sep,
+                       const void* ret, void* out, int M, int D, hipStream_t stream);
 int ln_finalize_launch(const float* parts, float* mean_rstd, long long M, int nparts, int groups, int ln_dim,
                        float eps, hipStream_t stream);
 int pack_cast_f32_launch(int dtype, const void* src, float* dst, int n, hipStream_t stream);

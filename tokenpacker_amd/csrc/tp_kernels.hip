@@ -181,6 +181,54 @@ int region_attention_launch(const void* q, const void* k, const void* v, void* o
 }
 
 // ---------------------------------------------------------------------------------------------------
+// TokenPacker-HD token assembly (llava_arch.py:140-154).  One workgroup per output row of D 16-bit elements,
+// 16 B per lane.  Row r of an image with an h x w grid: the first h*w*(M+1) rows are h*w segments of M crop
+// tokens + 1 separator (',' unless the crop ends its grid row, then '\n'); with more than one crop, M rows of
+// the global view and a final '\n' follow.  The per-image plan (<= 64 images per launch) travels by value.
+struct HdPlan { tp_hd_image img[64]; int n; };
+
+__global__ void __launch_bounds__(256)
+hd_assemble_kernel(const HdPlan plan, const uint4* __restrict__ tokens, const uint4* __restrict__ sep,
+                   const uint4* __restrict__ ret, uint4* __restrict__ out, int M, int vecs, long long row0) {
+    const long long row = row0 + blockIdx.x;
+    int i = 0;
+    while (i + 1 < plan.n && row >= plan.img[i + 1].out_row) ++i;      // images are in row order
+    const tp_hd_image im = plan.img[i];
+    const int r = (int)(row - im.out_row);
+    const int n = im.h_block * im.w_block, seg_rows = M + 1;
+    const uint4* src;
+    if (r < n * seg_rows) {
+        const int seg = r / seg_rows, k = r - seg * seg_rows;
+        if (k < M) src = tokens + ((long long)(im.first_crop + seg) * M + k) * vecs;
+        else src = (seg % im.w_block == im.w_block - 1) ? ret : sep;
+    } else {
+        const int k = r - n * seg_rows;
+        src = k < M ? tokens + ((long long)(im.first_crop + n) * M + k) * vecs : ret;
+    }
+    uint4* dst = out + row * vecs;
+    for (int v = threadIdx.x; v < vecs; v += blockDim.x) dst[v] = src[v];
+}
+
+int hd_assemble_launch(const tp_hd_image* plan, int n_images, const void* tokens, const void* sep, const void* ret,
+                       void* out, int M, int D, hipStream_t stream) {
+    const int vecs = D / 8;
+    for (int base = 0; base < n_images; base += 64) {
+        HdPlan hp{};
+        hp.n = n_images - base < 64 ? n_images - base : 64;
+        for (int i = 0; i < hp.n; ++i) hp.img[i] = plan[base + i];
+        const tp_hd_image& last = hp.img[hp.n - 1];
+        const long long row0 = hp.img[0].out_row;
+        const long long rows = last.out_row + tp_hd_rows(last.h_block, last.w_block, M) - row0;
+        if (rows <= 0) continue;
+        hipLaunchKernelGGL(hd_assemble_kernel, dim3((unsigned)rows), dim3(256), 0, stream, hp, (const uint4*)tokens,
+                           (const uint4*)sep, (const uint4*)ret, (uint4*)out, M, vecs, row0);
+        const int rc = check_launch("hd_assemble_kernel");
+        if (rc != TP_OK) return rc;
+    }
+    return TP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // LayerNorm statistics: the producing GEMM leaves one (sum, sumsq) slab per 128 output columns
 // ([parts][M][2]); this turns them into per-row (mean, rstd) for the consuming GEMM's epilogue.
 // The slabs are summed in slab order -> deterministic.  ~10 MB of traffic at B=256: noise.

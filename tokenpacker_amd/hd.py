@@ -1,0 +1,103 @@
+"""TokenPacker-HD helpers on either side of the projector.
+
+* :func:`select_grid` — the crop-grid choice for one image (host-side scalar math; reference
+  ``llava/patch_divide.py:71-104`` ``Image_Patch.calculate``).  Pure CPU, like the reference.
+* :func:`hd_token_rows`, :func:`assemble_hd_tokens` — what ``prepare_inputs_labels_for_multimodal`` does
+  with the projected crops in ``mode == 'slice'`` (reference ``llava/model/llava_arch.py:140-154``): the crops
+  of one image row are joined with the ``','`` token embedding, every row and the trailing global view end
+  with the ``'\\n'`` embedding.  The reference builds this with a Python loop and one ``torch.cat`` per image;
+  here ONE kernel launch (``tp_hd_assemble``) writes all images of the batch straight into one
+  ``[rows, D]`` buffer, of which per-image views are returned.  Device tensors only, no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Sequence, Tuple
+
+import torch
+
+from . import _capi
+
+# Candidate grids (h_block, w_block) in the reference's order — the order decides argmax ties, e.g. between
+# (a, b) and (b, a) on square images (patch_divide.py:4-54).  Rule behind the data: every factor pair with
+# product <= 9, and for larger products only pairs with both factors >= 2.
+_GRIDS_9 = ("1x1 1x2 2x1 1x3 3x1 2x2 1x4 4x1 1x5 5x1 1x6 6x1 2x3 3x2 1x7 7x1 4x2 2x4 1x8 8x1 3x3 1x9 9x1")
+_GRIDS_16 = _GRIDS_9 + " 2x5 5x2 2x6 6x2 3x4 4x3 2x7 7x2 3x5 5x3 2x8 8x2 4x4"
+_GRIDS_25 = _GRIDS_16 + (" 3x6 6x3 2x9 9x2 4x5 5x4 2x10 10x2 3x7 7x3 11x2 2x11 4x6 6x4 12x2 2x12 3x8 8x3 4x6 6x4 5x5")
+_GRID_TABLES = {n: tuple(tuple(int(v) for v in g.split("x")) for g in s.split())
+                for n, s in ((9, _GRIDS_9), (16, _GRIDS_16), (25, _GRIDS_25))}
+
+
+def select_grid(h: int, w: int, patch_num: int = 9, image_size: int = 336) -> Tuple[int, int]:
+    """(h_block, w_block) for an ``h x w`` image: the candidate grid maximising
+    ``round(h r) round(w r) / area + 0.1 IoU(grid box, 1.4 x image box)`` with ``r`` the largest scale that fits
+    the image into the grid box — evaluated in float32 tensor arithmetic exactly as the reference does
+    (int64 / int64 true division -> float32, ``torch.round`` half-to-even, first maximum wins)."""
+    if patch_num not in _GRID_TABLES:
+        raise NotImplementedError(f"patch_num {patch_num} (the reference defines 9, 16, 25)")
+    grids = _GRID_TABLES[patch_num]
+    size = (image_size, image_size) if isinstance(image_size, int) else tuple(image_size)
+    box = torch.tensor([[g[0] * size[0], g[1] * size[1]] for g in grids])           # int64 [n, 2] (far corner)
+    area = box[:, 0] * box[:, 1]                                                      # int64
+    img = torch.tensor([h, w])
+    r = (box / img).min(dim=-1)[0]                                                    # float32
+    score = torch.round(h * r) * torch.round(w * r) / area
+    img14 = img * 1.4                                                                 # float32
+    inter = torch.min(box, img14).clamp(min=0).prod(dim=-1)
+    union = area + img14.prod() - inter
+    score = score + inter / (union + 1e-5) * 0.1
+    return grids[int(torch.argmax(score))]
+
+
+def hd_token_rows(h_block: int, w_block: int, num_queries: int) -> int:
+    """Rows of one image's visual-token block: ``h*w`` crops of ``M`` tokens, a separator after every crop
+    (',' inside a row, '\\n' at its end), and — when there is more than one crop — the global view + '\\n'."""
+    n = h_block * w_block
+    return n * (num_queries + 1) + ((num_queries + 1) if n > 1 else 0)
+
+
+def hd_crop_count(h_block: int, w_block: int) -> int:
+    n = h_block * w_block
+    return n + (1 if n > 1 else 0)
+
+
+def assemble_hd_tokens(image_features: torch.Tensor, h_block: Sequence[int], w_block: Sequence[int],
+                       sep_embed: torch.Tensor, ret_embed: torch.Tensor) -> List[torch.Tensor]:
+    """``image_features [n_crops, M, D]`` (projector output for all crops of the batch, crops of image 0 first,
+    row-major inside an image, global view last) -> list of per-image ``[rows_i, D]`` views of one buffer, equal
+    to the reference's ``cur_image_features`` for each image."""
+    if not image_features.is_cuda:
+        raise RuntimeError("assemble_hd_tokens runs only on an AMD GPU (HIP kernel); there is no CPU fallback")
+    if image_features.dim() != 3:
+        raise ValueError("image_features must be [n_crops, M, D]")
+    if len(h_block) != len(w_block):
+        raise ValueError("h_block and w_block must have one entry per image")
+    n_crops, M, D = image_features.shape
+    dt = {torch.bfloat16: _capi.TP_BF16, torch.float16: _capi.TP_F16}.get(image_features.dtype)
+    if dt is None:
+        raise TypeError("image_features must be bfloat16 or float16")
+    feats = image_features.contiguous()
+    sep = sep_embed.reshape(-1).to(device=feats.device, dtype=feats.dtype).contiguous()
+    ret = ret_embed.reshape(-1).to(device=feats.device, dtype=feats.dtype).contiguous()
+    if sep.numel() != D or ret.numel() != D:
+        raise ValueError(f"separator embeddings must have {D} elements")
+    plan = (_capi.tp_hd_image * len(h_block))()
+    first, row, spans = 0, 0, []
+    for i, (hb, wb) in enumerate(zip(h_block, w_block)):
+        hb, wb = int(hb), int(wb)
+        if hb < 1 or wb < 1:
+            raise ValueError("h_block / w_block must be >= 1")
+        plan[i] = _capi.tp_hd_image(first, hb, wb, 0, row)
+        rows = hd_token_rows(hb, wb, M)
+        spans.append((row, rows))
+        first += hd_crop_count(hb, wb)
+        row += rows
+    if first != n_crops:
+        raise ValueError(f"h_block/w_block describe {first} crops, image_features holds {n_crops}")
+    out = torch.empty(row, D, dtype=feats.dtype, device=feats.device)
+    lib = _capi.load_library()
+    with torch.cuda.device(feats.device):
+        _capi.check(lib.tp_hd_assemble(plan, len(h_block), feats.data_ptr(), sep.data_ptr(), ret.data_ptr(),
+                                       out.data_ptr(), M, D, dt, torch.cuda.current_stream(feats.device).cuda_stream),
+                    "tp_hd_assemble")
+    return [out[a:a + n] for a, n in spans]
