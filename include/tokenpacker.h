@@ -171,7 +171,9 @@ enum {
     TP_LINEAR_GELU = 1,        /* exact erf GELU after bias (nn.GELU(), builder.py:63,69,81)      */
     TP_LINEAR_LN_FOLD = 2,
     TP_LINEAR_ROW_STATS = 4,
-    TP_LINEAR_OUT_F32 = 8      /* retired: use tp_linear_args.out_dtype = TP_F32                    */
+    TP_LINEAR_OUT_F32 = 8,     /* retired: use tp_linear_args.out_dtype = TP_F32                    */
+    TP_LINEAR_SAVE_PRE = 16,   /* with GELU: also store the pre-activation (training forward)       */
+    TP_LINEAR_GELU_BWD = 32    /* multiply the result by gelu'(z), z = fp16 pre-activations (backward) */
 };
 typedef struct tp_linear_args {
     int32_t M, N, K;           /* N % 128 == 0, K % 64 == 0                                        */
@@ -200,6 +202,36 @@ int tp_ln_finalize(const float* row_stats, int parts, int64_t M, int ln_dim, flo
                    float* row_mean_rstd, void* stream);
 /* Number of row-stat slabs a TP_LINEAR_ROW_STATS call with these M,N (and args->tile) writes. */
 int tp_linear_stats_parts(const tp_linear_args* args);
+
+/* ---- training: forward that keeps the backward's operands, and the backward pass ---------------------------
+ * Stage-1 training of the reference updates ONLY the projector (llava/train/train.py:950-953); the CLIP features
+ * come from a frozen, no_grad tower (clip_encoder.py:46).  tp_backward therefore produces the gradients of the
+ * 23 parameters (tp_grads mirrors tp_weights, each tensor contiguous, element type desc.dtype) and none for
+ * x / x_multi.  Replaces what autograd records for builder.py:107-137.
+ *   tp_forward_train : tp_forward + the fp16 pre-GELU activations, into a caller-owned `train_workspace`
+ *                      (tp_train_workspace_bytes) that must stay untouched until tp_backward has run.
+ *   tp_backward      : dy [B, M, D] contiguous (desc.dtype) -> grads; `raw` = the model's current parameters
+ *                      (the same tensors tp_pack_weights packed), `bw_workspace` = scratch
+ *                      (tp_backward_workspace_bytes).  Gradients travel in desc.dtype, accumulate in fp32;
+ *                      no atomics: results are deterministic. */
+typedef struct tp_grads {
+    void* q_proj_1_weight;
+    void* k_proj_1_0_weight;  void* k_proj_1_0_bias;  void* k_proj_1_2_weight;  void* k_proj_1_2_bias;
+    void* v_proj_1_0_weight;  void* v_proj_1_0_bias;  void* v_proj_1_2_weight;  void* v_proj_1_2_bias;
+    void* ln_q_1_weight;  void* ln_q_1_bias;  void* ln_k_1_weight;  void* ln_k_1_bias;
+    void* ln_v_1_weight;  void* ln_v_1_bias;
+    void* clip_attn_in_proj_weight;   void* clip_attn_in_proj_bias;
+    void* clip_attn_out_proj_weight;  void* clip_attn_out_proj_bias;
+    void* mlp_0_weight;  void* mlp_0_bias;  void* mlp_2_weight;  void* mlp_2_bias;
+} tp_grads;
+size_t tp_train_workspace_bytes(const tp_desc* desc);
+size_t tp_backward_workspace_bytes(const tp_desc* desc);
+int tp_forward_train(const tp_desc* desc, const void* x, const int64_t x_strides[3], const void* x_multi,
+                     const int64_t xm_strides[3], const void* packed_weights, void* out, void* train_workspace,
+                     size_t workspace_bytes, void* stream);
+int tp_backward(const tp_desc* desc, const void* x_multi, const int64_t xm_strides[3], const tp_weights* raw,
+                const void* packed_weights, const void* train_workspace, const void* dy, const tp_grads* grads,
+                void* bw_workspace, size_t bw_workspace_bytes, void* stream);
 
 /* ---- TokenPacker-HD token assembly (the step right after the projector) --------------------------------
  * Replaces the Python loop + torch.cat of `prepare_inputs_labels_for_multimodal` in mode 'slice'

@@ -206,5 +206,5 @@ def test_errors_on_gpu_inputs():
     with pytest.raises(NotImplementedError):
         m((x, xm), attn_mask=torch.zeros(1))
     m.requires_grad_(True)
-    with pytest.raises(NotImplementedError):
-        m((x, xm))
+    with pytest.raises(NotImplementedError):                    # CLIP features come from a frozen tower: no input grads
+        m((x.clone().requires_grad_(True), xm))

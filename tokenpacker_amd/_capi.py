@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = (
     "tp_version", "tp_last_error", "tp_packed_weight_bytes", "tp_workspace_bytes",
     "tp_pack_weights", "tp_forward", "tp_forward_staged", "tp_point_queries", "tp_region_attention", "tp_linear",
     "tp_ln_finalize", "tp_linear_stats_parts", "tp_set_tuning", "tp_hd_rows", "tp_hd_assemble",
+    "tp_train_workspace_bytes", "tp_backward_workspace_bytes", "tp_forward_train", "tp_backward",
 )
 
 # state-dict name -> tp_weights field order (include/tokenpacker.h)
@@ -53,6 +54,11 @@ class tp_desc(Structure):
 
 
 class tp_weights(Structure):
+    _fields_ = [(name.replace(".", "_"), c_void_p) for name in WEIGHT_FIELDS]
+
+
+class tp_grads(Structure):
+    """Output pointers of tp_backward: one gradient tensor per parameter, same order as tp_weights."""
     _fields_ = [(name.replace(".", "_"), c_void_p) for name in WEIGHT_FIELDS]
 
 
@@ -120,6 +126,15 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.tp_linear_stats_parts.argtypes = [POINTER(tp_linear_args)]
     lib.tp_set_tuning.restype = c_int
     lib.tp_set_tuning.argtypes = [c_int, c_int]
+    lib.tp_train_workspace_bytes.restype = c_size_t
+    lib.tp_train_workspace_bytes.argtypes = [POINTER(tp_desc)]
+    lib.tp_backward_workspace_bytes.restype = c_size_t
+    lib.tp_backward_workspace_bytes.argtypes = [POINTER(tp_desc)]
+    lib.tp_forward_train.restype = c_int
+    lib.tp_forward_train.argtypes = lib.tp_forward.argtypes
+    lib.tp_backward.restype = c_int
+    lib.tp_backward.argtypes = [POINTER(tp_desc), c_void_p, POINTER(c_int64), POINTER(tp_weights), c_void_p, c_void_p,
+                                c_void_p, POINTER(tp_grads), c_void_p, c_size_t, c_void_p]
     lib.tp_hd_rows.restype = c_int64
     lib.tp_hd_rows.argtypes = [c_int, c_int, c_int]
     lib.tp_hd_assemble.restype = c_int

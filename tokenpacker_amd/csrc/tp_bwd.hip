@@ -1,0 +1,304 @@
+// tp_bwd.hip — the non-GEMM kernels of the projector's BACKWARD pass on gfx950 (stage-1
+// training updates only the projector, reference llava/train/train.py:950-953).  The contractions of the
+// backward pass run on the forward's MFMA kernels (tp_gemm8.hip / tp_gemm.hip):
+//   dgrad  dX[M,K] = dY[M,N] · W[N,K]        =  linear(A = dY, W-operand = W^T [K,N])
+//   wgrad  dW[N,K] = dY^T[N,M] · X[M,K]      =  linear(A = dY^T [N,M], W-operand = X^T [K,M]), split over M
+// so what is needed here are transposed (and cast / LayerNorm-applied) operand copies, column sums for the
+// bias gradients, the split-K reduction, the LayerNorm backward and the region-attention backward.
+// Gradients travel in the MODEL dtype (bf16 range for bf16 training, fp16 with the caller's loss scaling),
+// accumulate in fp32.  No atomics anywhere: every reduction is two-stage and ordered -> deterministic.
+#include "tp_internal.h"
+
+namespace tp {
+
+template <typename T> __device__ __forceinline__ float ld1(const T* p) { return (float)*p; }
+template <typename T> __device__ __forceinline__ T sat_cast(float v);
+template <> __device__ __forceinline__ f16_t sat_cast<f16_t>(float v) { return (f16_t)fminf(fmaxf(v, -65504.f), 65504.f); }
+template <> __device__ __forceinline__ bf16_t sat_cast<bf16_t>(float v) { return (bf16_t)v; }
+
+// ---------------------------------------------------------------------------------------------------
+// dst[c][r] = cast( f(src[r][c]) )  for r < R (zero for R <= r < Rpad), c < C.   f = identity, or the LayerNorm
+// (src - mean_r) * rstd_r * gamma_c + beta_c when `mean_rstd` is given.  src rows may be batch-strided (the CLIP
+// tower's [:,1:] slices).  Optionally emits per-row-block column sums of the SOURCE values (bias gradients):
+// colsum_part[blockIdx.y][c].  64x64 tiles through LDS, 256 threads.
+template <typename TS, typename TD>
+__global__ void __launch_bounds__(256)
+transpose_kernel(const TS* __restrict__ src, long long ld, int rows_per_batch, long long batch_stride, int R, int C,
+                 TD* __restrict__ dst, long long ldd, int Rpad, const float* __restrict__ mean_rstd,
+                 const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ colsum_part) {
+    __shared__ float tile[64][65];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 64 x 4
+    for (int rr = ty; rr < 64; rr += 4) {
+        const int r = r0 + rr, c = c0 + tx;
+        float v = 0.f;
+        if (r < R && c < C) {
+            const int b = r / rows_per_batch;
+            v = ld1(src + (long long)b * batch_stride + (long long)(r - b * rows_per_batch) * ld + c);
+        }
+        tile[rr][tx] = v;
+    }
+    __syncthreads();
+    if (colsum_part && ty == 0) {                                   // column sums of the raw source tile, row order
+        float s = 0.f;
+        for (int rr = 0; rr < 64; ++rr) s += tile[rr][tx];
+        if (c0 + tx < C) colsum_part[(long long)blockIdx.y * C + c0 + tx] = s;
+    }
+    for (int cc = ty; cc < 64; cc += 4) {
+        const int c = c0 + cc, r = r0 + tx;
+        if (c < C && r < Rpad) {
+            float v = tile[tx][cc];
+            if (mean_rstd && r < R) v = (v - mean_rstd[2 * (long long)r]) * mean_rstd[2 * (long long)r + 1] * gamma[c] + beta[c];
+            dst[(long long)c * ldd + r] = sat_cast<TD>(r < R ? v : 0.f);
+        }
+    }
+}
+
+template <typename TS, typename TD>
+static int transpose_launch_t(const void* src, long long ld, int rpb, long long bstride, int R, int C, void* dst,
+                              long long ldd, int Rpad, const float* mr, const float* gamma, const float* beta,
+                              float* colsum_part, hipStream_t stream) {
+    dim3 grid((unsigned)((C + 63) / 64), (unsigned)((Rpad + 63) / 64));
+    hipLaunchKernelGGL((transpose_kernel<TS, TD>), grid, dim3(256), 0, stream, (const TS*)src, ld, rpb, bstride, R, C,
+                       (TD*)dst, ldd, Rpad, mr, gamma, beta, colsum_part);
+    return check_launch("transpose_kernel");
+}
+
+int bw_transpose_launch(int src_dtype, int dst_dtype, const void* src, long long ld, int rows_per_batch,
+                        long long batch_stride, int R, int C, void* dst, long long ldd, int Rpad, const float* mean_rstd,
+                        const float* gamma, const float* beta, float* colsum_part, hipStream_t stream) {
+    if (rows_per_batch <= 0 || rows_per_batch > R) { rows_per_batch = R > 0 ? R : 1; batch_stride = 0; }
+#define TP_TR(SD, DD, TS, TD) if (src_dtype == SD && dst_dtype == DD) return transpose_launch_t<TS, TD>(src, ld, \
+        rows_per_batch, batch_stride, R, C, dst, ldd, Rpad, mean_rstd, gamma, beta, colsum_part, stream)
+    TP_TR(TP_BF16, TP_BF16, bf16_t, bf16_t); TP_TR(TP_F16, TP_F16, f16_t, f16_t);
+    TP_TR(TP_F16, TP_BF16, f16_t, bf16_t);   TP_TR(TP_BF16, TP_F16, bf16_t, f16_t);
+#undef TP_TR
+    set_error("bw transpose: unsupported dtypes %d -> %d", src_dtype, dst_dtype);
+    return TP_ERR_INVALID_ARG;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// out[i] = cast( scale-free sum over parts of part[s][i] ), i < n   (split-K wgrad partials, column-sum partials)
+template <typename TD>
+__global__ void __launch_bounds__(256)
+reduce_parts_kernel(const float* __restrict__ part, long long part_stride, int nparts, long long n, TD* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nparts; ++k) s += part[(long long)k * part_stride + i];
+    out[i] = sat_cast<TD>(s);
+}
+
+int bw_reduce_parts_launch(int dst_dtype, const float* part, long long part_stride, int nparts, long long n, void* out,
+                           hipStream_t stream) {
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (dst_dtype == TP_BF16)
+        hipLaunchKernelGGL(reduce_parts_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, part, part_stride, nparts, n, (bf16_t*)out);
+    else if (dst_dtype == TP_F16)
+        hipLaunchKernelGGL(reduce_parts_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream, part, part_stride, nparts, n, (f16_t*)out);
+    else { set_error("bw reduce: unsupported dtype %d", dst_dtype); return TP_ERR_INVALID_ARG; }
+    return check_launch("reduce_parts_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm backward over rows of E = 1024 (one wave per row, 16 elements per lane):
+//   xhat = (x - mean) rstd,  g = dy gamma,  dx = rstd (g - mean(g) - xhat mean(g xhat))
+// plus per-workgroup partial sums of dgamma = sum_rows dy xhat and dbeta = sum_rows dy
+// (part[blk][0][E], part[blk][1][E]; reduced by bw_reduce_parts).  x: fp16 (forward activations), dy/dx: TG.
+template <typename TG>
+__global__ void __launch_bounds__(256)
+ln_backward_kernel(const TG* __restrict__ dy, const f16_t* __restrict__ x, const float* __restrict__ mean_rstd,
+                   const float* __restrict__ gamma, TG* __restrict__ dx, float* __restrict__ part, long long rows) {
+    constexpr int E = kEmbed;
+    __shared__ float red[2][4][E];                       // 32 KiB
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float dg[16], db[16], gm[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dg[e] = 0.f; db[e] = 0.f; gm[e] = gamma[(e >> 3) * 512 + lane * 8 + (e & 7)]; }
+    for (long long r = (long long)blockIdx.x * 4 + wave; r < rows; r += (long long)gridDim.x * 4) {
+        const float mu = mean_rstd[2 * r], rstd = mean_rstd[2 * r + 1];
+        float dyv[16], xh[16];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            using G8 = typename Vec<TG>::x8;
+            const G8 d8 = *(const G8*)(dy + r * E + h * 512 + lane * 8);
+            const f16x8 x8 = *(const f16x8*)(x + r * E + h * 512 + lane * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { dyv[h * 8 + e] = (float)d8[e]; xh[h * 8 + e] = ((float)x8[e] - mu) * rstd; }
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { const float g = dyv[e] * gm[e]; s1 += g; s2 = fmaf(g, xh[e], s2); }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+        const float m1 = s1 * (1.0f / E), m2 = s2 * (1.0f / E);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            using G8 = typename Vec<TG>::x8;
+            G8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = h * 8 + e;
+                o[e] = sat_cast<TG>(rstd * (dyv[k] * gm[k] - m1 - xh[k] * m2));
+                dg[k] = fmaf(dyv[k], xh[k], dg[k]);
+                db[k] += dyv[k];
+            }
+            *(G8*)(dx + r * E + h * 512 + lane * 8) = o;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        red[0][wave][(e >> 3) * 512 + lane * 8 + (e & 7)] = dg[e];
+        red[1][wave][(e >> 3) * 512 + lane * 8 + (e & 7)] = db[e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * E; i += 256) {
+        const int w = i / E, c = i - w * E;
+        part[((long long)blockIdx.x * 2 + w) * E + c] = red[w][0][c] + red[w][1][c] + red[w][2][c] + red[w][3][c];
+    }
+}
+
+int bw_ln_backward_launch(int gdtype, const void* dy, const void* x_f16, const float* mean_rstd, const float* gamma,
+                          void* dx, float* part, int nblocks, long long rows, hipStream_t stream) {
+    if (gdtype == TP_BF16)
+        hipLaunchKernelGGL(ln_backward_kernel<bf16_t>, dim3(nblocks), dim3(256), 0, stream, (const bf16_t*)dy,
+                           (const f16_t*)x_f16, mean_rstd, gamma, (bf16_t*)dx, part, rows);
+    else
+        hipLaunchKernelGGL(ln_backward_kernel<f16_t>, dim3(nblocks), dim3(256), 0, stream, (const f16_t*)dy,
+                           (const f16_t*)x_f16, mean_rstd, gamma, (f16_t*)dx, part, rows);
+    return check_launch("ln_backward_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Region-to-point attention backward.  One wavefront per coarse query, lane layout of the forward kernel
+// (lane l: elements [8l, 8l+8) of head l>>4 and [512+8l, ...) of head 4 + (l>>4)).  With p = softmax_j(q·k_j scale):
+//   dv_j = p_j dO,   dP_j = dO·v_j,   D = sum_j p_j dP_j,   dS_j = p_j (dP_j - D),
+//   dq = scale sum_j dS_j k_j,        dk_j = scale dS_j q.
+// Every key/value row belongs to exactly one query (regions partition the grid), so dK / dV rows are written
+// once, without atomics.  Three sweeps over the region's keys (max+denominator | D and dV | dq and dK) keep the
+// kernel valid for any s; K/V are fp16 forward activations, dO / dQ / dK / dV the gradient dtype TG.
+template <typename TG>
+__global__ void __launch_bounds__(256)
+region_attention_bwd_kernel(const f16_t* __restrict__ q, const f16_t* __restrict__ k, const f16_t* __restrict__ v,
+                            const TG* __restrict__ dout, TG* __restrict__ dq, TG* __restrict__ dk, TG* __restrict__ dv,
+                            int B, int g, int s, float scale) {
+    constexpr int E = kEmbed;
+    using G8 = typename Vec<TG>::x8;
+    const int lane = threadIdx.x & 63;
+    const int G = g / s, M = G * G, N = g * g, S2 = s * s;
+    const long long qi = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= (long long)B * M) return;
+    const int b = (int)(qi / M), m = (int)(qi % M);
+    const int i = m / G, j = m % G;
+    const int ea = lane * 8, eb = 512 + lane * 8;
+    auto row_of = [&](int kk) -> long long {
+        const int a = kk / s, c = kk - a * s;
+        return ((long long)b * N + (i * s + a) * g + j * s + c) * E;
+    };
+    auto load8h = [&](const f16_t* p, float (&f)[8]) {
+        const f16x8 t = *(const f16x8*)p;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (float)t[e];
+    };
+    auto dot16 = [&](float d) {                          // 128-wide head dot product: 16-lane butterfly
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) d += __shfl_xor(d, off);
+        return d;
+    };
+    float qa[8], qb[8], doa[8], dob[8];
+    load8h(q + qi * E + ea, qa);
+    load8h(q + qi * E + eb, qb);
+    {
+        const G8 ta = *(const G8*)(dout + qi * E + ea), tb = *(const G8*)(dout + qi * E + eb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { doa[e] = (float)ta[e]; dob[e] = (float)tb[e]; }
+    }
+    // sweep 1: max and denominator
+    float mxa = -INFINITY, mxb = -INFINITY;
+    for (int kk = 0; kk < S2; ++kk) {
+        float ka[8], kb[8];
+        const long long r = row_of(kk);
+        load8h(k + r + ea, ka); load8h(k + r + eb, kb);
+        float da = 0.f, db = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { da = fmaf(qa[e], ka[e], da); db = fmaf(qb[e], kb[e], db); }
+        mxa = fmaxf(mxa, dot16(da) * scale); mxb = fmaxf(mxb, dot16(db) * scale);
+    }
+    float dena = 0.f, denb = 0.f;
+    for (int kk = 0; kk < S2; ++kk) {
+        float ka[8], kb[8];
+        const long long r = row_of(kk);
+        load8h(k + r + ea, ka); load8h(k + r + eb, kb);
+        float da = 0.f, db = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { da = fmaf(qa[e], ka[e], da); db = fmaf(qb[e], kb[e], db); }
+        dena += __expf(dot16(da) * scale - mxa); denb += __expf(dot16(db) * scale - mxb);
+    }
+    const float inva = 1.0f / dena, invb = 1.0f / denb;
+    // sweep 2: D = sum_j p_j dP_j, and dV
+    float Da = 0.f, Db = 0.f;
+    for (int kk = 0; kk < S2; ++kk) {
+        float ka[8], kb[8], va[8], vb[8];
+        const long long r = row_of(kk);
+        load8h(k + r + ea, ka); load8h(k + r + eb, kb);
+        load8h(v + r + ea, va); load8h(v + r + eb, vb);
+        float da = 0.f, db = 0.f, pa_ = 0.f, pb_ = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            da = fmaf(qa[e], ka[e], da); db = fmaf(qb[e], kb[e], db);
+            pa_ = fmaf(doa[e], va[e], pa_); pb_ = fmaf(dob[e], vb[e], pb_);
+        }
+        const float pa = __expf(dot16(da) * scale - mxa) * inva, pb = __expf(dot16(db) * scale - mxb) * invb;
+        Da = fmaf(pa, dot16(pa_), Da); Db = fmaf(pb, dot16(pb_), Db);
+        G8 oa, ob;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { oa[e] = sat_cast<TG>(pa * doa[e]); ob[e] = sat_cast<TG>(pb * dob[e]); }
+        *(G8*)(dv + r + ea) = oa; *(G8*)(dv + r + eb) = ob;
+    }
+    // sweep 3: dS, dq, dK
+    float dqa[8], dqb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dqa[e] = 0.f; dqb[e] = 0.f; }
+    for (int kk = 0; kk < S2; ++kk) {
+        float ka[8], kb[8], va[8], vb[8];
+        const long long r = row_of(kk);
+        load8h(k + r + ea, ka); load8h(k + r + eb, kb);
+        load8h(v + r + ea, va); load8h(v + r + eb, vb);
+        float da = 0.f, db = 0.f, pa_ = 0.f, pb_ = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            da = fmaf(qa[e], ka[e], da); db = fmaf(qb[e], kb[e], db);
+            pa_ = fmaf(doa[e], va[e], pa_); pb_ = fmaf(dob[e], vb[e], pb_);
+        }
+        const float pa = __expf(dot16(da) * scale - mxa) * inva, pb = __expf(dot16(db) * scale - mxb) * invb;
+        const float dsa = pa * (dot16(pa_) - Da) * scale, dsb = pb * (dot16(pb_) - Db) * scale;
+        G8 oa, ob;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            dqa[e] = fmaf(dsa, ka[e], dqa[e]); dqb[e] = fmaf(dsb, kb[e], dqb[e]);
+            oa[e] = sat_cast<TG>(dsa * qa[e]); ob[e] = sat_cast<TG>(dsb * qb[e]);
+        }
+        *(G8*)(dk + r + ea) = oa; *(G8*)(dk + r + eb) = ob;
+    }
+    G8 oa, ob;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { oa[e] = sat_cast<TG>(dqa[e]); ob[e] = sat_cast<TG>(dqb[e]); }
+    *(G8*)(dq + qi * E + ea) = oa; *(G8*)(dq + qi * E + eb) = ob;
+}
+
+int bw_region_attention_launch(int gdtype, const void* q, const void* k, const void* v, const void* dout, void* dq,
+                               void* dk, void* dv, int B, int grid, int s, hipStream_t stream) {
+    const int G = grid / s, M = G * G;
+    const long long nq = (long long)B * M;
+    const unsigned blocks = (unsigned)((nq + 3) / 4);
+    const float scale = 0.08838834764831845f;   // 1/sqrt(128)
+    if (gdtype == TP_BF16)
+        hipLaunchKernelGGL(region_attention_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const f16_t*)q,
+                           (const f16_t*)k, (const f16_t*)v, (const bf16_t*)dout, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, B, grid, s, scale);
+    else
+        hipLaunchKernelGGL(region_attention_bwd_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream, (const f16_t*)q,
+                           (const f16_t*)k, (const f16_t*)v, (const f16_t*)dout, (f16_t*)dq, (f16_t*)dk, (f16_t*)dv, B, grid, s, scale);
+    return check_launch("region_attention_bwd_kernel");
+}
+
+}  // namespace tp

@@ -83,7 +83,7 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
             }
         } else {
             const int n = n0 + (c - BM / 8) * 8 + (lane >> 3);
-            src[i] = Wg + (long long)n * p.K * 2 + kslot * 16;
+            src[i] = Wg + (long long)n * (p.ldw_bytes ? p.ldw_bytes : (long long)p.K * 2) + kslot * 16;
         }
     }
 

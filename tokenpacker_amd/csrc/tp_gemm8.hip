@@ -81,6 +81,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
     const int wm = wave >> 2, wn = wave & 3;
     const int g = blockIdx.y;
     const int nk = p.K / BK;
+    const long long ldw = p.ldw_bytes ? p.ldw_bytes : (long long)p.K * 2;
 
     // ---- this workgroup's tile list: L, L + L_step, ... < L_end (indices into the tile_m-major tile order) ----
     const int ntiles = tiles_m * tiles_n, nwg = gridDim.x;
@@ -123,7 +124,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         m0 = tm * BM; n0 = tile_n * BN;
         const long long a_tile_off = a_row_off(m0);
         rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + g * p.a_gs + a_tile_off), 0, 0x7fffffff, 0x00020000);
-        rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + g * p.w_gs + (long long)n0 * p.K * 2), 0, 0x7fffffff,
+        rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + g * p.w_gs + (long long)n0 * ldw), 0, 0x7fffffff,
                                                    0x00020000);
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
@@ -134,7 +135,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
                 row = row < p.M ? row : p.M - 1;
                 voff_a[sub][q] = (int)(a_row_off(row) - a_tile_off) + kslot * 16;
                 const int col = (rho >> 5) * 64 + sub * 32 + (rho & 31);
-                voff_w[sub][q] = col * p.K * 2 + kslot * 16;
+                voff_w[sub][q] = (int)(col * ldw) + kslot * 16;
             }
     };
 

@@ -26,6 +26,21 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 // round-off class next to the 1.0 it is added to): 1 rcp + 1 exp + ~12 FMA-class ops per element instead
 // of ocml erff's ~45 with divergent branches — the epilogue runs with the matrix pipe idle, so its VALU
 // time is pure cost (measured: ~0.1 ms per GELU layer at B=256 with erff).
+// d/dv of the erf-form GELU:  Phi(v) + v phi(v)
+__device__ __forceinline__ float gelu_erf_grad(float v) {
+    const float x = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    poly *= t;
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);      // exp(-v^2/2)
+    const float erf_abs = fmaf(-poly, e, 1.0f);
+    const float cdf = fmaf(0.5f, copysignf(erf_abs, v), 0.5f);
+    return fmaf(v * 0.3989422804014327f, e, cdf);                               // + v * exp(-v^2/2)/sqrt(2 pi)
+}
+
 __device__ __forceinline__ float gelu_erf(float v) {
     const float x = fabsf(v) * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
@@ -121,6 +136,25 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
                 f32x4 v0 = acc[i][j0], v1 = acc[i][j1];
                 if (flags & TP_LINEAR_LN_FOLD) { v0 = rstd * (v0 - mu * csum_v[j0]); v1 = rstd * (v1 - mu * csum_v[j1]); }
                 v0 += bias_v[j0]; v1 += bias_v[j1];
+                if (flags & TP_LINEAR_GELU_BWD) {          // backward of a GELU layer: dZ = dA * gelu'(Z), Z fp16 [M, ldz]
+                    const f16_t* zrow = (const f16_t*)(p.Z + g * p.z_gs) + (long long)(row_ok ? m : 0) * p.ldz + col_base;
+                    const f16x4 z0 = *(const f16x4*)(zrow + j0 * 16), z1 = *(const f16x4*)(zrow + j1 * 16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v0[r] *= gelu_erf_grad((float)z0[r]); v1[r] *= gelu_erf_grad((float)z1[r]); }
+                }
+                if ((flags & TP_LINEAR_SAVE_PRE) && !OUT_F32) {   // training forward: keep the pre-activation (fp16)
+                    using O4p = typename Vec<f16_t>::x4;
+                    f32x4 c0 = v0, c1 = v1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        c0[r] = fminf(fmaxf(c0[r], -65504.f), 65504.f); c1[r] = fminf(fmaxf(c1[r], -65504.f), 65504.f);
+                    }
+                    f16_t* prow = (f16_t*)(p.C2 + g * p.c2_gs) + (long long)m * p.ldc + col_base;
+                    if (row_ok) {
+                        *(O4p*)(prow + j0 * 16) = __builtin_convertvector(c0, O4p);
+                        *(O4p*)(prow + j1 * 16) = __builtin_convertvector(c1, O4p);
+                    }
+                }
                 if (flags & TP_LINEAR_GELU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { v0[r] = gelu_erf(v0[r]); v1[r] = gelu_erf(v1[r]); }

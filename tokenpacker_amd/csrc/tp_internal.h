@@ -39,9 +39,14 @@ struct GemmArgs {
     const float* bias;
     const float* stats_in;            // LN_FOLD: per-row (mean, rstd) [M][2]
     const float* colsum; float* stats_out;
+    char* C2;                         // SAVE_PRE: pre-activation copy of C (same dtype / ldc), NULL otherwise
+    const char* Z;                    // GELU_BWD: fp16 pre-activations [M, ldz] the result is multiplied by gelu'(.)
+    long long ldz;                    // elements
+    long long c2_gs, z_gs;            // per-group strides in bytes
     long long a_batch_stride_bytes;   // between batches of rows_per_batch rows
     long long lda_bytes;              // between rows inside a batch
     long long ldc;                    // elements
+    long long ldw_bytes;              // between rows of W (0: K * 2 — a contiguous [N, K] weight)
     // per-group strides (bytes for A/W/C, floats for the fp32 side arrays)
     long long a_gs, w_gs, c_gs, bias_gs, stats_in_gs, colsum_gs, stats_out_gs;
     int M, N, K;
@@ -95,9 +100,27 @@ PackedLayout packed_layout(int D);
 
 struct WorkspaceLayout {
     size_t q0, hkv, h2, stats_kv, mr_kv, kv, q1pre, stats_q, mr_q, q, o, a1, a2;
+    size_t z1, z2;                // training forward only: fp16 pre-GELU activations [B*N, 2048], [B*M, D]
     size_t total;
     int stats_parts_kv, stats_parts_q;
 };
-WorkspaceLayout workspace_layout(int B, int grid, int s, int D);
+WorkspaceLayout workspace_layout(int B, int grid, int s, int D, bool train = false);
+
+// ---- backward helpers (tp_bwd.hip) -------------------------------------------------------------
+int bw_transpose_launch(int src_dtype, int dst_dtype, const void* src, long long ld, int rows_per_batch,
+                        long long batch_stride, int R, int C, void* dst, long long ldd, int Rpad, const float* mean_rstd,
+                        const float* gamma, const float* beta, float* colsum_part, hipStream_t stream);
+int bw_reduce_parts_launch(int dst_dtype, const float* part, long long part_stride, int nparts, long long n, void* out,
+                           hipStream_t stream);
+int bw_ln_backward_launch(int gdtype, const void* dy, const void* x_f16, const float* mean_rstd, const float* gamma,
+                          void* dx, float* part, int nblocks, long long rows, hipStream_t stream);
+int bw_region_attention_launch(int gdtype, const void* q, const void* k, const void* v, const void* dout, void* dq,
+                               void* dk, void* dv, int B, int grid, int s, hipStream_t stream);
+int validate_desc(const tp_desc* d);
+GemmArgs plain_gemm(const void* A, long long lda_elems, const void* W, void* C, long long ldc, int M, int N, int K,
+                    const float* bias, int flags);
+int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3], const void* x_multi,
+                 const int64_t xm_strides[3], const void* packed_weights, void* out, void* workspace,
+                 size_t workspace_bytes, void* stream_, void* const* stage_events, bool train);
 
 }  // namespace tp

@@ -1,0 +1,280 @@
+// tp_train.hip — training entry points of libtokenpacker_hip.so: the forward that keeps what the backward needs,
+// and the backward pass of the projector (gradients of all 23 parameters; the CLIP features come from a frozen
+// tower and get none — reference llava/train/train.py:950-953, clip_encoder.py:46 `@torch.no_grad()`).
+//
+// Backward schedule (reverse of tp_api.hip's forward; R = B*576 fine tokens, Rq = B*M coarse tokens, G = the
+// model dtype in which gradients travel):
+//   mlp[2]      dW = dy^T·A2, db = colsum(dy);         dZ2 = (dy·Wm2) * gelu'(Z2)
+//   mlp[0]      dW = dZ2^T·A1, db = colsum(dZ2);       dA1 = dZ2·Wm0
+//   out_proj    dW = dA1^T·O,  db = colsum(dA1);       dO  = dA1·Wout
+//   attention   (Q, K, V, dO) -> dQ, dK, dV                                   region_attention_bwd_kernel
+//   in_proj     dW{q,k,v} = d{Q,K,V}^T·LN(.), db = colsum;   d(LN out) = d{Q,K,V}·W{q,k,v}
+//   LayerNorms  d(pre-LN), dgamma, dbeta                                      ln_backward_kernel
+//   q_proj_1    dW = dQ1pre^T·q0
+//   k/v_proj[2] dW = dH2^T·Hkv, db = colsum(dH2);      dZ1 = (dH2·W2) * gelu'(Z1)
+//   k/v_proj[0] dW = dZ1^T·x_multi, db = colsum(dZ1)
+// Every contraction runs on the forward's MFMA kernels: dgrad as linear(dY, W^T), wgrad as
+// linear(dY^T, X^T) split over the token dimension into fp32 partials that a reduction kernel sums and casts.
+#include "tp_internal.h"
+
+namespace tp {
+
+static inline size_t up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+static inline int pad_tokens(long long r) { return (int)((r + 511) / 512 * 512); }     // any split in {1,2,4,8} keeps K % 64 == 0
+
+struct BwLayout {
+    // transposed weights (G) for the dgrad GEMMs, fp32 LayerNorm affines
+    size_t wt_m2, wt_m0, wt_out, wt_in, wt_2;        // wt_in: [3][E,E] (q,k,v);  wt_2: [2][E,E] (k,v)
+    size_t ln_g, ln_b;                                // [3][E] fp32 each (q,k,v)
+    // coarse-token side
+    size_t dyT, a2T, dz2, dz2T, a1T, da1, da1T, oT, dO, dQ, dQT, q1T, dq1, dQ1pre, dQ1preT, q0T;
+    // fine-token side ([2] = k, v)
+    size_t dKV, dKVT, kv1T, dkv1, dH2, dH2T, hkvT, dZ1, dZ1T, xmT;
+    size_t part, colpart, lnpart;                     // fp32 partials: split-K wgrad, column sums, LN affine grads
+    size_t part_bytes;
+    size_t total;
+    int Rp, Rqp;
+};
+
+static BwLayout bw_layout(int B, int grid, int s, int D) {
+    BwLayout L{};
+    const size_t N = (size_t)grid * grid, G = grid / s, M = G * G, E = kEmbed;
+    const size_t R = (size_t)B * N, Rq = (size_t)B * M;
+    L.Rp = pad_tokens((long long)R); L.Rqp = pad_tokens((long long)Rq);
+    const size_t Rp = L.Rp, Rqp = L.Rqp;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = up(off + bytes); return o; };
+    L.wt_m2 = take((size_t)D * D * 2); L.wt_m0 = take(E * D * 2); L.wt_out = take(E * E * 2);
+    L.wt_in = take(3 * E * E * 2); L.wt_2 = take(2 * E * E * 2);
+    L.ln_g = take(3 * E * 4); L.ln_b = take(3 * E * 4);
+    L.dyT = take(D * Rqp * 2); L.a2T = take(D * Rqp * 2); L.dz2 = take(Rq * D * 2); L.dz2T = take(D * Rqp * 2);
+    L.a1T = take(E * Rqp * 2); L.da1 = take(Rq * E * 2); L.da1T = take(E * Rqp * 2); L.oT = take(E * Rqp * 2);
+    L.dO = take(Rq * E * 2); L.dQ = take(Rq * E * 2); L.dQT = take(E * Rqp * 2); L.q1T = take(E * Rqp * 2);
+    L.dq1 = take(Rq * E * 2); L.dQ1pre = take(Rq * E * 2); L.dQ1preT = take(E * Rqp * 2); L.q0T = take(E * Rqp * 2);
+    L.dKV = take(2 * R * E * 2); L.dKVT = take(2 * E * Rp * 2); L.kv1T = take(2 * E * Rp * 2); L.dkv1 = take(2 * R * E * 2);
+    L.dH2 = take(2 * R * E * 2); L.dH2T = take(2 * E * Rp * 2); L.hkvT = take(2 * E * Rp * 2);
+    L.dZ1 = take(R * 2 * E * 2); L.dZ1T = take(2 * E * Rp * 2); L.xmT = take((size_t)kMulti * Rp * 2);
+    // split-K partials: at most 8 splits of the largest weight
+    size_t wmax = (size_t)D * D;
+    if ((size_t)2 * E * kMulti > wmax) wmax = (size_t)2 * E * kMulti;
+    L.part_bytes = 8 * wmax * 4;
+    L.part = take(L.part_bytes);
+    const size_t cmax = (size_t)D > 2 * E ? (size_t)D : 2 * E;
+    L.colpart = take((Rp / 64) * cmax * 4);
+    L.lnpart = take((size_t)256 * 2 * E * 4);
+    L.total = off;
+    return L;
+}
+
+}  // namespace tp
+
+using namespace tp;
+
+#define TP_TRY(expr) do { int rc_ = (expr); if (rc_ != TP_OK) return rc_; } while (0)
+
+extern "C" {
+
+size_t tp_train_workspace_bytes(const tp_desc* desc) {
+    if (validate_desc(desc) != TP_OK) return 0;
+    return workspace_layout(desc->batch, desc->raw_grid, desc->scale_factor, desc->hidden_size, true).total;
+}
+
+size_t tp_backward_workspace_bytes(const tp_desc* desc) {
+    if (validate_desc(desc) != TP_OK) return 0;
+    return bw_layout(desc->batch, desc->raw_grid, desc->scale_factor, desc->hidden_size).total;
+}
+
+int tp_forward_train(const tp_desc* desc, const void* x, const int64_t x_strides[3], const void* x_multi,
+                     const int64_t xm_strides[3], const void* packed_weights, void* out, void* train_workspace,
+                     size_t workspace_bytes, void* stream) {
+    return forward_impl(desc, x, x_strides, x_multi, xm_strides, packed_weights, out, train_workspace, workspace_bytes,
+                        stream, nullptr, true);
+}
+
+int tp_backward(const tp_desc* desc, const void* x_multi, const int64_t xm_strides[3], const tp_weights* raw,
+                const void* packed_weights, const void* train_workspace, const void* dy, const tp_grads* grads,
+                void* bw_workspace, size_t bw_workspace_bytes, void* stream_) {
+    TP_TRY(validate_desc(desc));
+    if (!x_multi || !xm_strides || !raw || !packed_weights || !train_workspace || !dy || !grads || !bw_workspace) {
+        set_error("tp_backward: NULL argument");
+        return TP_ERR_INVALID_ARG;
+    }
+    {
+        const void* const* gp = reinterpret_cast<const void* const*>(grads);
+        const void* const* wp = reinterpret_cast<const void* const*>(raw);
+        for (size_t i = 0; i < sizeof(tp_grads) / sizeof(void*); ++i)
+            if (!gp[i] || !wp[i]) { set_error("tp_backward: weight / gradient pointer #%zu is NULL", i); return TP_ERR_INVALID_ARG; }
+    }
+    if (desc->out_dtype != desc->dtype) { set_error("tp_backward: out_dtype must equal dtype"); return TP_ERR_INVALID_ARG; }
+    const int B = desc->batch, g = desc->raw_grid, s = desc->scale_factor, D = desc->hidden_size, GT = desc->dtype;
+    const int N = g * g, Gq = g / s, M = Gq * Gq, E = kEmbed;
+    const int R = B * N, Rq = B * M;
+    const WorkspaceLayout W = workspace_layout(B, g, s, D, true);
+    const PackedLayout P = packed_layout(D);
+    const BwLayout L = bw_layout(B, g, s, D);
+    if (bw_workspace_bytes < L.total) {
+        set_error("tp_backward: workspace %zu B < required %zu B", bw_workspace_bytes, L.total);
+        return TP_ERR_WORKSPACE;
+    }
+    if (((uintptr_t)bw_workspace & 255) || ((uintptr_t)train_workspace & 255) || ((uintptr_t)dy & 15)) {
+        set_error("tp_backward: workspaces must be 256-byte aligned, dy 16-byte aligned");
+        return TP_ERR_INVALID_ARG;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    const char* fw = (const char*)train_workspace;
+    const char* pw = (const char*)packed_weights;
+    char* bw = (char*)bw_workspace;
+    const int Rp = L.Rp, Rqp = L.Rqp;
+    float* part = (float*)(bw + L.part);
+    float* colpart = (float*)(bw + L.colpart);
+    const long long kvE = (long long)R * E;
+
+    // ---- small helpers ------------------------------------------------------------------------------------
+    // transpose (+cast) of a contiguous-row matrix; optional LayerNorm application and column sums
+    auto T = [&](int sdt, const void* src, long long ld, int rows, int cols, void* dst, int rpad, const float* mr = nullptr,
+                 const float* gam = nullptr, const float* bet = nullptr, float* csum = nullptr) -> int {
+        return bw_transpose_launch(sdt, GT, src, ld, rows, 0, rows, cols, dst, rpad, rpad, mr, gam, bet, csum, stream);
+    };
+    // bias gradient from the column-sum partials the last transpose left behind
+    auto bias_grad = [&](int rpad, int cols, void* out) -> int {
+        return bw_reduce_parts_launch(GT, colpart, cols, rpad / 64, cols, out, stream);
+    };
+    // dX[rows, Kin] = dY[rows, Nout] · W[Nout, Kin]  with W^T [Kin, Nout] given
+    auto dgrad = [&](const void* dY, long long ldy, int rows, int Nout, const void* WT, int Kin, void* dX, long long ldx,
+                     int flags = 0, const void* Z = nullptr, long long ldz = 0) -> int {
+        GemmArgs a = plain_gemm(dY, ldy, WT, dX, ldx, rows, Kin, Nout, nullptr, flags);
+        a.Z = (const char*)Z; a.ldz = ldz;
+        return gemm_launch(GT, GT, a, stream);
+    };
+    // dW[Nout, Kin] = dY^T[Nout, rpad] · X^T[Kin, rpad]^T, split over the token dimension
+    auto wgrad = [&](const void* dYT, const void* XT, int Nout, int Kin, int rpad, void* grad_out) -> int {
+        const long long tiles = (long long)((Nout + 255) / 256) * ((Kin + 255) / 256);
+        int S = 1;
+        while (S < 8 && tiles * S < 256 && (rpad / (S * 2)) % 64 == 0) S *= 2;
+        if ((size_t)S * Nout * Kin * 4 > L.part_bytes) { set_error("tp_backward: split-K partial buffer too small"); return TP_ERR_WORKSPACE; }
+        GemmArgs a = plain_gemm(dYT, rpad, XT, part, Kin, Nout, Kin, rpad / S, nullptr, 0);
+        a.ldw_bytes = (long long)rpad * 2;
+        a.groups = S; a.a_gs = (long long)(rpad / S) * 2; a.w_gs = (long long)(rpad / S) * 2; a.c_gs = (long long)Nout * Kin * 4;
+        a.tile = (Nout % 256 == 0 && Kin % 256 == 0) ? 0 : 128;
+        TP_TRY(gemm_launch(GT, TP_F32, a, stream));
+        return bw_reduce_parts_launch(GT, part, (long long)Nout * Kin, S, (long long)Nout * Kin, grad_out, stream);
+    };
+
+    // ---- operands the backward needs in its own layout --------------------------------------------------------
+    // transposed weights (model dtype): W [out, in] -> W^T [in, out]
+    TP_TRY(T(GT, raw->mlp_2_weight, D, D, D, bw + L.wt_m2, D));
+    TP_TRY(T(GT, raw->mlp_0_weight, E, D, E, bw + L.wt_m0, D));
+    TP_TRY(T(GT, raw->clip_attn_out_proj_weight, E, E, E, bw + L.wt_out, E));
+    for (int t = 0; t < 3; ++t)
+        TP_TRY(T(GT, (const char*)raw->clip_attn_in_proj_weight + (size_t)t * E * E * 2, E, E, E, bw + L.wt_in + (size_t)t * E * E * 2, E));
+    TP_TRY(T(GT, raw->k_proj_1_2_weight, E, E, E, bw + L.wt_2, E));
+    TP_TRY(T(GT, raw->v_proj_1_2_weight, E, E, E, bw + L.wt_2 + (size_t)E * E * 2, E));
+    float* ln_g = (float*)(bw + L.ln_g);
+    float* ln_b = (float*)(bw + L.ln_b);
+    const void* gam_src[3] = {raw->ln_q_1_weight, raw->ln_k_1_weight, raw->ln_v_1_weight};
+    const void* bet_src[3] = {raw->ln_q_1_bias, raw->ln_k_1_bias, raw->ln_v_1_bias};
+    for (int t = 0; t < 3; ++t) {
+        TP_TRY(pack_cast_f32_launch(GT, gam_src[t], ln_g + t * E, E, stream));
+        TP_TRY(pack_cast_f32_launch(GT, bet_src[t], ln_b + t * E, E, stream));
+    }
+
+    // ---- mlp[2] ---------------------------------------------------------------------------------------------
+    TP_TRY(T(GT, dy, D, Rq, D, bw + L.dyT, Rqp, nullptr, nullptr, nullptr, colpart));
+    TP_TRY(bias_grad(Rqp, D, grads->mlp_2_bias));
+    TP_TRY(T(TP_F16, fw + W.a2, D, Rq, D, bw + L.a2T, Rqp));
+    TP_TRY(wgrad(bw + L.dyT, bw + L.a2T, D, D, Rqp, grads->mlp_2_weight));
+    TP_TRY(dgrad(dy, D, Rq, D, bw + L.wt_m2, D, bw + L.dz2, D, TP_LINEAR_GELU_BWD, fw + W.z2, D));
+    // ---- mlp[0] ---------------------------------------------------------------------------------------------
+    TP_TRY(T(GT, bw + L.dz2, D, Rq, D, bw + L.dz2T, Rqp, nullptr, nullptr, nullptr, colpart));
+    TP_TRY(bias_grad(Rqp, D, grads->mlp_0_bias));
+    TP_TRY(T(TP_F16, fw + W.a1, E, Rq, E, bw + L.a1T, Rqp));
+    TP_TRY(wgrad(bw + L.dz2T, bw + L.a1T, D, E, Rqp, grads->mlp_0_weight));
+    TP_TRY(dgrad(bw + L.dz2, D, Rq, D, bw + L.wt_m0, E, bw + L.da1, E));
+    // ---- out_proj ---------------------------------------------------------------------------------------------
+    TP_TRY(T(GT, bw + L.da1, E, Rq, E, bw + L.da1T, Rqp, nullptr, nullptr, nullptr, colpart));
+    TP_TRY(bias_grad(Rqp, E, grads->clip_attn_out_proj_bias));
+    TP_TRY(T(TP_F16, fw + W.o, E, Rq, E, bw + L.oT, Rqp));
+    TP_TRY(wgrad(bw + L.da1T, bw + L.oT, E, E, Rqp, grads->clip_attn_out_proj_weight));
+    TP_TRY(dgrad(bw + L.da1, E, Rq, E, bw + L.wt_out, E, bw + L.dO, E));
+    // ---- region attention ---------------------------------------------------------------------------------------
+    TP_TRY(bw_region_attention_launch(GT, fw + W.q, fw + W.kv, fw + W.kv + kvE * 2, bw + L.dO, bw + L.dQ, bw + L.dKV,
+                                      bw + L.dKV + kvE * 2, B, g, s, stream));
+    // ---- attention in-projection (rows of in_proj_weight / in_proj_bias: q | k | v) --------------------------------
+    char* g_inw = (char*)grads->clip_attn_in_proj_weight;
+    char* g_inb = (char*)grads->clip_attn_in_proj_bias;
+    //   q
+    TP_TRY(T(GT, bw + L.dQ, E, Rq, E, bw + L.dQT, Rqp, nullptr, nullptr, nullptr, colpart));
+    TP_TRY(bias_grad(Rqp, E, g_inb));
+    TP_TRY(T(TP_F16, fw + W.q1pre, E, Rq, E, bw + L.q1T, Rqp, (const float*)(fw + W.mr_q), ln_g, ln_b));
+    TP_TRY(wgrad(bw + L.dQT, bw + L.q1T, E, E, Rqp, g_inw));
+    TP_TRY(dgrad(bw + L.dQ, E, Rq, E, bw + L.wt_in, E, bw + L.dq1, E));
+    //   k, v
+    for (int t = 0; t < 2; ++t) {
+        const char* dX = bw + L.dKV + (size_t)t * kvE * 2;
+        char* dXT = bw + L.dKVT + (size_t)t * E * Rp * 2;
+        char* x1T = bw + L.kv1T + (size_t)t * E * Rp * 2;
+        const float* mr = (const float*)(fw + W.mr_kv) + (size_t)t * R * 2;
+        TP_TRY(T(GT, dX, E, R, E, dXT, Rp, nullptr, nullptr, nullptr, colpart));
+        TP_TRY(bias_grad(Rp, E, g_inb + (size_t)(1 + t) * E * 2));
+        TP_TRY(T(TP_F16, fw + W.h2 + (size_t)t * kvE * 2, E, R, E, x1T, Rp, mr, ln_g + (1 + t) * E, ln_b + (1 + t) * E));
+        TP_TRY(wgrad(dXT, x1T, E, E, Rp, g_inw + (size_t)(1 + t) * E * E * 2));
+        TP_TRY(dgrad(dX, E, R, E, bw + L.wt_in + (size_t)(1 + t) * E * E * 2, E, bw + L.dkv1 + (size_t)t * kvE * 2, E));
+    }
+    // ---- LayerNorms ---------------------------------------------------------------------------------------------
+    float* lnpart = (float*)(bw + L.lnpart);
+    {
+        const int nb = 256;
+        TP_TRY(bw_ln_backward_launch(GT, bw + L.dq1, fw + W.q1pre, (const float*)(fw + W.mr_q), ln_g, bw + L.dQ1pre, lnpart, nb, Rq, stream));
+        TP_TRY(bw_reduce_parts_launch(GT, lnpart, 2 * E, nb, E, grads->ln_q_1_weight, stream));
+        TP_TRY(bw_reduce_parts_launch(GT, lnpart + E, 2 * E, nb, E, grads->ln_q_1_bias, stream));
+        void* gw[2] = {grads->ln_k_1_weight, grads->ln_v_1_weight};
+        void* gb[2] = {grads->ln_k_1_bias, grads->ln_v_1_bias};
+        for (int t = 0; t < 2; ++t) {
+            TP_TRY(bw_ln_backward_launch(GT, bw + L.dkv1 + (size_t)t * kvE * 2, fw + W.h2 + (size_t)t * kvE * 2,
+                                         (const float*)(fw + W.mr_kv) + (size_t)t * R * 2, ln_g + (1 + t) * E,
+                                         bw + L.dH2 + (size_t)t * kvE * 2, lnpart, nb, R, stream));
+            TP_TRY(bw_reduce_parts_launch(GT, lnpart, 2 * E, nb, E, gw[t], stream));
+            TP_TRY(bw_reduce_parts_launch(GT, lnpart + E, 2 * E, nb, E, gb[t], stream));
+        }
+    }
+    // ---- q_proj_1 (no bias) ---------------------------------------------------------------------------------------
+    TP_TRY(T(GT, bw + L.dQ1pre, E, Rq, E, bw + L.dQ1preT, Rqp));
+    TP_TRY(T(TP_F16, fw + W.q0, E, Rq, E, bw + L.q0T, Rqp));
+    TP_TRY(wgrad(bw + L.dQ1preT, bw + L.q0T, E, E, Rqp, grads->q_proj_1_weight));
+    // ---- k/v_proj_1[2] -----------------------------------------------------------------------------------------------
+    {
+        void* gw[2] = {grads->k_proj_1_2_weight, grads->v_proj_1_2_weight};
+        void* gb[2] = {grads->k_proj_1_2_bias, grads->v_proj_1_2_bias};
+        for (int t = 0; t < 2; ++t) {
+            const char* dH = bw + L.dH2 + (size_t)t * kvE * 2;
+            char* dHT = bw + L.dH2T + (size_t)t * E * Rp * 2;
+            char* hT = bw + L.hkvT + (size_t)t * E * Rp * 2;
+            TP_TRY(T(GT, dH, E, R, E, dHT, Rp, nullptr, nullptr, nullptr, colpart));
+            TP_TRY(bias_grad(Rp, E, gb[t]));
+            TP_TRY(T(TP_F16, fw + W.hkv + (size_t)t * E * 2, 2 * E, R, E, hT, Rp));
+            TP_TRY(wgrad(dHT, hT, E, E, Rp, gw[t]));
+            TP_TRY(dgrad(dH, E, R, E, bw + L.wt_2 + (size_t)t * E * E * 2, E, bw + L.dZ1 + (size_t)t * E * 2, 2 * E,
+                         TP_LINEAR_GELU_BWD, fw + W.z1 + (size_t)t * E * 2, 2 * E));
+        }
+    }
+    // ---- k/v_proj_1[0] -----------------------------------------------------------------------------------------------
+    TP_TRY(T(GT, bw + L.dZ1, 2 * E, R, 2 * E, bw + L.dZ1T, Rp, nullptr, nullptr, nullptr, colpart));
+    TP_TRY(bw_reduce_parts_launch(GT, colpart, 2 * E, Rp / 64, E, grads->k_proj_1_0_bias, stream));
+    TP_TRY(bw_reduce_parts_launch(GT, colpart + E, 2 * E, Rp / 64, E, grads->v_proj_1_0_bias, stream));
+    TP_TRY(bw_transpose_launch(GT, GT, x_multi, xm_strides[1], N, xm_strides[0], R, kMulti, bw + L.xmT, Rp, Rp, nullptr,
+                               nullptr, nullptr, nullptr, stream));
+    {   // dW0 [2E, 4096] = dZ1^T · x_multi: rows 0..E-1 belong to k_proj_1[0], E..2E-1 to v_proj_1[0]
+        const int Nout = 2 * E, Kin = kMulti;
+        int S = 2;                                                       // 128 tiles of 256^2 -> 2 splits fill the chip
+        GemmArgs a = plain_gemm(bw + L.dZ1T, Rp, bw + L.xmT, part, Kin, Nout, Kin, Rp / S, nullptr, 0);
+        a.ldw_bytes = (long long)Rp * 2;
+        a.groups = S; a.a_gs = (long long)(Rp / S) * 2; a.w_gs = (long long)(Rp / S) * 2; a.c_gs = (long long)Nout * Kin * 4;
+        TP_TRY(gemm_launch(GT, TP_F32, a, stream));
+        TP_TRY(bw_reduce_parts_launch(GT, part, (long long)Nout * Kin, S, (long long)E * Kin, grads->k_proj_1_0_weight, stream));
+        TP_TRY(bw_reduce_parts_launch(GT, part + (size_t)E * Kin, (long long)Nout * Kin, S, (long long)E * Kin,
+                                      grads->v_proj_1_0_weight, stream));
+    }
+    return TP_OK;
+}
+
+}  // extern "C"

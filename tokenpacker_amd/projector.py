@@ -33,6 +33,25 @@ from . import _capi
 _DTYPES = {torch.bfloat16: _capi.TP_BF16, torch.float16: _capi.TP_F16}
 
 
+class _ProjectFn(torch.autograd.Function):
+    """Autograd node of the HIP projector: ``tp_forward_train`` keeps the backward's operands in a per-call
+    workspace, ``tp_backward`` returns the gradients of the 23 parameters (the CLIP features come from a frozen
+    ``no_grad`` tower — reference clip_encoder.py:46, train.py:950-953 — and get none)."""
+
+    @staticmethod
+    def forward(ctx, module, x, x_multi, *params):
+        out, train_ws, desc = module._launch_forward(x, x_multi, train=True)
+        ctx.module, ctx.desc = module, desc
+        ctx.save_for_backward(x_multi, train_ws, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_multi, train_ws, *params = ctx.saved_tensors
+        grads = ctx.module._launch_backward(ctx.desc, x_multi, train_ws, params, dy)
+        return (None, None, None) + tuple(grads)
+
+
 class TokenPacker(nn.Module):
     """Region-to-point visual projector (see module docstring)."""
 
@@ -74,7 +93,7 @@ class TokenPacker(nn.Module):
         self.output_fp32 = False
         self._packed: Optional[torch.Tensor] = None
         self._packed_key = None
-        self._workspaces: Dict[Tuple[int, int], torch.Tensor] = {}
+        self._workspaces: Dict[tuple, torch.Tensor] = {}
 
     # ------------------------------------------------------------------------------------------
     def _reset_parameters(self) -> None:
@@ -123,7 +142,7 @@ class TokenPacker(nn.Module):
         self._packed, self._packed_key = packed, key
         return packed
 
-    def _workspace(self, nbytes: int, device: torch.device, stream_ptr: int) -> torch.Tensor:
+    def _workspace(self, nbytes: int, device: torch.device, stream_ptr) -> torch.Tensor:
         key = (device.index if device.index is not None else -1, stream_ptr)
         ws = self._workspaces.get(key)
         if ws is None or ws.numel() < nbytes:
@@ -148,18 +167,25 @@ class TokenPacker(nn.Module):
                 or x.shape[0] != x_multi.shape[0]:
             raise ValueError(f"expected x [B,{N},{self.embed_dim}] and x_multi [B,{N},{self.MULTI_LEVEL_DIM}], "
                              f"got {tuple(x.shape)} and {tuple(x_multi.shape)}")
-        if torch.is_grad_enabled() and (x.requires_grad or x_multi.requires_grad
-                                        or any(p.requires_grad for p in self.parameters())):
+        if torch.is_grad_enabled() and (x.requires_grad or x_multi.requires_grad):
             raise NotImplementedError(
-                "the HIP projector is forward-only for now (backward is the next scope row, SURVEY.md §8f-1): "
-                "call it under torch.no_grad()/inference_mode() or freeze it with requires_grad_(False)")
-
-        B = x.shape[0]
-        device = x.device
+                "the HIP projector does not differentiate with respect to the CLIP features (the reference's tower is "
+                "frozen and runs under no_grad, clip_encoder.py:46); detach them")
         # the kernels take element strides (tower outputs are [:,1:] slices); only fix layouts they cannot address
         x = self._addressable(x)
         x_multi = self._addressable(x_multi)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if _stage_events is not None or self.output_fp32:
+                raise NotImplementedError("staged timing / fp32 output are inference-only")
+            if not all(p.requires_grad for p in self.parameters()):
+                raise NotImplementedError("training needs requires_grad on ALL projector parameters "
+                                          "(the reference trains the whole projector, train.py:952-958)")
+            return _ProjectFn.apply(self, x, x_multi, *self._named_weights())
+        return self._launch_forward(x, x_multi, train=False, _stage_events=_stage_events)[0]
 
+    # ------------------------------------------------------------------------------------------
+    def _launch_forward(self, x, x_multi, train: bool, _stage_events=None):
+        B, device = x.shape[0], x.device
         with torch.cuda.device(device):
             stream_ptr = torch.cuda.current_stream(device).cuda_stream
             lib = _capi.load_library()
@@ -167,11 +193,22 @@ class TokenPacker(nn.Module):
             out_dtype = torch.float32 if self.output_fp32 else x.dtype
             desc = _capi.make_desc(B, self.raw_grid, self.scale_factor, self.hidden_size, _DTYPES[x.dtype],
                                    _capi.TP_F32 if self.output_fp32 else _DTYPES[x.dtype], self._ln_eps())
+            out = torch.empty(B, self.num_queries, self.hidden_size, dtype=out_dtype, device=device)
+            if train:
+                ws_bytes = lib.tp_train_workspace_bytes(ctypes.byref(desc))
+                if ws_bytes == 0:
+                    raise RuntimeError(f"tp_train_workspace_bytes: {_capi.last_error()}")
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)     # lives until backward has run
+                _capi.check(lib.tp_forward_train(ctypes.byref(desc),
+                                                 x.data_ptr(), _capi.strides3(x.stride()),
+                                                 x_multi.data_ptr(), _capi.strides3(x_multi.stride()),
+                                                 packed.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                 stream_ptr), "tp_forward_train")
+                return out, ws, desc
             ws_bytes = lib.tp_workspace_bytes(ctypes.byref(desc))
             if ws_bytes == 0:
                 raise RuntimeError(f"tp_workspace_bytes: {_capi.last_error()}")
             ws = self._workspace(ws_bytes, device, stream_ptr)
-            out = torch.empty(B, self.num_queries, self.hidden_size, dtype=out_dtype, device=device)
             if _stage_events is None:
                 _capi.check(lib.tp_forward(ctypes.byref(desc),
                                            x.data_ptr(), _capi.strides3(x.stride()),
@@ -185,7 +222,27 @@ class TokenPacker(nn.Module):
                                                   x_multi.data_ptr(), _capi.strides3(x_multi.stride()),
                                                   packed.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
                                                   stream_ptr, handles, len(_stage_events)), "tp_forward_staged")
-        return out
+        return out, ws, desc
+
+    def _launch_backward(self, desc, x_multi, train_ws, params, dy):
+        device = x_multi.device
+        with torch.cuda.device(device):
+            stream_ptr = torch.cuda.current_stream(device).cuda_stream
+            lib = _capi.load_library()
+            packed = self._ensure_packed(x_multi.dtype, device, stream_ptr)
+            contiguous = [p.detach().contiguous() for p in params]
+            raw = _capi.tp_weights(*[t.data_ptr() for t in contiguous])
+            grads = [torch.empty_like(t) for t in contiguous]
+            gptr = _capi.tp_grads(*[t.data_ptr() for t in grads])
+            bw_bytes = lib.tp_backward_workspace_bytes(ctypes.byref(desc))
+            if bw_bytes == 0:
+                raise RuntimeError(f"tp_backward_workspace_bytes: {_capi.last_error()}")
+            bw = self._workspace(bw_bytes, device, ("bwd", stream_ptr))
+            dy = dy.to(x_multi.dtype).contiguous()
+            _capi.check(lib.tp_backward(ctypes.byref(desc), x_multi.data_ptr(), _capi.strides3(x_multi.stride()),
+                                        ctypes.byref(raw), packed.data_ptr(), train_ws.data_ptr(), dy.data_ptr(),
+                                        ctypes.byref(gptr), bw.data_ptr(), bw.numel(), stream_ptr), "tp_backward")
+        return grads
 
     def forward_staged(self, x):
         """Forward that also times every kernel of the schedule with HIP events recorded by the
