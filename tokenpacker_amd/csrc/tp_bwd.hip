@@ -26,30 +26,60 @@ __global__ void __launch_bounds__(256)
 transpose_kernel(const TS* __restrict__ src, long long ld, int rows_per_batch, long long batch_stride, int R, int C,
                  TD* __restrict__ dst, long long ldd, int Rpad, const float* __restrict__ mean_rstd,
                  const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ colsum_part) {
+    // 64 x 64 tile; every thread moves 16 elements with two 16-byte accesses on either side (rows are 16-byte
+    // aligned and C, ld, ldd multiples of 8 — checked on the host).  The LDS tile is fp32 with a 65-word pitch:
+    // the column gathers of the write phase hit 16 different banks.
     __shared__ float tile[64][65];
+    using S8 = typename Vec<TS>::x8;
+    using D8 = typename Vec<TD>::x8;
     const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 64 x 4
-    for (int rr = ty; rr < 64; rr += 4) {
-        const int r = r0 + rr, c = c0 + tx;
-        float v = 0.f;
-        if (r < R && c < C) {
-            const int b = r / rows_per_batch;
-            v = ld1(src + (long long)b * batch_stride + (long long)(r - b * rows_per_batch) * ld + c);
+    const int tr = threadIdx.x >> 2, seg = (threadIdx.x & 3) * 16;       // 64 rows x 4 segments of 16
+    {
+        const int r = r0 + tr;
+        float mu = 0.f, rs = 1.f;
+        const bool ln = mean_rstd != nullptr && r < R;
+        if (ln) { mu = mean_rstd[2 * (long long)r]; rs = mean_rstd[2 * (long long)r + 1]; }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = c0 + seg + h * 8;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            if (r < R && c < C) {
+                const int b = r / rows_per_batch;
+                const S8 t = *(const S8*)(src + (long long)b * batch_stride + (long long)(r - b * rows_per_batch) * ld + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tile[tr][seg + h * 8 + e] = v[e];
         }
-        tile[rr][tx] = v;
     }
     __syncthreads();
-    if (colsum_part && ty == 0) {                                   // column sums of the raw source tile, row order
-        float s = 0.f;
-        for (int rr = 0; rr < 64; ++rr) s += tile[rr][tx];
-        if (c0 + tx < C) colsum_part[(long long)blockIdx.y * C + c0 + tx] = s;
+    if (colsum_part && threadIdx.x < 64) {                          // column sums of the raw source tile, row order
+        float sum = 0.f;
+        for (int rr = 0; rr < 64; ++rr) sum += tile[rr][threadIdx.x];
+        if (c0 + (int)threadIdx.x < C) colsum_part[(long long)blockIdx.y * C + c0 + threadIdx.x] = sum;
     }
-    for (int cc = ty; cc < 64; cc += 4) {
-        const int c = c0 + cc, r = r0 + tx;
-        if (c < C && r < Rpad) {
-            float v = tile[tx][cc];
-            if (mean_rstd && r < R) v = (v - mean_rstd[2 * (long long)r]) * mean_rstd[2 * (long long)r + 1] * gamma[c] + beta[c];
-            dst[(long long)c * ldd + r] = sat_cast<TD>(r < R ? v : 0.f);
+    {
+        const int c = c0 + tr;                                       // output row = source column
+        if (c < C) {
+            const float gm = mean_rstd ? gamma[c] : 1.f, bt = mean_rstd ? beta[c] : 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int rb = r0 + seg + h * 8;
+                if (rb < Rpad) {
+                    D8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = rb + e;
+                        float v = tile[seg + h * 8 + e][tr];
+                        if (mean_rstd && r < R) v = (v - mean_rstd[2 * (long long)r]) * mean_rstd[2 * (long long)r + 1] * gm + bt;
+                        o[e] = sat_cast<TD>(r < R ? v : 0.f);
+                    }
+                    *(D8*)(dst + (long long)c * ldd + rb) = o;
+                }
+            }
         }
     }
 }
@@ -87,6 +117,42 @@ reduce_parts_kernel(const float* __restrict__ part, long long part_stride, int n
     float s = 0.f;
     for (int k = 0; k < nparts; ++k) s += part[(long long)k * part_stride + i];
     out[i] = sat_cast<TD>(s);
+}
+
+// Same sum, many parts (column-sum / LayerNorm partials: hundreds to thousands of parts of a few thousand values):
+// 16 columns per workgroup, 16 part-lanes per column walking the parts with stride 16, then a fixed 16 -> 1 tree.
+template <typename TD>
+__global__ void __launch_bounds__(256)
+reduce_many_parts_kernel(const float* __restrict__ part, long long part_stride, int nparts, int n, TD* __restrict__ out) {
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float s = 0.f;
+    if (c < n)
+        for (int k = pl; k < nparts; k += 16) s += part[(long long)k * part_stride + c];
+    red[pl][cl] = s;
+    __syncthreads();
+    if (pl == 0 && c < n) {
+        float t[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = red[i][cl];
+#pragma unroll
+        for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+            for (int i = 0; i < w; ++i) t[i] += t[i + w];
+        out[c] = sat_cast<TD>(t[0]);
+    }
+}
+
+int bw_reduce_many_parts_launch(int dst_dtype, const float* part, long long part_stride, int nparts, int n, void* out,
+                                hipStream_t stream) {
+    const unsigned blocks = (unsigned)((n + 15) / 16);
+    if (dst_dtype == TP_BF16)
+        hipLaunchKernelGGL(reduce_many_parts_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, part, part_stride, nparts, n, (bf16_t*)out);
+    else if (dst_dtype == TP_F16)
+        hipLaunchKernelGGL(reduce_many_parts_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream, part, part_stride, nparts, n, (f16_t*)out);
+    else { set_error("bw reduce: unsupported dtype %d", dst_dtype); return TP_ERR_INVALID_ARG; }
+    return check_launch("reduce_many_parts_kernel");
 }
 
 int bw_reduce_parts_launch(int dst_dtype, const float* part, long long part_stride, int nparts, long long n, void* out,

@@ -150,12 +150,12 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
 }
 
 // ---- host side ------------------------------------------------------------------------------------
-int gemm_pick_tile(int M, int N, int forced) {
+int gemm_pick_tile(int M, int N, int forced, int groups) {
     if (forced == 0) forced = tuning(TP_TUNE_GEMM_TILE);
     if (forced == 128) return 128;
     if (forced == 256 && N % 256 == 0) return 256;
     if (N % 256 != 0) return 128;
-    const long long tiles256 = (long long)((M + 255) / 256) * (N / 256);
+    const long long tiles256 = (long long)((M + 255) / 256) * (N / 256) * (groups > 0 ? groups : 1);
     return tiles256 >= 200 ? 256 : 128;     // the persistent 256-tile kernel from ~0.8 of a CU round up, else finer tiles
 }
 
@@ -182,7 +182,7 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
 
 template <typename TI, typename TO>
 static int launch_types(const GemmArgs& a, hipStream_t stream) {
-    const int tile = gemm_pick_tile(a.M, a.N, a.tile);
+    const int tile = gemm_pick_tile(a.M, a.N, a.tile, a.groups);
     const bool strided = a.rows_per_batch < a.M;
     if (tile == 256)
         return strided ? launch_cfg<TI, TO, 256, 256, 128, 64, true>(a, stream)
@@ -200,7 +200,7 @@ int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stre
         set_error("tp gemm: ROW_STATS with fp32 output is not supported");
         return TP_ERR_INVALID_ARG;
     }
-    if (gemm_pick_tile(a.M, a.N, a.tile) == 256 && tuning(TP_TUNE_GEMM_KERNEL) != 1)
+    if (gemm_pick_tile(a.M, a.N, a.tile, a.groups) == 256 && tuning(TP_TUNE_GEMM_KERNEL) != 1)
         return gemm8_launch(in_dtype, out_dtype, a, stream);
     if (in_dtype == TP_BF16) {
         if (out_dtype == TP_BF16) return launch_types<bf16_t, bf16_t>(a, stream);

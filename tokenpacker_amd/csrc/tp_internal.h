@@ -56,7 +56,7 @@ struct GemmArgs {
     int tile;                         // 0 auto, 128, 256
 };
 int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream);
-int gemm_pick_tile(int M, int N, int forced);     // -> 128 or 256
+int gemm_pick_tile(int M, int N, int forced, int groups = 1);     // -> 128 or 256
 // 256x256x64 ping-pong kernel (tp_gemm8.hip); gemm_launch routes tile-256 problems to it
 int gemm8_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream);
 inline int gemm_stats_parts(int N) { return N / 128; }   // one (sum, sumsq) slab per 128 output columns
@@ -112,6 +112,8 @@ int bw_transpose_launch(int src_dtype, int dst_dtype, const void* src, long long
                         const float* gamma, const float* beta, float* colsum_part, hipStream_t stream);
 int bw_reduce_parts_launch(int dst_dtype, const float* part, long long part_stride, int nparts, long long n, void* out,
                            hipStream_t stream);
+int bw_reduce_many_parts_launch(int dst_dtype, const float* part, long long part_stride, int nparts, int n, void* out,
+                                hipStream_t stream);
 int bw_ln_backward_launch(int gdtype, const void* dy, const void* x_f16, const float* mean_rstd, const float* gamma,
                           void* dx, float* part, int nblocks, long long rows, hipStream_t stream);
 int bw_region_attention_launch(int gdtype, const void* q, const void* k, const void* v, const void* dout, void* dq,

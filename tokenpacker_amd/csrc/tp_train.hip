@@ -20,7 +20,7 @@
 namespace tp {
 
 static inline size_t up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
-static inline int pad_tokens(long long r) { return (int)((r + 511) / 512 * 512); }     // any split in {1,2,4,8} keeps K % 64 == 0
+static inline int pad_tokens(long long r) { return (int)((r + 1023) / 1024 * 1024); }   // any split in {1,..,16} keeps K % 64 == 0
 
 struct BwLayout {
     // transposed weights (G) for the dgrad GEMMs, fp32 LayerNorm affines
@@ -54,10 +54,11 @@ static BwLayout bw_layout(int B, int grid, int s, int D) {
     L.dKV = take(2 * R * E * 2); L.dKVT = take(2 * E * Rp * 2); L.kv1T = take(2 * E * Rp * 2); L.dkv1 = take(2 * R * E * 2);
     L.dH2 = take(2 * R * E * 2); L.dH2T = take(2 * E * Rp * 2); L.hkvT = take(2 * E * Rp * 2);
     L.dZ1 = take(R * 2 * E * 2); L.dZ1T = take(2 * E * Rp * 2); L.xmT = take((size_t)kMulti * Rp * 2);
-    // split-K partials: at most 8 splits of the largest weight
+    // split-K partials: S splits of an [Nout, Kin] weight with S * tiles(256^2) <= ~512
     size_t wmax = (size_t)D * D;
     if ((size_t)2 * E * kMulti > wmax) wmax = (size_t)2 * E * kMulti;
-    L.part_bytes = 8 * wmax * 4;
+    L.part_bytes = 2 * wmax * 4;
+    if (L.part_bytes < (size_t)16 * D * E * 4) L.part_bytes = (size_t)16 * D * E * 4;
     L.part = take(L.part_bytes);
     const size_t cmax = (size_t)D > 2 * E ? (size_t)D : 2 * E;
     L.colpart = take((Rp / 64) * cmax * 4);
@@ -137,7 +138,7 @@ int tp_backward(const tp_desc* desc, const void* x_multi, const int64_t xm_strid
     };
     // bias gradient from the column-sum partials the last transpose left behind
     auto bias_grad = [&](int rpad, int cols, void* out) -> int {
-        return bw_reduce_parts_launch(GT, colpart, cols, rpad / 64, cols, out, stream);
+        return bw_reduce_many_parts_launch(GT, colpart, cols, rpad / 64, cols, out, stream);
     };
     // dX[rows, Kin] = dY[rows, Nout] · W[Nout, Kin]  with W^T [Kin, Nout] given
     auto dgrad = [&](const void* dY, long long ldy, int rows, int Nout, const void* WT, int Kin, void* dX, long long ldx,
@@ -150,12 +151,12 @@ int tp_backward(const tp_desc* desc, const void* x_multi, const int64_t xm_strid
     auto wgrad = [&](const void* dYT, const void* XT, int Nout, int Kin, int rpad, void* grad_out) -> int {
         const long long tiles = (long long)((Nout + 255) / 256) * ((Kin + 255) / 256);
         int S = 1;
-        while (S < 8 && tiles * S < 256 && (rpad / (S * 2)) % 64 == 0) S *= 2;
+        while (S < 16 && tiles * S < 256 && (rpad / (S * 2)) % 64 == 0) S *= 2;
         if ((size_t)S * Nout * Kin * 4 > L.part_bytes) { set_error("tp_backward: split-K partial buffer too small"); return TP_ERR_WORKSPACE; }
         GemmArgs a = plain_gemm(dYT, rpad, XT, part, Kin, Nout, Kin, rpad / S, nullptr, 0);
         a.ldw_bytes = (long long)rpad * 2;
         a.groups = S; a.a_gs = (long long)(rpad / S) * 2; a.w_gs = (long long)(rpad / S) * 2; a.c_gs = (long long)Nout * Kin * 4;
-        a.tile = (Nout % 256 == 0 && Kin % 256 == 0) ? 0 : 128;
+        a.tile = (Nout % 256 == 0 && Kin % 256 == 0) ? 0 : 128;      // auto: 256-tile persistent kernel once S * tiles fills the chip
         TP_TRY(gemm_launch(GT, TP_F32, a, stream));
         return bw_reduce_parts_launch(GT, part, (long long)Nout * Kin, S, (long long)Nout * Kin, grad_out, stream);
     };
@@ -225,16 +226,16 @@ int tp_backward(const tp_desc* desc, const void* x_multi, const int64_t xm_strid
     {
         const int nb = 256;
         TP_TRY(bw_ln_backward_launch(GT, bw + L.dq1, fw + W.q1pre, (const float*)(fw + W.mr_q), ln_g, bw + L.dQ1pre, lnpart, nb, Rq, stream));
-        TP_TRY(bw_reduce_parts_launch(GT, lnpart, 2 * E, nb, E, grads->ln_q_1_weight, stream));
-        TP_TRY(bw_reduce_parts_launch(GT, lnpart + E, 2 * E, nb, E, grads->ln_q_1_bias, stream));
+        TP_TRY(bw_reduce_many_parts_launch(GT, lnpart, 2 * E, nb, E, grads->ln_q_1_weight, stream));
+        TP_TRY(bw_reduce_many_parts_launch(GT, lnpart + E, 2 * E, nb, E, grads->ln_q_1_bias, stream));
         void* gw[2] = {grads->ln_k_1_weight, grads->ln_v_1_weight};
         void* gb[2] = {grads->ln_k_1_bias, grads->ln_v_1_bias};
         for (int t = 0; t < 2; ++t) {
             TP_TRY(bw_ln_backward_launch(GT, bw + L.dkv1 + (size_t)t * kvE * 2, fw + W.h2 + (size_t)t * kvE * 2,
                                          (const float*)(fw + W.mr_kv) + (size_t)t * R * 2, ln_g + (1 + t) * E,
                                          bw + L.dH2 + (size_t)t * kvE * 2, lnpart, nb, R, stream));
-            TP_TRY(bw_reduce_parts_launch(GT, lnpart, 2 * E, nb, E, gw[t], stream));
-            TP_TRY(bw_reduce_parts_launch(GT, lnpart + E, 2 * E, nb, E, gb[t], stream));
+            TP_TRY(bw_reduce_many_parts_launch(GT, lnpart, 2 * E, nb, E, gw[t], stream));
+            TP_TRY(bw_reduce_many_parts_launch(GT, lnpart + E, 2 * E, nb, E, gb[t], stream));
         }
     }
     // ---- q_proj_1 (no bias) ---------------------------------------------------------------------------------------
@@ -259,8 +260,8 @@ int tp_backward(const tp_desc* desc, const void* x_multi, const int64_t xm_strid
     }
     // ---- k/v_proj_1[0] -----------------------------------------------------------------------------------------------
     TP_TRY(T(GT, bw + L.dZ1, 2 * E, R, 2 * E, bw + L.dZ1T, Rp, nullptr, nullptr, nullptr, colpart));
-    TP_TRY(bw_reduce_parts_launch(GT, colpart, 2 * E, Rp / 64, E, grads->k_proj_1_0_bias, stream));
-    TP_TRY(bw_reduce_parts_launch(GT, colpart + E, 2 * E, Rp / 64, E, grads->v_proj_1_0_bias, stream));
+    TP_TRY(bw_reduce_many_parts_launch(GT, colpart, 2 * E, Rp / 64, E, grads->k_proj_1_0_bias, stream));
+    TP_TRY(bw_reduce_many_parts_launch(GT, colpart + E, 2 * E, Rp / 64, E, grads->v_proj_1_0_bias, stream));
     TP_TRY(bw_transpose_launch(GT, GT, x_multi, xm_strides[1], N, xm_strides[0], R, kMulti, bw + L.xmT, Rp, Rp, nullptr,
                                nullptr, nullptr, nullptr, stream));
     {   // dW0 [2E, 4096] = dZ1^T · x_multi: rows 0..E-1 belong to k_proj_1[0], E..2E-1 to v_proj_1[0]

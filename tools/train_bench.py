@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Training-step timing of the projector on one MI355X: HIP forward+backward (tp_forward_train / tp_backward
+through the autograd node) next to the reference's op sequence under PyTorch-ROCm eager autograd
+(tests/eager_port.py).  Batch 32 is the reference's per-GPU pretraining batch (scripts/v1_5/pretrain.sh:19).
+
+    python tools/train_bench.py [--batches 32 256] [--scale-factor 2] [--out gpurun_out/train_bench.json]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests.eager_port import eager_forward  # noqa: E402  (baseline only)
+from tokenpacker_amd import TokenPacker  # noqa: E402
+
+
+def flops_fwd(B, s, D):
+    N, M, E = 576, (24 // s) ** 2, 1024
+    return 2.0 * B * (N * 4096 * E * 2 + N * E * E * 4 + M * E * E * 3 + M * E * D + M * D * D)
+
+
+def timed(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batches", type=int, nargs="+", default=[32, 256])
+    ap.add_argument("--scale-factor", type=int, default=2)
+    ap.add_argument("--hidden-size", type=int, default=4096)
+    ap.add_argument("--out", default="gpurun_out/train_bench.json")
+    ap.add_argument("--hip-only", action="store_true", help="skip the eager baseline (profiling runs)")
+    args = ap.parse_args()
+    s, D, dtype = args.scale_factor, args.hidden_size, torch.bfloat16
+    results = []
+    for B in args.batches:
+        torch.manual_seed(0)
+        m = TokenPacker(hidden_size=D, scale_factor=s).to(device="cuda", dtype=dtype)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        x = torch.randn(B, 576, 1024, generator=g, device="cuda").to(dtype)
+        xm = torch.randn(B, 576, 4096, generator=g, device="cuda").to(dtype)
+        w = torch.randn(B, (24 // s) ** 2, D, generator=g, device="cuda").to(dtype)
+
+        def step_hip():
+            m.zero_grad(set_to_none=True)
+            (m((x, xm)) * w).sum().backward()
+
+        def step_eager():
+            m.zero_grad(set_to_none=True)
+            (eager_forward(m, x, xm) * w).sum().backward()
+
+        def fwd_hip():
+            with torch.no_grad():
+                m((x, xm))
+
+        iters = 20 if B <= 64 else 8
+        ms_hip = timed(step_hip, iters)
+        ms_eager = timed(step_eager, iters) if not args.hip_only else float("nan")
+        ms_fwd = timed(fwd_hip, iters)
+        # gradient agreement of the two bf16 pipelines (sanity, loose)
+        # (ln_k_1.bias and the k third of in_proj_bias have a mathematically zero gradient: round-off in both)
+        E = 1024
+        if args.hip_only:
+            print(json.dumps({"B": B, "hip_fwd_bwd_ms": round(ms_hip, 3), "hip_fwd_only_ms": round(ms_fwd, 3)}), flush=True)
+            continue
+        step_eager(); ge = {k: p.grad.float().clone() for k, p in m.named_parameters()}
+        step_hip(); gh = {k: p.grad.float().clone() for k, p in m.named_parameters()}
+        for d in (ge, gh):
+            d.pop("ln_k_1.bias")
+            d["clip_attn.in_proj_bias"] = torch.cat([d["clip_attn.in_proj_bias"][:E], d["clip_attn.in_proj_bias"][2 * E:]])
+        agree = max(float((gh[k] - ge[k]).norm() / (ge[k].norm() + 1e-20)) for k in ge)
+        rec = {"B": B, "scale_factor": s, "D": D, "dtype": "bf16", "hip_fwd_bwd_ms": round(ms_hip, 3),
+               "hip_fwd_only_ms": round(ms_fwd, 3), "eager_rocm_fwd_bwd_ms": round(ms_eager, 3),
+               "speedup": round(ms_eager / ms_hip, 3), "images_per_s_train": round(B / ms_hip * 1e3, 1),
+               "train_tflops_algorithmic": round(3 * flops_fwd(B, s, D) / ms_hip / 1e9, 1),
+               "max_param_grad_rel_l2_vs_eager": agree}
+        print(json.dumps(rec), flush=True)
+        results.append(rec)
+        del m, x, xm, w
+        torch.cuda.empty_cache()
+    os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+    json.dump(results, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
