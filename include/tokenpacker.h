@@ -125,6 +125,19 @@ int tp_forward(const tp_desc* desc,
                void* workspace, size_t workspace_bytes,
                void* stream);
 
+/* tp_forward with x_multi given as its FOUR [B, g*g, 1024] sources — the CLIP hidden states 12, 16, 22, 23 that
+ * `CLIPVisionTower.feature_select` concatenates (clip_encoder.py:28-32) — each with the element strides
+ * `part_strides` (e.g. the `[:, 1:]` slice of a [B, 577, 1024] hidden state).  The first GEMM walks the four
+ * sources as K-ranges, so the tower's torch.cat (1.2 GB written and read again at B = 256) never happens.
+ * Bit-identical to tp_forward on the concatenated tensor. */
+int tp_forward_parts(const tp_desc* desc,
+                     const void* x, const int64_t x_strides[3],
+                     const void* const xm_parts[4], const int64_t part_strides[3],
+                     const void* packed_weights,
+                     void* out,
+                     void* workspace, size_t workspace_bytes,
+                     void* stream);
+
 /* Same as tp_forward, additionally recording caller-owned HIP events (hipEvent_t, created with
  * timing enabled) on `stream` at the TP_NUM_STAGES+1 stage boundaries, so a benchmark can time each
  * kernel of the schedule inside the real forward (bench.py's `roofline` object).  Stages, in order:
@@ -232,6 +245,13 @@ int tp_forward_train(const tp_desc* desc, const void* x, const int64_t x_strides
 int tp_backward(const tp_desc* desc, const void* x_multi, const int64_t xm_strides[3], const tp_weights* raw,
                 const void* packed_weights, const void* train_workspace, const void* dy, const tp_grads* grads,
                 void* bw_workspace, size_t bw_workspace_bytes, void* stream);
+/* the same two with x_multi as its four sources (see tp_forward_parts) */
+int tp_forward_train_parts(const tp_desc* desc, const void* x, const int64_t x_strides[3],
+                           const void* const xm_parts[4], const int64_t part_strides[3], const void* packed_weights,
+                           void* out, void* train_workspace, size_t workspace_bytes, void* stream);
+int tp_backward_parts(const tp_desc* desc, const void* const xm_parts[4], const int64_t part_strides[3],
+                      const tp_weights* raw, const void* packed_weights, const void* train_workspace, const void* dy,
+                      const tp_grads* grads, void* bw_workspace, size_t bw_workspace_bytes, void* stream);
 
 /* ---- TokenPacker-HD token assembly (the step right after the projector) --------------------------------
  * Replaces the Python loop + torch.cat of `prepare_inputs_labels_for_multimodal` in mode 'slice'

@@ -36,8 +36,12 @@ def _grads(dtype, s, D, B, seed):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("s,D,B", [(2, 256, 2), (3, 256, 3), (4, 512, 2)])
+@pytest.mark.parametrize("s,D,B", [(2, 256, 2), (3, 256, 3), (4, 512, 2), (2, 4096, 32)])
 def test_parameter_gradients_vs_oracle_autograd(dtype, s, D, B):
+    """(2, 4096, 32) is the reference's pretraining shape per GPU (pretrain.sh:19): every backward GEMM large
+    enough runs on the persistent 256-tile kernel there (dgrad with the GELU' epilogue, split-K wgrad)."""
+    if D == 4096 and dtype == torch.float16:
+        pytest.skip("full-size case once (bf16, the training dtype of the reference)")
     y, y_ref, got, want = _grads(dtype, s, D, B, seed=40 + s)
     assert orc.rel_err(y, y_ref.detach()) <= (2.0 ** -8 if dtype == torch.bfloat16 else 1.2e-3)   # training forward == forward
     # Some gradients are mathematically ZERO (ln_k_1.bias and the k-third of in_proj_bias shift every logit of a

@@ -318,10 +318,16 @@ int tp_linear(const tp_linear_args* a, void* stream) {
 namespace tp {
 int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3], const void* x_multi,
                  const int64_t xm_strides[3], const void* packed_weights, void* out, void* workspace,
-                 size_t workspace_bytes, void* stream_, void* const* stage_events, bool train) {
+                 size_t workspace_bytes, void* stream_, void* const* stage_events, bool train,
+                 const void* const* xm_parts) {
     TP_TRY(validate_desc(desc));
     TP_TRY(check_strides("x", x, x_strides));
-    TP_TRY(check_strides("x_multi", x_multi, xm_strides));
+    if (xm_parts) {                                     // x_multi given as the four [B, N, 1024] hidden-state slices
+        for (int i = 0; i < 4; ++i) TP_TRY(check_strides("x_multi part", xm_parts[i], xm_strides));
+        x_multi = xm_parts[0];
+    } else {
+        TP_TRY(check_strides("x_multi", x_multi, xm_strides));
+    }
     if (!packed_weights || !out || !workspace) { set_error("tp_forward: NULL argument"); return TP_ERR_INVALID_ARG; }
     const int B = desc->batch, g = desc->raw_grid, s = desc->scale_factor, D = desc->hidden_size, dt = desc->dtype;
     const int N = g * g, G = g / s, M = G * G, E = kEmbed;
@@ -361,6 +367,10 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
                                 (const float*)(pw + P.b_kv0), TP_LINEAR_GELU | (train ? TP_LINEAR_SAVE_PRE : 0));
         a.rows_per_batch = N; a.a_batch_stride_bytes = xm_strides[0] * 2;
         a.C2 = train ? ws + W.z1 : nullptr;
+        if (xm_parts) {
+            for (int i = 0; i < 4; ++i) a.A_parts[i] = (const char*)xm_parts[i];
+            a.k_part = kMulti / 4;
+        }
         TP_TRY(gemm_launch(dt, TP_F16, a, stream));      // raw operands in the io dtype, fp16 activations out
     }
     // 3. H2[g] = Hkv[:, g*1024:(g+1)*1024] · W{k,v}2^T + b, and LayerNorm partials of H2
@@ -442,6 +452,14 @@ int tp_forward(const tp_desc* desc, const void* x, const int64_t x_strides[3], c
                size_t workspace_bytes, void* stream) {
     return forward_impl(desc, x, x_strides, x_multi, xm_strides, packed_weights, out, workspace, workspace_bytes,
                         stream, nullptr, false);
+}
+
+int tp_forward_parts(const tp_desc* desc, const void* x, const int64_t x_strides[3], const void* const xm_parts[4],
+                     const int64_t part_strides[3], const void* packed_weights, void* out, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    if (!xm_parts) { set_error("tp_forward_parts: xm_parts is NULL"); return TP_ERR_INVALID_ARG; }
+    return forward_impl(desc, x, x_strides, nullptr, part_strides, packed_weights, out, workspace, workspace_bytes,
+                        stream, nullptr, false, xm_parts);
 }
 
 int tp_forward_staged(const tp_desc* desc, const void* x, const int64_t x_strides[3], const void* x_multi,

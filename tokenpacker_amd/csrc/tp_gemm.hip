@@ -33,7 +33,7 @@ constexpr int gemm_lds_bytes() { return 2 * (BM + BN) * ROW_BYTES; }
 // [:,1:] slices) — only the first K/V layer needs it, which also gives that launch (45 % of the path's
 // FLOPs) its own kernel symbol in profiles.
 // TI: operand element type (bf16 / fp16) — selects the MFMA;  TO: output element type (bf16 / fp16 / float).
-template <typename TI, typename TO, int BM, int BN, int WM, int WN, bool STRIDED_A>
+template <typename TI, typename TO, int BM, int BN, int WM, int WN, int AMODE, bool TRAIN_EPI>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
     using T = TI;
@@ -74,7 +74,7 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
         if (c < BM / 8) {
             int row = m0 + c * 8 + (lane >> 3);
             row = row < p.M ? row : p.M - 1;
-            if constexpr (STRIDED_A) {
+            if constexpr (AMODE != 0) {
                 const int b = row / p.rows_per_batch;
                 const int t = row - b * p.rows_per_batch;
                 src[i] = Ag + (long long)b * p.a_batch_stride_bytes + (long long)t * p.lda_bytes + kslot * 16;
@@ -89,9 +89,15 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
 
     auto issue = [&](int kt, int stage) {
         char* dst = smem + stage * STAGE + wave * CPW * 1024;
+        long long a_adv = (long long)kt * ROW_BYTES;            // K advance of the A pieces
+        if constexpr (AMODE == 2) {                              // K split over four source tensors
+            const int tpp = p.k_part / BK, part = kt / tpp;
+            a_adv = (p.A_parts[part] - p.A_parts[0]) + (long long)(kt - part * tpp) * ROW_BYTES;
+        }
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
-            __builtin_amdgcn_global_load_lds((gbl_void*)(src[i] + (long long)kt * ROW_BYTES),
+            const bool is_a = (wave * CPW + i) < BM / 8;         // wave-uniform
+            __builtin_amdgcn_global_load_lds((gbl_void*)(src[i] + (is_a ? a_adv : (long long)kt * ROW_BYTES)),
                                              (lds_void*)(dst + i * 1024), 16, 0, 0);
         }
     };
@@ -146,7 +152,7 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
         }
     }
 
-    gemm_epilogue<TO, BM, BN, WM, WN>(acc, p, g, m0, n0, tile_n, wm, wn, lane, tid, mean_rstd, smem);
+    gemm_epilogue<TO, BM, BN, WM, WN, false, TRAIN_EPI>(acc, p, g, m0, n0, tile_n, wm, wn, lane, tid, mean_rstd, smem);
 }
 
 // ---- host side ------------------------------------------------------------------------------------
@@ -159,11 +165,11 @@ int gemm_pick_tile(int M, int N, int forced, int groups) {
     return tiles256 >= 200 ? 256 : 128;     // the persistent 256-tile kernel from ~0.8 of a CU round up, else finer tiles
 }
 
-template <typename TI, typename TO, int BM, int BN, int WM, int WN, bool STRIDED_A>
+template <typename TI, typename TO, int BM, int BN, int WM, int WN, int AMODE, bool TRAIN_EPI = false>
 static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     constexpr int lds = gemm_lds_bytes<BM, BN>();
     constexpr int threads = (BM / WM) * (BN / WN) * 64;
-    auto kern = gemm_kernel<TI, TO, BM, BN, WM, WN, STRIDED_A>;
+    auto kern = gemm_kernel<TI, TO, BM, BN, WM, WN, AMODE, TRAIN_EPI>;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [&] {
@@ -184,11 +190,29 @@ template <typename TI, typename TO>
 static int launch_types(const GemmArgs& a, hipStream_t stream) {
     const int tile = gemm_pick_tile(a.M, a.N, a.tile, a.groups);
     const bool strided = a.rows_per_batch < a.M;
+    constexpr bool HALF_OUT = !std::is_same<TO, float>::value;
+    const bool train_epi = (a.flags & (TP_LINEAR_SAVE_PRE | TP_LINEAR_GELU_BWD)) != 0;
+    if (a.A_parts[0] || train_epi) {                   // training epilogues / four-source A: 128-tile kernel only
+        if constexpr (HALF_OUT) {
+            if (a.A_parts[0]) {
+                if constexpr (std::is_same<TO, f16_t>::value)
+                    return train_epi ? launch_cfg<TI, TO, 128, 128, 64, 64, 2, true>(a, stream)
+                                     : launch_cfg<TI, TO, 128, 128, 64, 64, 2, false>(a, stream);
+                set_error("tp gemm: a multi-part A operand is supported for fp16 output only");
+                return TP_ERR_INVALID_ARG;
+            }
+            return strided ? launch_cfg<TI, TO, 128, 128, 64, 64, 1, true>(a, stream)
+                           : launch_cfg<TI, TO, 128, 128, 64, 64, 0, true>(a, stream);
+        } else {
+            set_error("tp gemm: training epilogues / multi-part A need a 16-bit output");
+            return TP_ERR_INVALID_ARG;
+        }
+    }
     if (tile == 256)
-        return strided ? launch_cfg<TI, TO, 256, 256, 128, 64, true>(a, stream)
-                       : launch_cfg<TI, TO, 256, 256, 128, 64, false>(a, stream);
-    return strided ? launch_cfg<TI, TO, 128, 128, 64, 64, true>(a, stream)
-                   : launch_cfg<TI, TO, 128, 128, 64, 64, false>(a, stream);
+        return strided ? launch_cfg<TI, TO, 256, 256, 128, 64, 1>(a, stream)
+                       : launch_cfg<TI, TO, 256, 256, 128, 64, 0>(a, stream);
+    return strided ? launch_cfg<TI, TO, 128, 128, 64, 64, 1>(a, stream)
+                   : launch_cfg<TI, TO, 128, 128, 64, 64, 0>(a, stream);
 }
 
 int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream) {

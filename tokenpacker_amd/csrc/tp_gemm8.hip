@@ -66,7 +66,9 @@ constexpr int G8_DEPTH = 3;                        // DMA groups left in flight 
 
 }  // namespace
 
-template <typename TI, typename TO, bool STRIDED_A, bool PERSIST>
+// AMODE: 0 = A rows contiguous (lda), 1 = rows in batches with a batch stride (the CLIP tower's [:,1:] slices),
+//        2 = like 1 with K split over four source tensors (the tower's hidden states consumed without torch.cat)
+template <typename TI, typename TO, int AMODE, bool PERSIST, bool TRAIN_EPI>
 __global__ void __launch_bounds__(512, 2)
 gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int xcd_swizzle) {
     using X8 = typename Vec<TI>::x8;
@@ -100,6 +102,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
     // ---- per-tile state ------------------------------------------------------------------------------------
     int m0, n0, tile_n;
     __amdgpu_buffer_rsrc_t rsrc_a, rsrc_w;
+    long long a_tile_off_cur = 0;                      // AMODE 2: the descriptor of a K-part is rebuilt from its base
     int voff_a[2][2], voff_w[2][2];                    // [sub][q] per-lane DMA source offsets
     const int kslot = (lane & 7) ^ (lane >> 3);
 
@@ -110,7 +113,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
     //   A groups: rho -> tile row  (rho / 64) * 128 + sub * 64 + rho % 64     (sub = 0: G0, 1: G3)
     //   W groups: rho -> tile col  (rho / 32) *  64 + sub * 32 + rho % 32     (sub = 0: G1, 1: G2)
     auto a_row_off = [&](int row) __attribute__((always_inline)) -> long long {
-        if constexpr (STRIDED_A) {
+        if constexpr (AMODE != 0) {
             const int b = row / p.rows_per_batch;
             const int t = row - b * p.rows_per_batch;
             return (long long)b * p.a_batch_stride_bytes + (long long)t * p.lda_bytes;
@@ -124,6 +127,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         m0 = tm * BM; n0 = tile_n * BN;
         const long long a_tile_off = a_row_off(m0);
         rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + g * p.a_gs + a_tile_off), 0, 0x7fffffff, 0x00020000);
+        a_tile_off_cur = a_tile_off;
         rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + g * p.w_gs + (long long)n0 * ldw), 0, 0x7fffffff,
                                                    0x00020000);
 #pragma unroll
@@ -146,12 +150,27 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         constexpr int sub = (grp == 2 || grp == 3) ? 1 : 0;
         char* dst = smem + (kt & 1) * G8_BUF + grp * G8_GROUP + wave * 2048;
         const int soff = kt * ROW_BYTES;
+        if constexpr (is_a && AMODE == 2) {
+            // K-tile kt lives in source kt / tpp: pick that source's base with scalar selects and rebuild the
+            // descriptor (words 2, 3 are constants) — four resident descriptors cost 12 more SGPRs, which pushed
+            // hipcc into VGPR-held descriptors and waterfall loops around every DMA instruction
+            const int tpp = p.k_part / BK, part = kt / tpp, so = (kt - part * tpp) * ROW_BYTES;   // wave-uniform
+            const char* b = part == 0 ? p.A_parts[0] : part == 1 ? p.A_parts[1] : part == 2 ? p.A_parts[2] : p.A_parts[3];
+            const unsigned long long addr = (unsigned long long)(b + a_tile_off_cur);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)addr);
+            const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(addr >> 32));
+            const auto r = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            if constexpr (is_a)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)(dst + q * 1024), 16, voff_a[sub][q], soff, 0, 0);
-            else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void*)(dst + q * 1024), 16, voff_w[sub][q], soff, 0, 0);
+            for (int q = 0; q < 2; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst + q * 1024), 16, voff_a[sub][q], so, 0, 0);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if constexpr (is_a)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)(dst + q * 1024), 16, voff_a[sub][q], soff, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void*)(dst + q * 1024), 16, voff_w[sub][q], soff, 0, 0);
+            }
         }
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -283,7 +302,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
                 mean_rstd[i] = *(const float2*)(p.stats_in + g * p.stats_in_gs + (long long)m * 2);
             }
         }
-        gemm_epilogue<TO, BM, BN, WM, WN>(acc, p, g, m0, n0, tile_n, wm, wn, lane, tid, mean_rstd, smem);
+        gemm_epilogue<TO, BM, BN, WM, WN, false, TRAIN_EPI>(acc, p, g, m0, n0, tile_n, wm, wn, lane, tid, mean_rstd, smem);
     } else {
         // ---- persistent: walk the tile list ----------------------------------------------------------------
         // Epilogue parameters of a tile, one element per thread: threads 0..255 the tile's bias / colsum column,
@@ -338,8 +357,8 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
                 const f32x2_t v = *(const f32x2_t*)(smem + G8_PAR + 2 * BN * 4 + (wm * WM + i * 16 + (lane & 15)) * 8);
                 mean_rstd[i] = make_float2(v[0], v[1]);
             }
-            gemm_epilogue<TO, BM, BN, WM, WN, true>(acc, p, g, m0c, n0c, tile_nc, wm, wn, lane, tid, mean_rstd,
-                                                    smem + G8_RED, smem + G8_PAR);
+            gemm_epilogue<TO, BM, BN, WM, WN, true, TRAIN_EPI>(acc, p, g, m0c, n0c, tile_nc, wm, wn, lane, tid, mean_rstd,
+                                                               smem + G8_RED, smem + G8_PAR);
             if (!has_next) break;
             L = Ln;
             block_sync_lds();                               // everyone is done with this tile's parameters
@@ -358,9 +377,9 @@ static int g8_num_cus() {
     return cus;
 }
 
-template <typename TI, typename TO, bool STRIDED_A, bool PERSIST>
+template <typename TI, typename TO, int AMODE, bool PERSIST, bool TRAIN_EPI>
 static int launch8_cfg(const GemmArgs& a, hipStream_t stream) {
-    auto kern = gemm8_kernel<TI, TO, STRIDED_A, PERSIST>;
+    auto kern = gemm8_kernel<TI, TO, AMODE, PERSIST, TRAIN_EPI>;
     constexpr int lds = PERSIST ? G8_LDS : G8_RING;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
@@ -386,8 +405,23 @@ static int launch8_cfg(const GemmArgs& a, hipStream_t stream) {
 
 template <typename TI, typename TO, bool PERSIST>
 static int launch8_var(const GemmArgs& a, hipStream_t stream) {
-    return a.rows_per_batch < a.M ? launch8_cfg<TI, TO, true, PERSIST>(a, stream)
-                                  : launch8_cfg<TI, TO, false, PERSIST>(a, stream);
+    constexpr bool HALF_OUT = !std::is_same<TO, float>::value;
+    const bool train_epi = (a.flags & (TP_LINEAR_SAVE_PRE | TP_LINEAR_GELU_BWD)) != 0;
+    if (a.A_parts[0]) {                                // K split over four sources: the forward's first layer only
+        if constexpr (std::is_same<TO, f16_t>::value && PERSIST)
+            return train_epi ? launch8_cfg<TI, TO, 2, PERSIST, true>(a, stream) : launch8_cfg<TI, TO, 2, PERSIST, false>(a, stream);
+        set_error("tp gemm8: a multi-part A operand is supported for fp16 output on the persistent kernel only");
+        return TP_ERR_INVALID_ARG;
+    }
+    if (train_epi) {
+        if constexpr (HALF_OUT && PERSIST)
+            return a.rows_per_batch < a.M ? launch8_cfg<TI, TO, 1, PERSIST, true>(a, stream)
+                                          : launch8_cfg<TI, TO, 0, PERSIST, true>(a, stream);
+        set_error("tp gemm8: training epilogues need a 16-bit output on the persistent kernel");
+        return TP_ERR_INVALID_ARG;
+    }
+    return a.rows_per_batch < a.M ? launch8_cfg<TI, TO, 1, PERSIST, false>(a, stream)
+                                  : launch8_cfg<TI, TO, 0, PERSIST, false>(a, stream);
 }
 
 // TP_TUNE_GEMM_KERNEL: 0 persistent (default) | 2 one tile per workgroup

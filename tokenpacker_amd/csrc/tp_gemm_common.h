@@ -79,7 +79,9 @@ __device__ __forceinline__ void block_sync_lds() {
     __builtin_amdgcn_s_barrier();
 }
 
-template <typename TO, int BM, int BN, int WM, int WN, bool LDS_PARAMS = false>
+// TRAIN_EPI compiles in the two training-only epilogue features (TP_LINEAR_SAVE_PRE, TP_LINEAR_GELU_BWD); the
+// inference kernels are instantiated without them so that their register budget is not taxed.
+template <typename TO, int BM, int BN, int WM, int WN, bool LDS_PARAMS = false, bool TRAIN_EPI = false>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], const GemmArgs& p, const int g,
                                               const int m0, const int n0, const int tile_n, const int wm,
                                               const int wn, const int lane, const int tid,
@@ -136,6 +138,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
                 f32x4 v0 = acc[i][j0], v1 = acc[i][j1];
                 if (flags & TP_LINEAR_LN_FOLD) { v0 = rstd * (v0 - mu * csum_v[j0]); v1 = rstd * (v1 - mu * csum_v[j1]); }
                 v0 += bias_v[j0]; v1 += bias_v[j1];
+                if constexpr (TRAIN_EPI) {
                 if (flags & TP_LINEAR_GELU_BWD) {          // backward of a GELU layer: dZ = dA * gelu'(Z), Z fp16 [M, ldz]
                     const f16_t* zrow = (const f16_t*)(p.Z + g * p.z_gs) + (long long)(row_ok ? m : 0) * p.ldz + col_base;
                     const f16x4 z0 = *(const f16x4*)(zrow + j0 * 16), z1 = *(const f16x4*)(zrow + j1 * 16);
@@ -154,6 +157,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
                         *(O4p*)(prow + j0 * 16) = __builtin_convertvector(c0, O4p);
                         *(O4p*)(prow + j1 * 16) = __builtin_convertvector(c1, O4p);
                     }
+                }
                 }
                 if (flags & TP_LINEAR_GELU) {
 #pragma unroll

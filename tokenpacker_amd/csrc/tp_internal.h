@@ -47,6 +47,8 @@ struct GemmArgs {
     long long lda_bytes;              // between rows inside a batch
     long long ldc;                    // elements
     long long ldw_bytes;              // between rows of W (0: K * 2 — a contiguous [N, K] weight)
+    const char* A_parts[4];           // K split over 4 source tensors of k_part columns each (NULL: A alone)
+    int k_part;
     // per-group strides (bytes for A/W/C, floats for the fp32 side arrays)
     long long a_gs, w_gs, c_gs, bias_gs, stats_in_gs, colsum_gs, stats_out_gs;
     int M, N, K;
@@ -123,6 +125,7 @@ GemmArgs plain_gemm(const void* A, long long lda_elems, const void* W, void* C, 
                     const float* bias, int flags);
 int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3], const void* x_multi,
                  const int64_t xm_strides[3], const void* packed_weights, void* out, void* workspace,
-                 size_t workspace_bytes, void* stream_, void* const* stage_events, bool train);
+                 size_t workspace_bytes, void* stream_, void* const* stage_events, bool train,
+                 const void* const* xm_parts = nullptr);
 
 }  // namespace tp

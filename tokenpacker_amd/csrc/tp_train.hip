@@ -92,10 +92,22 @@ int tp_forward_train(const tp_desc* desc, const void* x, const int64_t x_strides
                         stream, nullptr, true);
 }
 
-int tp_backward(const tp_desc* desc, const void* x_multi, const int64_t xm_strides[3], const tp_weights* raw,
-                const void* packed_weights, const void* train_workspace, const void* dy, const tp_grads* grads,
-                void* bw_workspace, size_t bw_workspace_bytes, void* stream_) {
+int tp_forward_train_parts(const tp_desc* desc, const void* x, const int64_t x_strides[3],
+                           const void* const xm_parts[4], const int64_t part_strides[3], const void* packed_weights,
+                           void* out, void* train_workspace, size_t workspace_bytes, void* stream) {
+    if (!xm_parts) { set_error("tp_forward_train_parts: xm_parts is NULL"); return TP_ERR_INVALID_ARG; }
+    return forward_impl(desc, x, x_strides, nullptr, part_strides, packed_weights, out, train_workspace, workspace_bytes,
+                        stream, nullptr, true, xm_parts);
+}
+
+static int backward_impl(const tp_desc* desc, const void* x_multi, const void* const* xm_parts, const int64_t xm_strides[3],
+                         const tp_weights* raw, const void* packed_weights, const void* train_workspace, const void* dy,
+                         const tp_grads* grads, void* bw_workspace, size_t bw_workspace_bytes, void* stream_) {
     TP_TRY(validate_desc(desc));
+    if (xm_parts) {
+        for (int i = 0; i < 4; ++i) if (!xm_parts[i]) { set_error("tp_backward: x_multi part %d is NULL", i); return TP_ERR_INVALID_ARG; }
+        x_multi = xm_parts[0];
+    }
     if (!x_multi || !xm_strides || !raw || !packed_weights || !train_workspace || !dy || !grads || !bw_workspace) {
         set_error("tp_backward: NULL argument");
         return TP_ERR_INVALID_ARG;
@@ -111,7 +123,6 @@ int tp_backward(const tp_desc* desc, const void* x_multi, const int64_t xm_strid
     const int N = g * g, Gq = g / s, M = Gq * Gq, E = kEmbed;
     const int R = B * N, Rq = B * M;
     const WorkspaceLayout W = workspace_layout(B, g, s, D, true);
-    const PackedLayout P = packed_layout(D);
     const BwLayout L = bw_layout(B, g, s, D);
     if (bw_workspace_bytes < L.total) {
         set_error("tp_backward: workspace %zu B < required %zu B", bw_workspace_bytes, L.total);
@@ -123,7 +134,6 @@ int tp_backward(const tp_desc* desc, const void* x_multi, const int64_t xm_strid
     }
     hipStream_t stream = (hipStream_t)stream_;
     const char* fw = (const char*)train_workspace;
-    const char* pw = (const char*)packed_weights;
     char* bw = (char*)bw_workspace;
     const int Rp = L.Rp, Rqp = L.Rqp;
     float* part = (float*)(bw + L.part);
@@ -262,8 +272,15 @@ int tp_backward(const tp_desc* desc, const void* x_multi, const int64_t xm_strid
     TP_TRY(T(GT, bw + L.dZ1, 2 * E, R, 2 * E, bw + L.dZ1T, Rp, nullptr, nullptr, nullptr, colpart));
     TP_TRY(bw_reduce_many_parts_launch(GT, colpart, 2 * E, Rp / 64, E, grads->k_proj_1_0_bias, stream));
     TP_TRY(bw_reduce_many_parts_launch(GT, colpart + E, 2 * E, Rp / 64, E, grads->v_proj_1_0_bias, stream));
-    TP_TRY(bw_transpose_launch(GT, GT, x_multi, xm_strides[1], N, xm_strides[0], R, kMulti, bw + L.xmT, Rp, Rp, nullptr,
-                               nullptr, nullptr, nullptr, stream));
+    if (xm_parts) {                                     // four [B, N, 1024] sources -> rows part*1024 .. of x_multi^T
+        for (int i = 0; i < 4; ++i)
+            TP_TRY(bw_transpose_launch(GT, GT, xm_parts[i], xm_strides[1], N, xm_strides[0], R, kMulti / 4,
+                                       bw + L.xmT + (size_t)i * (kMulti / 4) * Rp * 2, Rp, Rp, nullptr, nullptr, nullptr,
+                                       nullptr, stream));
+    } else {
+        TP_TRY(bw_transpose_launch(GT, GT, x_multi, xm_strides[1], N, xm_strides[0], R, kMulti, bw + L.xmT, Rp, Rp, nullptr,
+                                   nullptr, nullptr, nullptr, stream));
+    }
     {   // dW0 [2E, 4096] = dZ1^T · x_multi: rows 0..E-1 belong to k_proj_1[0], E..2E-1 to v_proj_1[0]
         const int Nout = 2 * E, Kin = kMulti;
         int S = 2;                                                       // 128 tiles of 256^2 -> 2 splits fill the chip
@@ -276,6 +293,21 @@ int tp_backward(const tp_desc* desc, const void* x_multi, const int64_t xm_strid
                                       grads->v_proj_1_0_weight, stream));
     }
     return TP_OK;
+}
+
+int tp_backward(const tp_desc* desc, const void* x_multi, const int64_t xm_strides[3], const tp_weights* raw,
+                const void* packed_weights, const void* train_workspace, const void* dy, const tp_grads* grads,
+                void* bw_workspace, size_t bw_workspace_bytes, void* stream) {
+    return backward_impl(desc, x_multi, nullptr, xm_strides, raw, packed_weights, train_workspace, dy, grads,
+                         bw_workspace, bw_workspace_bytes, stream);
+}
+
+int tp_backward_parts(const tp_desc* desc, const void* const xm_parts[4], const int64_t part_strides[3],
+                      const tp_weights* raw, const void* packed_weights, const void* train_workspace, const void* dy,
+                      const tp_grads* grads, void* bw_workspace, size_t bw_workspace_bytes, void* stream) {
+    if (!xm_parts) { set_error("tp_backward_parts: xm_parts is NULL"); return TP_ERR_INVALID_ARG; }
+    return backward_impl(desc, nullptr, xm_parts, part_strides, raw, packed_weights, train_workspace, dy, grads,
+                         bw_workspace, bw_workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -39,17 +39,19 @@ class _ProjectFn(torch.autograd.Function):
     ``no_grad`` tower — reference clip_encoder.py:46, train.py:950-953 — and get none)."""
 
     @staticmethod
-    def forward(ctx, module, x, x_multi, *params):
-        out, train_ws, desc = module._launch_forward(x, x_multi, train=True)
-        ctx.module, ctx.desc = module, desc
-        ctx.save_for_backward(x_multi, train_ws, *params)
+    def forward(ctx, module, x, n_parts, *rest):
+        xm, params = rest[:n_parts], rest[n_parts:]          # x_multi: one tensor, or its four sources
+        out, train_ws, desc = module._launch_forward(x, xm[0] if n_parts == 1 else xm, train=True)
+        ctx.module, ctx.desc, ctx.n_parts = module, desc, n_parts
+        ctx.save_for_backward(train_ws, *xm, *params)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        x_multi, train_ws, *params = ctx.saved_tensors
-        grads = ctx.module._launch_backward(ctx.desc, x_multi, train_ws, params, dy)
-        return (None, None, None) + tuple(grads)
+        train_ws, *rest = ctx.saved_tensors
+        xm, params = rest[:ctx.n_parts], rest[ctx.n_parts:]
+        grads = ctx.module._launch_backward(ctx.desc, xm[0] if ctx.n_parts == 1 else xm, train_ws, params, dy)
+        return (None, None, None) + (None,) * ctx.n_parts + tuple(grads)
 
 
 class TokenPacker(nn.Module):
@@ -154,38 +156,58 @@ class TokenPacker(nn.Module):
     def forward(self, x, attn_mask=None, _stage_events=None):
         if attn_mask is not None:
             raise NotImplementedError("attn_mask is always None on the reference path (llava_arch.py:97)")
-        x_multi = x[1]      # multi-level [B, N, 4096]
+        x_multi = x[1]      # multi-level [B, N, 4096] — or its four [B, N, 1024] sources (tokenpacker_amd.tower)
         x = x[0]            # single-level [B, N, 1024]
-        if not (x.is_cuda and x_multi.is_cuda):
+        parts = None
+        if isinstance(x_multi, (list, tuple)):
+            parts = tuple(x_multi)
+            if len(parts) != 4:
+                raise ValueError("x_multi given as parts must be the 4 hidden-state slices (clip_encoder.py:28)")
+            x_multi = parts[0]
+        if not (x.is_cuda and all(t.is_cuda for t in (parts or (x_multi,)))):
             raise RuntimeError("tokenpacker_amd.TokenPacker runs only on an AMD GPU (HIP kernels); "
                                "there is no CPU fallback")
-        if x.dtype not in _DTYPES or x_multi.dtype != x.dtype:
+        if x.dtype not in _DTYPES or any(t.dtype != x.dtype for t in (parts or (x_multi,))):
             raise TypeError(f"supported dtypes: bfloat16 / float16 for both inputs (got {x.dtype}, {x_multi.dtype})")
         N = self.raw_grid * self.raw_grid
-        if x.dim() != 3 or x_multi.dim() != 3 or x.shape[1] != N or x_multi.shape[1] != N \
-                or x.shape[2] != self.embed_dim or x_multi.shape[2] != self.MULTI_LEVEL_DIM \
-                or x.shape[0] != x_multi.shape[0]:
-            raise ValueError(f"expected x [B,{N},{self.embed_dim}] and x_multi [B,{N},{self.MULTI_LEVEL_DIM}], "
-                             f"got {tuple(x.shape)} and {tuple(x_multi.shape)}")
-        if torch.is_grad_enabled() and (x.requires_grad or x_multi.requires_grad):
+        cm = self.MULTI_LEVEL_DIM // 4 if parts else self.MULTI_LEVEL_DIM
+        if x.dim() != 3 or x.shape[1] != N or x.shape[2] != self.embed_dim \
+                or any(t.dim() != 3 or tuple(t.shape) != (x.shape[0], N, cm) for t in (parts or (x_multi,))):
+            raise ValueError(f"expected x [B,{N},{self.embed_dim}] and x_multi [B,{N},{self.MULTI_LEVEL_DIM}] "
+                             f"(or four [B,{N},{self.MULTI_LEVEL_DIM // 4}] parts), "
+                             f"got {tuple(x.shape)} and {[tuple(t.shape) for t in (parts or (x_multi,))]}")
+        if torch.is_grad_enabled() and (x.requires_grad or any(t.requires_grad for t in (parts or (x_multi,)))):
             raise NotImplementedError(
                 "the HIP projector does not differentiate with respect to the CLIP features (the reference's tower is "
                 "frozen and runs under no_grad, clip_encoder.py:46); detach them")
         # the kernels take element strides (tower outputs are [:,1:] slices); only fix layouts they cannot address
         x = self._addressable(x)
-        x_multi = self._addressable(x_multi)
+        if parts:
+            parts = tuple(self._addressable(t) for t in parts)
+            if any(t.stride() != parts[0].stride() for t in parts):       # one stride triple serves all four
+                parts = tuple(t.contiguous() for t in parts)
+            x_multi = parts
+        else:
+            x_multi = self._addressable(x_multi)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             if _stage_events is not None or self.output_fp32:
                 raise NotImplementedError("staged timing / fp32 output are inference-only")
             if not all(p.requires_grad for p in self.parameters()):
                 raise NotImplementedError("training needs requires_grad on ALL projector parameters "
                                           "(the reference trains the whole projector, train.py:952-958)")
-            return _ProjectFn.apply(self, x, x_multi, *self._named_weights())
+            xm = x_multi if parts else (x_multi,)
+            return _ProjectFn.apply(self, x, len(xm), *xm, *self._named_weights())
         return self._launch_forward(x, x_multi, train=False, _stage_events=_stage_events)[0]
 
     # ------------------------------------------------------------------------------------------
     def _launch_forward(self, x, x_multi, train: bool, _stage_events=None):
         B, device = x.shape[0], x.device
+        parts = x_multi if isinstance(x_multi, tuple) else None
+        if parts:
+            if _stage_events is not None:
+                raise NotImplementedError("staged timing takes the concatenated x_multi")
+            part_ptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in parts])
+            part_strides = _capi.strides3(parts[0].stride())
         with torch.cuda.device(device):
             stream_ptr = torch.cuda.current_stream(device).cuda_stream
             lib = _capi.load_library()
@@ -199,17 +221,26 @@ class TokenPacker(nn.Module):
                 if ws_bytes == 0:
                     raise RuntimeError(f"tp_train_workspace_bytes: {_capi.last_error()}")
                 ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)     # lives until backward has run
-                _capi.check(lib.tp_forward_train(ctypes.byref(desc),
-                                                 x.data_ptr(), _capi.strides3(x.stride()),
-                                                 x_multi.data_ptr(), _capi.strides3(x_multi.stride()),
-                                                 packed.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                 stream_ptr), "tp_forward_train")
+                if parts:
+                    _capi.check(lib.tp_forward_train_parts(ctypes.byref(desc), x.data_ptr(), _capi.strides3(x.stride()),
+                                                           part_ptrs, part_strides, packed.data_ptr(), out.data_ptr(),
+                                                           ws.data_ptr(), ws.numel(), stream_ptr), "tp_forward_train_parts")
+                else:
+                    _capi.check(lib.tp_forward_train(ctypes.byref(desc),
+                                                     x.data_ptr(), _capi.strides3(x.stride()),
+                                                     x_multi.data_ptr(), _capi.strides3(x_multi.stride()),
+                                                     packed.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                     stream_ptr), "tp_forward_train")
                 return out, ws, desc
             ws_bytes = lib.tp_workspace_bytes(ctypes.byref(desc))
             if ws_bytes == 0:
                 raise RuntimeError(f"tp_workspace_bytes: {_capi.last_error()}")
             ws = self._workspace(ws_bytes, device, stream_ptr)
-            if _stage_events is None:
+            if parts:
+                _capi.check(lib.tp_forward_parts(ctypes.byref(desc), x.data_ptr(), _capi.strides3(x.stride()),
+                                                 part_ptrs, part_strides, packed.data_ptr(), out.data_ptr(),
+                                                 ws.data_ptr(), ws.numel(), stream_ptr), "tp_forward_parts")
+            elif _stage_events is None:
                 _capi.check(lib.tp_forward(ctypes.byref(desc),
                                            x.data_ptr(), _capi.strides3(x.stride()),
                                            x_multi.data_ptr(), _capi.strides3(x_multi.stride()),
@@ -225,6 +256,9 @@ class TokenPacker(nn.Module):
         return out, ws, desc
 
     def _launch_backward(self, desc, x_multi, train_ws, params, dy):
+        parts = tuple(x_multi) if isinstance(x_multi, (tuple, list)) else None
+        if parts:
+            x_multi = parts[0]
         device = x_multi.device
         with torch.cuda.device(device):
             stream_ptr = torch.cuda.current_stream(device).cuda_stream
@@ -239,9 +273,16 @@ class TokenPacker(nn.Module):
                 raise RuntimeError(f"tp_backward_workspace_bytes: {_capi.last_error()}")
             bw = self._workspace(bw_bytes, device, ("bwd", stream_ptr))
             dy = dy.to(x_multi.dtype).contiguous()
-            _capi.check(lib.tp_backward(ctypes.byref(desc), x_multi.data_ptr(), _capi.strides3(x_multi.stride()),
-                                        ctypes.byref(raw), packed.data_ptr(), train_ws.data_ptr(), dy.data_ptr(),
-                                        ctypes.byref(gptr), bw.data_ptr(), bw.numel(), stream_ptr), "tp_backward")
+            if parts:
+                part_ptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in parts])
+                _capi.check(lib.tp_backward_parts(ctypes.byref(desc), part_ptrs, _capi.strides3(parts[0].stride()),
+                                                  ctypes.byref(raw), packed.data_ptr(), train_ws.data_ptr(), dy.data_ptr(),
+                                                  ctypes.byref(gptr), bw.data_ptr(), bw.numel(), stream_ptr),
+                            "tp_backward_parts")
+            else:
+                _capi.check(lib.tp_backward(ctypes.byref(desc), x_multi.data_ptr(), _capi.strides3(x_multi.stride()),
+                                            ctypes.byref(raw), packed.data_ptr(), train_ws.data_ptr(), dy.data_ptr(),
+                                            ctypes.byref(gptr), bw.data_ptr(), bw.numel(), stream_ptr), "tp_backward")
         return grads
 
     def forward_staged(self, x):
