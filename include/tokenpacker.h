@@ -270,11 +270,16 @@ int64_t tp_hd_rows(int h_block, int w_block, int M);
 int tp_hd_assemble(const tp_hd_image* plan, int n_images, const void* tokens, const void* sep, const void* ret,
                    void* out, int M, int D, int dtype, void* stream);
 
+/* ---- test hook: occupy `workgroups` CUs for ~`microseconds` on `stream` (100 KiB LDS each; `scratch_int`: any
+ * device int).  Stands in for another stream's kernels when the GEMM tile queue is measured (tools/hog_bench.py). */
+int tp_test_occupy_cus(int workgroups, int microseconds, void* scratch_int, void* stream);
+
 /* ---- tuning knobs (benchmarks only; defaults are what tp_forward ships with) ------------------ */
 enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto | 128 | 256                                              */
        TP_TUNE_XCD_SWIZZLE = 1, /* 1 (default) | 0                                                 */
        TP_TUNE_GEMM_KERNEL = 2, /* 256-tile main loop: 0 persistent ping-pong (default) | 1 two-phase
                                    | 2 ping-pong, one tile per workgroup                              */
+       TP_TUNE_DYNAMIC_TILES = 4, /* 1 (default): persistent GEMMs draw tiles from per-XCD queues | 0: static striding */
        TP_TUNE_FOLD_OUT_PROJ = 3, /* 0 (default): out_proj and mlp[0] as two GEMMs | 1: folded (W = Wm0·Wout) */
        TP_TUNE_COUNT_ = 8 };
 int tp_set_tuning(int key, int value);

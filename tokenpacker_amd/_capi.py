@@ -15,7 +15,7 @@ TP_ABI_VERSION = 1
 TP_BF16, TP_F16, TP_F32 = 0, 1, 2
 TP_OK, TP_ERR_INVALID_ARG, TP_ERR_BAD_SCALE, TP_ERR_WORKSPACE, TP_ERR_LAUNCH = 0, -1, -2, -3, -4
 TP_LINEAR_GELU, TP_LINEAR_LN_FOLD, TP_LINEAR_ROW_STATS = 1, 2, 4
-TP_TUNE_GEMM_TILE, TP_TUNE_XCD_SWIZZLE, TP_TUNE_GEMM_KERNEL, TP_TUNE_FOLD_OUT_PROJ = 0, 1, 2, 3
+TP_TUNE_GEMM_TILE, TP_TUNE_XCD_SWIZZLE, TP_TUNE_GEMM_KERNEL, TP_TUNE_FOLD_OUT_PROJ, TP_TUNE_DYNAMIC_TILES = 0, 1, 2, 3, 4
 TP_NUM_STAGES = 10
 STAGE_NAMES = ("point_queries", "kv_layer0_gelu", "kv_layer2_stats", "kv_inproj_lnfold", "q_proj_1_stats",
                "q_inproj_lnfold", "region_attention", "out_proj", "mlp0_gelu", "mlp2")
@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = (
     "tp_pack_weights", "tp_forward", "tp_forward_staged", "tp_point_queries", "tp_region_attention", "tp_linear",
     "tp_ln_finalize", "tp_linear_stats_parts", "tp_set_tuning", "tp_hd_rows", "tp_hd_assemble",
     "tp_train_workspace_bytes", "tp_backward_workspace_bytes", "tp_forward_train", "tp_backward",
-    "tp_forward_parts", "tp_forward_train_parts", "tp_backward_parts",
+    "tp_forward_parts", "tp_forward_train_parts", "tp_backward_parts", "tp_test_occupy_cus",
 )
 
 # state-dict name -> tp_weights field order (include/tokenpacker.h)
@@ -144,6 +144,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.tp_backward_parts.restype = c_int
     lib.tp_backward_parts.argtypes = [POINTER(tp_desc), POINTER(c_void_p), POINTER(c_int64), POINTER(tp_weights), c_void_p,
                                       c_void_p, c_void_p, POINTER(tp_grads), c_void_p, c_size_t, c_void_p]
+    lib.tp_test_occupy_cus.restype = c_int
+    lib.tp_test_occupy_cus.argtypes = [c_int, c_int, c_void_p, c_void_p]
     lib.tp_hd_rows.restype = c_int64
     lib.tp_hd_rows.argtypes = [c_int, c_int, c_int]
     lib.tp_hd_assemble.restype = c_int

@@ -37,7 +37,7 @@ int check_launch(const char* what) {
     return TP_OK;
 }
 
-static std::atomic<int> g_tuning[TP_TUNE_COUNT_] = {{0}, {1}, {0}, {0}, {0}, {0}, {0}, {0}};
+static std::atomic<int> g_tuning[TP_TUNE_COUNT_] = {{0}, {1}, {0}, {0}, {1}, {0}, {0}, {0}};
 int tuning(int key) { return (key >= 0 && key < TP_TUNE_COUNT_) ? g_tuning[key].load() : 0; }
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
@@ -82,6 +82,7 @@ WorkspaceLayout workspace_layout(int B, int grid, int s, int D, bool train) {
     L.o = take(rows_q * E * 2);
     L.a1 = take(rows_q * E * 2);
     L.a2 = take(rows_q * (size_t)D * 2);
+    L.counters = take(4096);
     L.z1 = L.z2 = 0;
     if (train) { L.z1 = take(rows_kv * 2 * E * 2); L.z2 = take(rows_q * (size_t)D * 2); }
     L.total = off;
@@ -244,6 +245,11 @@ int tp_region_attention(const tp_desc* desc, const void* q, const void* k, const
     return region_attention_launch(q, k, v, o, desc->batch, desc->raw_grid, desc->scale_factor, (hipStream_t)stream);
 }
 
+int tp_test_occupy_cus(int workgroups, int microseconds, void* scratch_int, void* stream) {
+    if (workgroups <= 0 || microseconds <= 0 || !scratch_int) { set_error("tp_test_occupy_cus: bad argument"); return TP_ERR_INVALID_ARG; }
+    return occupy_cus_launch(workgroups, microseconds, (int*)scratch_int, (hipStream_t)stream);
+}
+
 int64_t tp_hd_rows(int h_block, int w_block, int M) {
     if (h_block < 1 || w_block < 1 || M < 1) return 0;
     const int64_t n = (int64_t)h_block * w_block;
@@ -347,6 +353,17 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     char* ws = (char*)workspace;
     const long long kvE = (long long)rows_kv * E;      // elements per K/V group slab
 
+    // tile-queue heads of the persistent GEMM launches: 32 ints per launch, zeroed once per forward
+    int* counters = tuning(TP_TUNE_DYNAMIC_TILES) ? (int*)(ws + W.counters) : nullptr;
+    if (counters) {
+        hipError_t e = hipMemsetAsync(counters, 0, 4096, stream);
+        if (e != hipSuccess) { set_error("tp_forward: hipMemsetAsync: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
+    }
+    int launch_no = 0;
+    auto launch = [&](int in_dt, int out_dt, GemmArgs& a) -> int {
+        a.tile_counters = counters ? counters + 32 * launch_no++ : nullptr;
+        return gemm_launch(in_dt, out_dt, a, stream);
+    };
     int stage_idx = 0;
     auto mark = [&]() -> int {
         if (stage_events) {
@@ -371,7 +388,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
             for (int i = 0; i < 4; ++i) a.A_parts[i] = (const char*)xm_parts[i];
             a.k_part = kMulti / 4;
         }
-        TP_TRY(gemm_launch(dt, TP_F16, a, stream));      // raw operands in the io dtype, fp16 activations out
+        TP_TRY(launch(dt, TP_F16, a));      // raw operands in the io dtype, fp16 activations out
     }
     // 3. H2[g] = Hkv[:, g*1024:(g+1)*1024] · W{k,v}2^T + b, and LayerNorm partials of H2
     TP_TRY(mark());
@@ -381,7 +398,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
                                 (const float*)(pw + P.b_kv2), TP_LINEAR_ROW_STATS);
         a.groups = 2; a.a_gs = E * 2; a.w_gs = (long long)E * E * 2; a.c_gs = kvE * 2; a.bias_gs = E;
         a.stats_out = (float*)(ws + W.stats_kv); a.stats_out_gs = (long long)parts_kv * rows_kv * 2;
-        TP_TRY(gemm_launch(TP_F16, TP_F16, a, stream));
+        TP_TRY(launch(TP_F16, TP_F16, a));
     }
     TP_TRY(mark());
     TP_TRY(ln_finalize_launch((const float*)(ws + W.stats_kv), (float*)(ws + W.mr_kv), rows_kv, parts_kv, 2, E,
@@ -393,7 +410,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         a.groups = 2; a.a_gs = kvE * 2; a.w_gs = (long long)E * E * 2; a.c_gs = kvE * 2; a.bias_gs = E;
         a.stats_in = (const float*)(ws + W.mr_kv); a.stats_in_gs = (long long)rows_kv * 2;
         a.colsum = (const float*)(pw + P.c_in_kv); a.colsum_gs = E;
-        TP_TRY(gemm_launch(TP_F16, TP_F16, a, stream));
+        TP_TRY(launch(TP_F16, TP_F16, a));
     }
     TP_TRY(mark());
     // 5. Q1pre = q0 · Wq1^T (no bias), LayerNorm partials
@@ -401,7 +418,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     {
         GemmArgs a = plain_gemm(ws + W.q0, E, pw + P.w_q1, ws + W.q1pre, E, rows_q, E, E, nullptr, TP_LINEAR_ROW_STATS);
         a.stats_out = (float*)(ws + W.stats_q);
-        TP_TRY(gemm_launch(TP_F16, TP_F16, a, stream));
+        TP_TRY(launch(TP_F16, TP_F16, a));
     }
     TP_TRY(mark());
     TP_TRY(ln_finalize_launch((const float*)(ws + W.stats_q), (float*)(ws + W.mr_q), rows_q, parts_q, 1, E,
@@ -412,7 +429,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
                                 (const float*)(pw + P.b_in_q), TP_LINEAR_LN_FOLD);
         a.stats_in = (const float*)(ws + W.mr_q);
         a.colsum = (const float*)(pw + P.c_in_q);
-        TP_TRY(gemm_launch(TP_F16, TP_F16, a, stream));
+        TP_TRY(launch(TP_F16, TP_F16, a));
     }
     TP_TRY(mark());
     // 7. region-to-point attention
@@ -423,7 +440,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     const bool fold = tuning(TP_TUNE_FOLD_OUT_PROJ) != 0 && !train;     // backward needs A1 and the plain weights
     if (!fold) {
         GemmArgs a = plain_gemm(ws + W.o, E, pw + P.w_out, ws + W.a1, E, rows_q, E, E, (const float*)(pw + P.b_out), 0);
-        TP_TRY(gemm_launch(TP_F16, TP_F16, a, stream));
+        TP_TRY(launch(TP_F16, TP_F16, a));
     }
     TP_TRY(mark());
     // 9. mlp[0] + GELU   (on O with W_om = Wm0·Wout when folded)
@@ -431,14 +448,14 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         GemmArgs a = fold ? plain_gemm(ws + W.o, E, pw + P.w_om, ws + W.a2, D, rows_q, D, E, (const float*)(pw + P.b_om), TP_LINEAR_GELU)
                           : plain_gemm(ws + W.a1, E, pw + P.w_m0, ws + W.a2, D, rows_q, D, E, (const float*)(pw + P.b_m0), TP_LINEAR_GELU);
         if (train) { a.flags |= TP_LINEAR_SAVE_PRE; a.C2 = ws + W.z2; }
-        TP_TRY(gemm_launch(TP_F16, TP_F16, a, stream));
+        TP_TRY(launch(TP_F16, TP_F16, a));
     }
     TP_TRY(mark());
     // 10. mlp[2] -> out
     {
         GemmArgs a = plain_gemm(ws + W.a2, D, pw + P.w_m2, out, D, rows_q, D, D, (const float*)(pw + P.b_m2),
                                 0);
-        TP_TRY(gemm_launch(TP_F16, desc->out_dtype, a, stream));
+        TP_TRY(launch(TP_F16, desc->out_dtype, a));
     }
     TP_TRY(mark());
     return TP_OK;

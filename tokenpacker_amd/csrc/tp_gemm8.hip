@@ -61,7 +61,8 @@ constexpr int G8_BUF = 4 * G8_GROUP;               // 64 KiB: one K-tile (G0 | G
 constexpr int G8_RING = 2 * G8_BUF;                // 128 KiB of K-tile buffers
 constexpr int G8_PAR = G8_RING;                    // persistent kernel: bias[256] | colsum[256] | (mean, rstd)[256]  (4 KiB)
 constexpr int G8_RED = G8_RING + 4096;             // persistent kernel: 8 KiB row-statistics scratch
-constexpr int G8_LDS = G8_RING + 4096 + 8192;      // 140 KiB
+constexpr int G8_NEXT = G8_RING + 4096 + 8192;     // persistent kernel: the next tile index drawn from the queue
+constexpr int G8_LDS = G8_RING + 4096 + 8192 + 256;
 constexpr int G8_DEPTH = 3;                        // DMA groups left in flight by the in-loop wait
 
 }  // namespace
@@ -88,6 +89,8 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
     // ---- this workgroup's tile list: L, L + L_step, ... < L_end (indices into the tile_m-major tile order) ----
     const int ntiles = tiles_m * tiles_n, nwg = gridDim.x;
     int L, L_end, L_step;
+    int* queue = nullptr;                               // per-XCD queue head (tiles beyond the first round), or static
+    int queue_base = 0;
     if (ntiles <= nwg) {                               // one tile per workgroup
         L = xcd_swizzle ? xcd_remap(blockIdx.x, nwg) : (int)blockIdx.x;
         L_end = L + 1; L_step = 1;
@@ -95,6 +98,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         const int x = blockIdx.x & 7, q = ntiles >> 3, r = ntiles & 7;
         const int start = x * q + (x < r ? x : r);
         L = start + (blockIdx.x >> 3); L_end = start + q + (x < r ? 1 : 0); L_step = nwg >> 3;
+        if (PERSIST && p.tile_counters) { queue = p.tile_counters + g * 8 + x; queue_base = start + L_step; }
     } else {
         L = blockIdx.x; L_end = ntiles; L_step = nwg;
     }
@@ -333,15 +337,23 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         setup_tile(L);
         prefetch_params();
         issue_prologue();
+        // Tile order inside an XCD's run: the first round is static (workgroup i takes tile i); later tiles are drawn
+        // from a per-XCD queue head, so a workgroup that starts late or shares its CU (a collective's kernels on
+        // another stream) simply draws fewer tiles instead of making the whole launch wait for its static share.
+        // The draw for the tile AFTER this one is issued here, a whole K loop before it is needed.
         while (true) {
+            int drawn = 0;
+            if (queue && tid == 0) drawn = __hip_atomic_fetch_add(queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             publish_params();                               // (hipcc waits for `pf` here)
+            if (queue && tid == 0) *(int*)(smem + G8_NEXT) = drawn;
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // DMA prologue landed, earlier stores retired
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             k_loop();
             // the ring is free now: request the next tile before finishing this one
             const int m0c = m0, n0c = n0, tile_nc = tile_n;
-            const int Ln = L + L_step;
+            int Ln = L + L_step;
+            if (queue) Ln = queue_base + __builtin_amdgcn_readfirstlane(*(const int*)(smem + G8_NEXT));
             const bool has_next = Ln < L_end;               // wave-uniform
             if (has_next) {
                 setup_tile(Ln);

@@ -49,6 +49,7 @@ struct GemmArgs {
     long long ldw_bytes;              // between rows of W (0: K * 2 — a contiguous [N, K] weight)
     const char* A_parts[4];           // K split over 4 source tensors of k_part columns each (NULL: A alone)
     int k_part;
+    int* tile_counters;               // persistent kernel: [groups][8] zeroed ints -> dynamic per-XCD tile queue (NULL: static)
     // per-group strides (bytes for A/W/C, floats for the fp32 side arrays)
     long long a_gs, w_gs, c_gs, bias_gs, stats_in_gs, colsum_gs, stats_out_gs;
     int M, N, K;
@@ -70,6 +71,7 @@ int point_queries_launch(int dtype, const void* x, const int64_t st[3], void* q0
                          int s, hipStream_t stream);
 int region_attention_launch(const void* q, const void* k, const void* v, void* o, int B,
                             int grid, int s, hipStream_t stream);      // fp16 in / fp16 out
+int occupy_cus_launch(int blocks, int usec, int* sink, hipStream_t stream);
 int hd_assemble_launch(const tp_hd_image* plan_dev_or_host, int n_images, const void* tokens, const void* sep,
                        const void* ret, void* out, int M, int D, hipStream_t stream);
 int ln_finalize_launch(const float* parts, float* mean_rstd, long long M, int nparts, int groups, int ln_dim,
@@ -102,6 +104,7 @@ PackedLayout packed_layout(int D);
 
 struct WorkspaceLayout {
     size_t q0, hkv, h2, stats_kv, mr_kv, kv, q1pre, stats_q, mr_q, q, o, a1, a2;
+    size_t counters;              // zeroed once per forward: tile-queue heads of the persistent GEMM launches
     size_t z1, z2;                // training forward only: fp16 pre-GELU activations [B*N, 2048], [B*M, D]
     size_t total;
     int stats_parts_kv, stats_parts_q;

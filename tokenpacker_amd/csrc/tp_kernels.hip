@@ -181,6 +181,29 @@ int region_attention_launch(const void* q, const void* k, const void* v, void* o
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Test hook: keep `blocks` CUs busy for about `usec` microseconds (100 KiB of LDS per workgroup, so none of the
+// path's 140-KiB workgroups fits beside it) — stands in for a collective's kernels on another stream when the
+// tile queue of the persistent GEMM is exercised (tools/hog_bench.py).
+__global__ void __launch_bounds__(256)
+occupy_cus_kernel(long long cycles, int* sink) {
+    extern __shared__ int hog_lds[];
+    const long long t0 = __builtin_readcyclecounter();
+    int acc = 0;
+    while ((long long)__builtin_readcyclecounter() - t0 < cycles) { hog_lds[threadIdx.x] = acc; acc += hog_lds[(threadIdx.x + 1) & 255]; }
+    if (acc == 0x7fffffff) *sink = acc;
+}
+
+int occupy_cus_launch(int blocks, int usec, int* sink, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_cus_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(occupy_cus_kernel, dim3(blocks), dim3(256), 100 * 1024, stream, (long long)usec * 2000, sink);   // s_memtime ticks at the shader clock (~2 GHz)
+    return check_launch("occupy_cus_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------
 // TokenPacker-HD token assembly (llava_arch.py:140-154).  One workgroup per output row of D 16-bit elements,
 // 16 B per lane.  Row r of an image with an h x w grid: the first h*w*(M+1) rows are h*w segments of M crop
 // tokens + 1 separator (',' unless the crop ends its grid row, then '\n'); with more than one crop, M rows of

@@ -30,6 +30,7 @@ struct BwLayout {
     size_t dyT, a2T, dz2, dz2T, a1T, da1, da1T, oT, dO, dQ, dQT, q1T, dq1, dQ1pre, dQ1preT, q0T;
     // fine-token side ([2] = k, v)
     size_t dKV, dKVT, kv1T, dkv1, dH2, dH2T, hkvT, dZ1, dZ1T, xmT;
+    size_t counters;                                  // tile-queue heads of the persistent GEMM launches (zeroed once)
     size_t part, colpart, lnpart;                     // fp32 partials: split-K wgrad, column sums, LN affine grads
     size_t part_bytes;
     size_t total;
@@ -63,6 +64,7 @@ static BwLayout bw_layout(int B, int grid, int s, int D) {
     const size_t cmax = (size_t)D > 2 * E ? (size_t)D : 2 * E;
     L.colpart = take((Rp / 64) * cmax * 4);
     L.lnpart = take((size_t)256 * 2 * E * 4);
+    L.counters = take(64 * 32 * 4);
     L.total = off;
     return L;
 }
@@ -140,6 +142,16 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
     float* colpart = (float*)(bw + L.colpart);
     const long long kvE = (long long)R * E;
 
+    int* counters = tuning(TP_TUNE_DYNAMIC_TILES) ? (int*)(bw + L.counters) : nullptr;
+    if (counters) {
+        hipError_t e = hipMemsetAsync(counters, 0, 64 * 32 * 4, stream);
+        if (e != hipSuccess) { set_error("tp_backward: hipMemsetAsync: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
+    }
+    int launch_no = 0;
+    auto launch = [&](int in_dt, int out_dt, GemmArgs& a) -> int {
+        a.tile_counters = (counters && launch_no < 64 && a.groups <= 4) ? counters + 32 * launch_no++ : nullptr;
+        return gemm_launch(in_dt, out_dt, a, stream);
+    };
     // ---- small helpers ------------------------------------------------------------------------------------
     // transpose (+cast) of a contiguous-row matrix; optional LayerNorm application and column sums
     auto T = [&](int sdt, const void* src, long long ld, int rows, int cols, void* dst, int rpad, const float* mr = nullptr,
@@ -155,7 +167,7 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
                      int flags = 0, const void* Z = nullptr, long long ldz = 0) -> int {
         GemmArgs a = plain_gemm(dY, ldy, WT, dX, ldx, rows, Kin, Nout, nullptr, flags);
         a.Z = (const char*)Z; a.ldz = ldz;
-        return gemm_launch(GT, GT, a, stream);
+        return launch(GT, GT, a);
     };
     // dW[Nout, Kin] = dY^T[Nout, rpad] · X^T[Kin, rpad]^T, split over the token dimension
     auto wgrad = [&](const void* dYT, const void* XT, int Nout, int Kin, int rpad, void* grad_out) -> int {
@@ -167,7 +179,7 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
         a.ldw_bytes = (long long)rpad * 2;
         a.groups = S; a.a_gs = (long long)(rpad / S) * 2; a.w_gs = (long long)(rpad / S) * 2; a.c_gs = (long long)Nout * Kin * 4;
         a.tile = (Nout % 256 == 0 && Kin % 256 == 0) ? 0 : 128;      // auto: 256-tile persistent kernel once S * tiles fills the chip
-        TP_TRY(gemm_launch(GT, TP_F32, a, stream));
+        TP_TRY(launch(GT, TP_F32, a));
         return bw_reduce_parts_launch(GT, part, (long long)Nout * Kin, S, (long long)Nout * Kin, grad_out, stream);
     };
 
@@ -287,7 +299,7 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
         GemmArgs a = plain_gemm(bw + L.dZ1T, Rp, bw + L.xmT, part, Kin, Nout, Kin, Rp / S, nullptr, 0);
         a.ldw_bytes = (long long)Rp * 2;
         a.groups = S; a.a_gs = (long long)(Rp / S) * 2; a.w_gs = (long long)(Rp / S) * 2; a.c_gs = (long long)Nout * Kin * 4;
-        TP_TRY(gemm_launch(GT, TP_F32, a, stream));
+        TP_TRY(launch(GT, TP_F32, a));
         TP_TRY(bw_reduce_parts_launch(GT, part, (long long)Nout * Kin, S, (long long)E * Kin, grads->k_proj_1_0_weight, stream));
         TP_TRY(bw_reduce_parts_launch(GT, part + (size_t)E * Kin, (long long)Nout * Kin, S, (long long)E * Kin,
                                       grads->v_proj_1_0_weight, stream));
