@@ -28,7 +28,8 @@
 //        group's reads retire at its lgkmcnt(0), one barrier before the early group's issue segment).
 //   Schedule: phase p of tile t issues   p=0: G2(t+1)  p=1: G3(t+1)  p=2: G0(t+2)  p=3: G1(t+2)
 //   (re-target distance 3,3,2,3 phases) and waits vmcnt(2*DEPTH), DEPTH = 3: the group issued 3 phases
-//   ago has landed; it is first read 1..2 phases after that.
+//   ago has landed; it is first read 1..2 phases after that.  (DEPTH = 4 is the latest legal placement —
+//   4..5 phases of flight time per group — and measured the same: DMA latency is not what bounds the loop.)
 //
 // PERSISTENT form (default): one workgroup per CU walks a strided list of output tiles.  When the K loop of a
 // tile ends, the DMA prologue of the NEXT tile (6 groups) and the loads of its epilogue parameters are issued
@@ -63,7 +64,8 @@ constexpr int G8_PAR = G8_RING;                    // persistent kernel: bias[25
 constexpr int G8_RED = G8_RING + 4096;             // persistent kernel: 8 KiB row-statistics scratch
 constexpr int G8_NEXT = G8_RING + 4096 + 8192;     // persistent kernel: the next tile index drawn from the queue
 constexpr int G8_LDS = G8_RING + 4096 + 8192 + 256;
-constexpr int G8_DEPTH = 3;                        // DMA groups left in flight by the in-loop wait
+constexpr int G8_DEPTH = 3;                        // DMA groups left in flight by the in-loop wait (3 or 4 are legal;
+                                                   // 4 = the latest legal wait placement measured no faster: r01u)
 
 }  // namespace
 
@@ -253,8 +255,12 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         __builtin_amdgcn_sched_barrier(0);
     };
     using T_ = std::true_type; using F_ = std::false_type;
-    using W6 = std::integral_constant<int, 2 * G8_DEPTH>; using W4 = std::integral_constant<int, 4>;
-    using W2 = std::integral_constant<int, 2>; using W0 = std::integral_constant<int, 0>;
+    // vmcnt left in flight: steady state 2*DEPTH; the tail counts shrink as fewer groups remain to be issued
+    using WS_ = std::integral_constant<int, 2 * G8_DEPTH>;                 // steady
+    using WA_ = std::integral_constant<int, 2 * (G8_DEPTH - 1)>;           // tile nk-2, phase 2
+    using WB_ = std::integral_constant<int, 2 * (G8_DEPTH - 2)>;           // tile nk-2, phase 3
+    using WC_ = std::integral_constant<int, G8_DEPTH == 4 ? 2 : 0>;        // tile nk-1, phase 0
+    using WD_ = std::integral_constant<int, G8_DEPTH == 4 ? 0 : -1>;       // tile nk-1, phase 1
     using WN_ = std::integral_constant<int, -1>;
 
     // The K loop of one output tile.  On entry: the tile's DMA prologue has been issued, G0(0) and G1(0) have
@@ -268,20 +274,20 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         __builtin_amdgcn_sched_barrier(0);
         int t = 0;
         for (; t < nk - 2; ++t) {                           // steady state: every phase issues, 3 groups stay in flight
-            phase(I0{}, T_{}, W6{}, t);
-            phase(I1{}, T_{}, W6{}, t);
-            phase(I2{}, T_{}, W6{}, t);
-            phase(I3{}, T_{}, W6{}, t);
+            phase(I0{}, T_{}, WS_{}, t);
+            phase(I1{}, T_{}, WS_{}, t);
+            phase(I2{}, T_{}, WS_{}, t);
+            phase(I3{}, T_{}, WS_{}, t);
         }
         if (nk >= 2) {                                      // tile nk-2: nothing beyond tile nk-1 to fetch
-            phase(I0{}, T_{}, W6{}, t);
-            phase(I1{}, T_{}, W6{}, t);
-            phase(I2{}, F_{}, W4{}, t);
-            phase(I3{}, F_{}, W2{}, t);
+            phase(I0{}, T_{}, WS_{}, t);
+            phase(I1{}, T_{}, WS_{}, t);
+            phase(I2{}, F_{}, WA_{}, t);
+            phase(I3{}, F_{}, WB_{}, t);
             ++t;
         }
-        phase(I0{}, F_{}, W0{}, t);                         // tile nk-1: drain
-        phase(I1{}, F_{}, WN_{}, t);
+        phase(I0{}, F_{}, WC_{}, t);                        // tile nk-1: drain
+        phase(I1{}, F_{}, WD_{}, t);
         phase(I2{}, F_{}, WN_{}, t);
         phase(I3{}, F_{}, WN_{}, t);
         if (wm == 0) __builtin_amdgcn_s_barrier();         // re-join: equal barrier counts for both halves
