@@ -12,9 +12,10 @@
  * Conventions
  *  - Plain C types only: device pointers, sizes, element strides, an opaque stream handle
  *    (`hipStream_t` passed as `void*`; NULL = the legacy default stream).
- *  - The caller owns every buffer.  The library allocates nothing on the device, keeps no global
- *    mutable state except a thread-local error string and the tuning table of tp_set_tuning().
- *  - Every call only ENQUEUES work on `stream`; it never synchronises the device.
+ *  - The caller owns every buffer.  The library allocates nothing on the device; its only global state is a
+ *    thread-local error string, the tuning table of tp_set_tuning() and, per caller stream, one side stream +
+ *    event pair that tp_forward forks from / joins back into `stream` for the query side of the path.
+ *  - Every call only ENQUEUES work (on `stream` and that side stream); it never synchronises the device.
  *  - Return value: 0 on success, a negative tp_status otherwise; tp_last_error() describes the
  *    failure for the calling thread.  Nothing throws across the ABI.
  *  - All tensors are row-major.  `dtype` is the element type of activations AND weights.
@@ -279,6 +280,7 @@ enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto | 128 | 256                           
        TP_TUNE_XCD_SWIZZLE = 1, /* 1 (default) | 0                                                 */
        TP_TUNE_GEMM_KERNEL = 2, /* 256-tile main loop: 0 persistent ping-pong (default) | 1 two-phase
                                    | 2 ping-pong, one tile per workgroup                              */
+       TP_TUNE_Q_SIDE_STREAM = 5, /* 1 (default): the query side runs on a forked side stream | 0: one stream */
        TP_TUNE_DYNAMIC_TILES = 4, /* 1 (default): persistent GEMMs draw tiles from per-XCD queues | 0: static striding */
        TP_TUNE_FOLD_OUT_PROJ = 3, /* 0 (default): out_proj and mlp[0] as two GEMMs | 1: folded (W = Wm0·Wout) */
        TP_TUNE_COUNT_ = 8 };

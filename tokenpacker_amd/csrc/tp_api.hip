@@ -16,6 +16,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <atomic>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 namespace tp {
 
@@ -37,7 +40,7 @@ int check_launch(const char* what) {
     return TP_OK;
 }
 
-static std::atomic<int> g_tuning[TP_TUNE_COUNT_] = {{0}, {1}, {0}, {0}, {1}, {0}, {0}, {0}};
+static std::atomic<int> g_tuning[TP_TUNE_COUNT_] = {{0}, {1}, {0}, {0}, {1}, {1}, {0}, {0}};
 int tuning(int key) { return (key >= 0 && key < TP_TUNE_COUNT_) ? g_tuning[key].load() : 0; }
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
@@ -322,6 +325,31 @@ int tp_linear(const tp_linear_args* a, void* stream) {
 }  // extern "C"  (forward_impl has C++ linkage: tp_train.hip calls it too)
 
 namespace tp {
+
+// The query side of the path (point queries -> q_proj_1 -> LayerNorm -> q in-projection, ~8 % of a forward) does
+// not depend on the K/V side until the attention kernel.  It is enqueued on a side stream forked from / joined
+// back into the caller's stream with two events, so its small launches fill the tails of the K/V side's
+// persistent GEMMs instead of running alone at 2.25 CU rounds.  One side stream + event pair per caller stream,
+// created on first use (the only state the library keeps besides the tuning table and the error string).
+struct SideCtx { hipStream_t s; hipEvent_t fork, join; };
+static SideCtx* side_ctx_for(hipStream_t main) {
+    static std::mutex mu;
+    static std::vector<std::pair<std::pair<int, hipStream_t>, SideCtx>> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& e : cache)
+        if (e.first.first == dev && e.first.second == main) return &e.second;
+    if (cache.size() >= 64) return nullptr;                 // unbounded stream churn: fall back to one stream
+    SideCtx c{};
+    if (hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    cache.reserve(64);
+    cache.push_back({{dev, main}, c});
+    return &cache.back().second;
+}
+
 int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3], const void* x_multi,
                  const int64_t xm_strides[3], const void* packed_weights, void* out, void* workspace,
                  size_t workspace_bytes, void* stream_, void* const* stage_events, bool train,
@@ -360,10 +388,37 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         if (e != hipSuccess) { set_error("tp_forward: hipMemsetAsync: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
     }
     int launch_no = 0;
-    auto launch = [&](int in_dt, int out_dt, GemmArgs& a) -> int {
+    auto launch = [&](int in_dt, int out_dt, GemmArgs& a, hipStream_t st) -> int {
         a.tile_counters = counters ? counters + 32 * launch_no++ : nullptr;
-        return gemm_launch(in_dt, out_dt, a, stream);
+        return gemm_launch(in_dt, out_dt, a, st);
     };
+    // query side on a side stream (not when the caller wants per-stage events: those need one stream)
+    SideCtx* side = (tuning(TP_TUNE_Q_SIDE_STREAM) && !stage_events) ? side_ctx_for(stream) : nullptr;
+    const int parts_q = gemm_stats_parts(E);
+    auto q_proj = [&](hipStream_t st) -> int {          // 5. Q1pre = q0 · Wq1^T (no bias), LayerNorm partials
+        GemmArgs a = plain_gemm(ws + W.q0, E, pw + P.w_q1, ws + W.q1pre, E, rows_q, E, E, nullptr, TP_LINEAR_ROW_STATS);
+        a.stats_out = (float*)(ws + W.stats_q);
+        return launch(TP_F16, TP_F16, a, st);
+    };
+    auto q_inproj = [&](hipStream_t st) -> int {        // 6. Q = LN(Q1pre) · Winq^T + b
+        TP_TRY(ln_finalize_launch((const float*)(ws + W.stats_q), (float*)(ws + W.mr_q), rows_q, parts_q, 1, E,
+                                  desc->ln_eps, st));
+        GemmArgs a = plain_gemm(ws + W.q1pre, E, pw + P.w_in_q, ws + W.q, E, rows_q, E, E,
+                                (const float*)(pw + P.b_in_q), TP_LINEAR_LN_FOLD);
+        a.stats_in = (const float*)(ws + W.mr_q);
+        a.colsum = (const float*)(pw + P.c_in_q);
+        return launch(TP_F16, TP_F16, a, st);
+    };
+    if (side) {
+        hipError_t e = hipEventRecord(side->fork, stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(side->s, side->fork, 0);
+        if (e != hipSuccess) { set_error("tp_forward: side stream fork: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
+        TP_TRY(point_queries_launch(dt, x, x_strides, ws + W.q0, B, g, s, side->s));
+        TP_TRY(q_proj(side->s));
+        TP_TRY(q_inproj(side->s));
+        e = hipEventRecord(side->join, side->s);
+        if (e != hipSuccess) { set_error("tp_forward: side stream join: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
+    }
     int stage_idx = 0;
     auto mark = [&]() -> int {
         if (stage_events) {
@@ -375,7 +430,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     };
     TP_TRY(mark());
     // 1. coarse point queries
-    TP_TRY(point_queries_launch(dt, x, x_strides, ws + W.q0, B, g, s, stream));
+    if (!side) TP_TRY(point_queries_launch(dt, x, x_strides, ws + W.q0, B, g, s, stream));
 
     TP_TRY(mark());
     // 2. Hkv = GELU(x_multi · [Wk0;Wv0]^T + b): strided A (tower hands over [:,1:] slices)
@@ -388,7 +443,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
             for (int i = 0; i < 4; ++i) a.A_parts[i] = (const char*)xm_parts[i];
             a.k_part = kMulti / 4;
         }
-        TP_TRY(launch(dt, TP_F16, a));      // raw operands in the io dtype, fp16 activations out
+        TP_TRY(launch(dt, TP_F16, a, stream));      // raw operands in the io dtype, fp16 activations out
     }
     // 3. H2[g] = Hkv[:, g*1024:(g+1)*1024] · W{k,v}2^T + b, and LayerNorm partials of H2
     TP_TRY(mark());
@@ -398,7 +453,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
                                 (const float*)(pw + P.b_kv2), TP_LINEAR_ROW_STATS);
         a.groups = 2; a.a_gs = E * 2; a.w_gs = (long long)E * E * 2; a.c_gs = kvE * 2; a.bias_gs = E;
         a.stats_out = (float*)(ws + W.stats_kv); a.stats_out_gs = (long long)parts_kv * rows_kv * 2;
-        TP_TRY(launch(TP_F16, TP_F16, a));
+        TP_TRY(launch(TP_F16, TP_F16, a, stream));
     }
     TP_TRY(mark());
     TP_TRY(ln_finalize_launch((const float*)(ws + W.stats_kv), (float*)(ws + W.mr_kv), rows_kv, parts_kv, 2, E,
@@ -410,28 +465,17 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         a.groups = 2; a.a_gs = kvE * 2; a.w_gs = (long long)E * E * 2; a.c_gs = kvE * 2; a.bias_gs = E;
         a.stats_in = (const float*)(ws + W.mr_kv); a.stats_in_gs = (long long)rows_kv * 2;
         a.colsum = (const float*)(pw + P.c_in_kv); a.colsum_gs = E;
-        TP_TRY(launch(TP_F16, TP_F16, a));
+        TP_TRY(launch(TP_F16, TP_F16, a, stream));
     }
     TP_TRY(mark());
-    // 5. Q1pre = q0 · Wq1^T (no bias), LayerNorm partials
-    const int parts_q = gemm_stats_parts(E);
-    {
-        GemmArgs a = plain_gemm(ws + W.q0, E, pw + P.w_q1, ws + W.q1pre, E, rows_q, E, E, nullptr, TP_LINEAR_ROW_STATS);
-        a.stats_out = (float*)(ws + W.stats_q);
-        TP_TRY(launch(TP_F16, TP_F16, a));
-    }
+    if (!side) TP_TRY(q_proj(stream));
     TP_TRY(mark());
-    TP_TRY(ln_finalize_launch((const float*)(ws + W.stats_q), (float*)(ws + W.mr_q), rows_q, parts_q, 1, E,
-                              desc->ln_eps, stream));
-    // 6. Q = LN(Q1pre) · Winq^T + b
-    {
-        GemmArgs a = plain_gemm(ws + W.q1pre, E, pw + P.w_in_q, ws + W.q, E, rows_q, E, E,
-                                (const float*)(pw + P.b_in_q), TP_LINEAR_LN_FOLD);
-        a.stats_in = (const float*)(ws + W.mr_q);
-        a.colsum = (const float*)(pw + P.c_in_q);
-        TP_TRY(launch(TP_F16, TP_F16, a));
-    }
+    if (!side) TP_TRY(q_inproj(stream));
     TP_TRY(mark());
+    if (side) {
+        hipError_t e = hipStreamWaitEvent(stream, side->join, 0);
+        if (e != hipSuccess) { set_error("tp_forward: side stream join wait: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
+    }
     // 7. region-to-point attention
     TP_TRY(region_attention_launch(ws + W.q, ws + W.kv, ws + W.kv + kvE * 2, ws + W.o, B, g, s, stream));
     TP_TRY(mark());
@@ -440,7 +484,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     const bool fold = tuning(TP_TUNE_FOLD_OUT_PROJ) != 0 && !train;     // backward needs A1 and the plain weights
     if (!fold) {
         GemmArgs a = plain_gemm(ws + W.o, E, pw + P.w_out, ws + W.a1, E, rows_q, E, E, (const float*)(pw + P.b_out), 0);
-        TP_TRY(launch(TP_F16, TP_F16, a));
+        TP_TRY(launch(TP_F16, TP_F16, a, stream));
     }
     TP_TRY(mark());
     // 9. mlp[0] + GELU   (on O with W_om = Wm0·Wout when folded)
@@ -448,14 +492,14 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         GemmArgs a = fold ? plain_gemm(ws + W.o, E, pw + P.w_om, ws + W.a2, D, rows_q, D, E, (const float*)(pw + P.b_om), TP_LINEAR_GELU)
                           : plain_gemm(ws + W.a1, E, pw + P.w_m0, ws + W.a2, D, rows_q, D, E, (const float*)(pw + P.b_m0), TP_LINEAR_GELU);
         if (train) { a.flags |= TP_LINEAR_SAVE_PRE; a.C2 = ws + W.z2; }
-        TP_TRY(launch(TP_F16, TP_F16, a));
+        TP_TRY(launch(TP_F16, TP_F16, a, stream));
     }
     TP_TRY(mark());
     // 10. mlp[2] -> out
     {
         GemmArgs a = plain_gemm(ws + W.a2, D, pw + P.w_m2, out, D, rows_q, D, D, (const float*)(pw + P.b_m2),
                                 0);
-        TP_TRY(launch(TP_F16, desc->out_dtype, a));
+        TP_TRY(launch(TP_F16, desc->out_dtype, a, stream));
     }
     TP_TRY(mark());
     return TP_OK;
