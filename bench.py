@@ -69,6 +69,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     ap.add_argument("--tile", type=int, default=0, help="force GEMM tile (0 auto, 128, 256)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N>1 (nccl = RCCL; gloo only to exercise the N>1 flow on one GPU)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="test aid: every rank uses cuda:0 (with --backend gloo)")
     return ap.parse_args()
 
 
@@ -119,13 +123,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an AMD GPU (no CPU fallback for the product path)")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from tokenpacker_amd import TokenPacker, _capi, shard
 
