@@ -271,6 +271,16 @@ int64_t tp_hd_rows(int h_block, int w_block, int M);
 int tp_hd_assemble(const tp_hd_image* plan, int n_images, const void* tokens, const void* sep, const void* ret,
                    void* out, int M, int D, int dtype, void* stream);
 
+/* ---- TokenPacker-HD image slicing (the step before the CLIP tower) ---------------------------------------------
+ * Replaces the resize / zero-pad / tile code of the data loader and the eval drivers (llava/train/train.py:695-731):
+ * image [3, H, W] fp32 (already normalised) -> crops [h_block*w_block (+1), 3, block, block] fp32: the image resized
+ * (F.interpolate bilinear, align_corners = False) to (h_res, w_res) in the top-left of a zero canvas of
+ * h_block x w_block blocks, cut row-major; with more than one crop, the canvas resized to (hg, wg) and
+ * zero-padded to block x block as the last crop.  The sizes follow the reference's rounding rules
+ * (tokenpacker_amd.hd.slice_plan). */
+int tp_hd_slice(const float* image, int H, int W, int h_block, int w_block, int h_res, int w_res, int hg, int wg,
+                float* crops, int block, void* stream);
+
 /* ---- test hook: occupy `workgroups` CUs for ~`microseconds` on `stream` (100 KiB LDS each; `scratch_int`: any
  * device int).  Stands in for another stream's kernels when the GEMM tile queue is measured (tools/hog_bench.py). */
 int tp_test_occupy_cus(int workgroups, int microseconds, void* scratch_int, void* stream);

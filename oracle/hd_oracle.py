@@ -41,3 +41,37 @@ def assemble_hd_tokens(image_features: torch.Tensor, h_block: Sequence[int], w_b
         out.append(t)
     assert idx == image_features.shape[0]
     return out
+
+
+def slice_image(image: torch.Tensor, h_block: int, w_block: int, block: int = 336) -> torch.Tensor:
+    """The reference's 'slice' pre-processing for ONE normalised image ``[1, 3, h, w]`` with a GIVEN grid
+    (llava/train/train.py:701-731; the grid comes from Image_Patch.calculate, pinned separately): resize
+    (torch's own F.interpolate: the third-party arithmetic of this step), zero-pad, tile, global view."""
+    import torch.nn.functional as F
+    h, w = image.shape[-2:]
+    h_ratio = block * h_block / h
+    w_ratio = block * w_block / w
+    if h_ratio <= w_ratio:
+        w_ = min(block * w_block, round(w * h_ratio))
+        h_ = block * h_block
+    else:
+        w_ = block * w_block
+        h_ = min(block * h_block, round(h * w_ratio))
+    inter = F.interpolate(image, size=(h_, w_), mode="bilinear")
+    canvas = torch.zeros((1, 3, block * h_block, block * w_block), dtype=inter.dtype)
+    canvas[:, :, :h_, :w_] = inter
+    pieces = [canvas[:, :, block * i:block * (i + 1), block * j:block * (j + 1)] for i in range(h_block) for j in range(w_block)]
+    if len(pieces) > 1:
+        h_ratio = block / h
+        w_ratio = block / w
+        if h_ratio <= w_ratio:
+            w_ = min(block, round(w * h_ratio))
+            h_ = block
+        else:
+            w_ = block
+            h_ = min(block, round(h * w_ratio))
+        inter = F.interpolate(canvas, size=(h_, w_), mode="bilinear")       # the CANVAS: train.py:710 re-binds `image`
+        view = torch.zeros((1, 3, block, block), dtype=inter.dtype)
+        view[:, :, :h_, :w_] = inter
+        pieces.append(view)
+    return torch.cat(pieces, dim=0)

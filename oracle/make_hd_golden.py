@@ -53,3 +53,45 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# HD image slicing: golden crops from the reference's OWN data-loader code.  The code sits inside
+# LazySupervisedDataset.__getitem__ (llava/train/train.py:695-731), which cannot be imported here (it needs
+# deepspeed / the llava package), so the 'slice' branch is lifted out of the source TEXT at mint time, wrapped in a
+# function and executed — nothing is copied into this repository.
+def load_reference_slicer():
+    import textwrap
+    import torch.nn.functional as F
+    src = open("/root/reference/llava/train/train.py").read().splitlines()
+    start = next(i for i, l in enumerate(src) if "image_aspect_ratio == 'slice'" in l and l.lstrip().startswith("elif"))
+    end = next(i for i in range(start, len(src)) if "image_tensor = torch.cat(split_images, dim=0)" in src[i])
+    body = textwrap.dedent("\n".join(src[start + 1:end + 1]))
+    body = body.replace("image = self.preprocess(image)\n", "")          # the test image is already normalised
+    code = "def ref_slice(image, self):\n" + textwrap.indent(body, "    ") + "\n    return image_tensor, h_block, w_block\n"
+    ns = {"torch": torch, "F": F}
+    exec(compile(code, "<reference train.py:695-731>", "exec"), ns)
+    return ns["ref_slice"]
+
+
+def mint_slices():
+    import numpy as np
+    ref = load_reference()
+    slicer = load_reference_slicer()
+    holder = types.SimpleNamespace(image_patch=ref.Image_Patch(patch_num=9))
+    cases = [(336, 336), (500, 700), (1088, 1088), (300, 1400), (901, 413), (224, 224)]
+    out = {"sizes": np.array(cases), "stride": np.array(11)}
+    for k, (h, w) in enumerate(cases):
+        g = torch.Generator().manual_seed(1000 + k)
+        img = torch.randn(3, h, w, generator=g)
+        crops, hb, wb = slicer(img.clone(), holder)
+        out[f"grid_{k}"] = np.array([hb, wb])
+        out[f"sub_{k}"] = crops[:, :, ::11, ::11].numpy()
+        out[f"sum_{k}"] = np.array([float(crops.double().sum()), float(crops.double().abs().sum())])
+    path = os.path.join(ROOT, "tests", "golden", "hd_slice.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, {k: tuple(v.shape) for k, v in out.items() if k.startswith("sub_")})
+
+
+if __name__ == "__main__":
+    mint_slices()

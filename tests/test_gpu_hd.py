@@ -36,3 +36,18 @@ def test_assemble_argument_errors():
         hd.assemble_hd_tokens(feats.float(), [1, 1, 1], [1, 1, 1], e, e)
     with pytest.raises(ValueError):
         hd.assemble_hd_tokens(feats, [1, 1, 1], [1, 1, 1], e[:8], e)
+
+
+@pytest.mark.parametrize("h,w", [(336, 336), (500, 700), (1088, 1088), (300, 1400), (901, 413), (224, 224), (37, 2000)])
+def test_slice_image_vs_oracle(h, w):
+    """HIP slicing kernel (tp_hd_slice) vs the oracle's torch-CPU F.interpolate restatement of train.py:695-731.
+    fp32 bilinear taps in the same formula; torch's vectorised CPU kernel contracts a*b + c*d differently, so the
+    bar is a few fp32 ulps of the pixel range rather than bit equality."""
+    img = torch.randn(3, h, w, generator=torch.Generator().manual_seed(h * 7 + w))
+    crops, hb, wb = hd.slice_image(img.cuda())
+    torch.cuda.synchronize()
+    want = hd_oracle.slice_image(img.unsqueeze(0), hb, wb)
+    assert crops.shape == want.shape and crops.dtype == torch.float32
+    err = (crops.cpu() - want).abs().max().item()
+    assert err <= 4e-6 * max(1.0, want.abs().max().item()), err
+    assert torch.equal(crops.cpu() == 0, want == 0)               # identical zero padding

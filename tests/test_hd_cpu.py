@@ -46,3 +46,24 @@ def test_row_count_matches_oracle_and_abi(h, w, M):
 def test_assemble_rejects_cpu_tensors():
     with pytest.raises(RuntimeError):
         hd.assemble_hd_tokens(torch.zeros(1, 4, 8, dtype=torch.bfloat16), [1], [1], torch.zeros(8), torch.zeros(8))
+
+
+def test_slice_oracle_matches_reference_dataloader_code():
+    """oracle.hd_oracle.slice_image against crops produced by the reference's own 'slice' code
+    (train.py:695-731, executed from the source text by oracle/make_hd_golden.py): bit-exact, both sides run
+    torch-CPU F.interpolate.  Also pins hd.slice_plan's grid and sizes."""
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "hd_slice.npz"))
+    stride = int(z["stride"])
+    for k, (h, w) in enumerate(z["sizes"].tolist()):
+        img = torch.randn(3, h, w, generator=torch.Generator().manual_seed(1000 + k))
+        hb, wb = [int(v) for v in z[f"grid_{k}"]]
+        plan = hd.slice_plan(h, w)
+        assert plan[:2] == (hb, wb)
+        crops = hd_oracle.slice_image(img.unsqueeze(0), hb, wb)
+        assert crops.shape[0] == hd.hd_crop_count(hb, wb)
+        assert np.array_equal(crops[:, :, ::stride, ::stride].numpy(), z[f"sub_{k}"])
+        s = z[f"sum_{k}"]
+        assert float(crops.double().sum()) == s[0] and float(crops.double().abs().sum()) == s[1]
+        # the resized extent implied by the plan is where the canvas stops being zero-padded
+        assert plan[2] <= 336 * hb and plan[3] <= 336 * wb and (plan[2] == 336 * hb or plan[3] == 336 * wb)

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = (
     "tp_pack_weights", "tp_forward", "tp_forward_staged", "tp_point_queries", "tp_region_attention", "tp_linear",
     "tp_ln_finalize", "tp_linear_stats_parts", "tp_set_tuning", "tp_hd_rows", "tp_hd_assemble",
     "tp_train_workspace_bytes", "tp_backward_workspace_bytes", "tp_forward_train", "tp_backward",
-    "tp_forward_parts", "tp_forward_train_parts", "tp_backward_parts", "tp_test_occupy_cus",
+    "tp_forward_parts", "tp_forward_train_parts", "tp_backward_parts", "tp_test_occupy_cus", "tp_hd_slice",
 )
 
 # state-dict name -> tp_weights field order (include/tokenpacker.h)
@@ -145,6 +145,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.tp_backward_parts.restype = c_int
     lib.tp_backward_parts.argtypes = [POINTER(tp_desc), POINTER(c_void_p), POINTER(c_int64), POINTER(tp_weights), c_void_p,
                                       c_void_p, c_void_p, POINTER(tp_grads), c_void_p, c_size_t, c_void_p]
+    lib.tp_hd_slice.restype = c_int
+    lib.tp_hd_slice.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]
     lib.tp_test_occupy_cus.restype = c_int
     lib.tp_test_occupy_cus.argtypes = [c_int, c_int, c_void_p, c_void_p]
     lib.tp_hd_rows.restype = c_int64

@@ -248,6 +248,16 @@ int tp_region_attention(const tp_desc* desc, const void* q, const void* k, const
     return region_attention_launch(q, k, v, o, desc->batch, desc->raw_grid, desc->scale_factor, (hipStream_t)stream);
 }
 
+int tp_hd_slice(const float* image, int H, int W, int h_block, int w_block, int h_res, int w_res, int hg, int wg,
+                float* crops, int block, void* stream) {
+    if (!image || !crops || H <= 0 || W <= 0 || h_block < 1 || w_block < 1 || block <= 0 || h_res <= 0 || w_res <= 0 ||
+        h_res > h_block * block || w_res > w_block * block || (h_block * w_block > 1 && (hg <= 0 || wg <= 0 || hg > block || wg > block))) {
+        set_error("tp_hd_slice: invalid argument");
+        return TP_ERR_INVALID_ARG;
+    }
+    return hd_slice_launch(image, H, W, h_block, w_block, h_res, w_res, hg, wg, crops, block, (hipStream_t)stream);
+}
+
 int tp_test_occupy_cus(int workgroups, int microseconds, void* scratch_int, void* stream) {
     if (workgroups <= 0 || microseconds <= 0 || !scratch_int) { set_error("tp_test_occupy_cus: bad argument"); return TP_ERR_INVALID_ARG; }
     return occupy_cus_launch(workgroups, microseconds, (int*)scratch_int, (hipStream_t)stream);

@@ -71,6 +71,8 @@ int point_queries_launch(int dtype, const void* x, const int64_t st[3], void* q0
                          int s, hipStream_t stream);
 int region_attention_launch(const void* q, const void* k, const void* v, void* o, int B,
                             int grid, int s, hipStream_t stream);      // fp16 in / fp16 out
+int hd_slice_launch(const float* img, int H, int W, int h_block, int w_block, int h_res, int w_res, int hg, int wg,
+                    float* crops, int block, hipStream_t stream);
 int occupy_cus_launch(int blocks, int usec, int* sink, hipStream_t stream);
 int hd_assemble_launch(const tp_hd_image* plan_dev_or_host, int n_images, const void* tokens, const void* sep,
                        const void* ret, void* out, int M, int D, hipStream_t stream);

@@ -252,6 +252,80 @@ int hd_assemble_launch(const tp_hd_image* plan, int n_images, const void* tokens
 }
 
 // ---------------------------------------------------------------------------------------------------
+// TokenPacker-HD image slicing (reference llava/train/train.py:695-731, duplicated in the eval drivers): the
+// normalised image [3, H, W] is resized (bilinear, align_corners = False, no antialias — F.interpolate's
+// arithmetic: src = scale (dst + 0.5) - 0.5 clamped at 0, scale = in / out in fp32) to (h_res, w_res), placed
+// in the top-left corner of a zero canvas of h_block x w_block blocks of `block` pixels, and the canvas is cut
+// into crops (row-major).  With more than one crop a global view follows: the CANVAS (padding included — the
+// reference re-uses the variable, train.py:710,728) resized to (hg, wg) and zero-padded to block x block.
+// One thread per output pixel; crops [n, 3, block, block] fp32.
+__device__ __forceinline__ void bilinear_taps(float scale, int dst, int in_size, int& i0, int& i1, float& l0, float& l1) {
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;
+    i0 = i0 < in_size - 1 ? i0 : in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+    l1 = fminf(fmaxf(l1, 0.f), 1.f);
+    l0 = 1.f - l1;
+}
+
+__global__ void __launch_bounds__(256)
+hd_slice_crops_kernel(const float* __restrict__ img, int H, int W, int h_block, int w_block, int h_res, int w_res,
+                      float* __restrict__ crops, int block) {
+    const long long total = (long long)h_block * w_block * 3 * block * block;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int px = (int)(idx % block), py = (int)(idx / block % block), ch = (int)(idx / ((long long)block * block) % 3);
+    const int crop = (int)(idx / ((long long)block * block * 3));
+    const int Y = (crop / w_block) * block + py, X = (crop % w_block) * block + px;
+    float v = 0.f;
+    if (Y < h_res && X < w_res) {
+        int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+        bilinear_taps((float)H / (float)h_res, Y, H, y0, y1, ly0, ly1);
+        bilinear_taps((float)W / (float)w_res, X, W, x0, x1, lx0, lx1);
+        const float* c = img + (long long)ch * H * W;
+        v = ly0 * (lx0 * c[(long long)y0 * W + x0] + lx1 * c[(long long)y0 * W + x1]) +
+            ly1 * (lx0 * c[(long long)y1 * W + x0] + lx1 * c[(long long)y1 * W + x1]);
+    }
+    crops[idx] = v;
+}
+
+__global__ void __launch_bounds__(256)
+hd_slice_global_kernel(float* __restrict__ crops, int h_block, int w_block, int hg, int wg, int block) {
+    const long long total = (long long)3 * block * block;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int px = (int)(idx % block), py = (int)(idx / block % block), ch = (int)(idx / ((long long)block * block));
+    const int CH = h_block * block, CW = w_block * block;
+    auto canvas = [&](int Y, int X) -> float {          // the canvas as laid out in the crops just written
+        const int crop = (Y / block) * w_block + X / block;
+        return crops[(((long long)crop * 3 + ch) * block + Y % block) * block + X % block];
+    };
+    float v = 0.f;
+    if (py < hg && px < wg) {
+        int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+        bilinear_taps((float)CH / (float)hg, py, CH, y0, y1, ly0, ly1);
+        bilinear_taps((float)CW / (float)wg, px, CW, x0, x1, lx0, lx1);
+        v = ly0 * (lx0 * canvas(y0, x0) + lx1 * canvas(y0, x1)) + ly1 * (lx0 * canvas(y1, x0) + lx1 * canvas(y1, x1));
+    }
+    crops[((long long)h_block * w_block * 3) * block * block + idx] = v;
+}
+
+int hd_slice_launch(const float* img, int H, int W, int h_block, int w_block, int h_res, int w_res, int hg, int wg,
+                    float* crops, int block, hipStream_t stream) {
+    const long long total = (long long)h_block * w_block * 3 * block * block;
+    hipLaunchKernelGGL(hd_slice_crops_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, img, H, W,
+                       h_block, w_block, h_res, w_res, crops, block);
+    int rc = check_launch("hd_slice_crops_kernel");
+    if (rc != TP_OK || h_block * w_block <= 1) return rc;
+    const long long gtotal = (long long)3 * block * block;
+    hipLaunchKernelGGL(hd_slice_global_kernel, dim3((unsigned)((gtotal + 255) / 256)), dim3(256), 0, stream, crops,
+                       h_block, w_block, hg, wg, block);
+    return check_launch("hd_slice_global_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------
 // LayerNorm statistics: the producing GEMM leaves one (sum, sumsq) slab per 128 output columns
 // ([parts][M][2]); this turns them into per-row (mean, rstd) for the consuming GEMM's epilogue.
 // The slabs are summed in slab order -> deterministic.  ~10 MB of traffic at B=256: noise.

@@ -49,6 +49,45 @@ def select_grid(h: int, w: int, patch_num: int = 9, image_size: int = 336) -> Tu
     return grids[int(torch.argmax(score))]
 
 
+def slice_plan(h: int, w: int, patch_num: int = 9, block: int = 336):
+    """Sizes of the reference's HD slicing for an ``h x w`` image (train.py:699-708, 720-727):
+    ``(h_block, w_block, h_res, w_res, hg, wg)`` — the grid, the size the image is resized to inside the
+    ``h_block x w_block`` canvas (aspect preserved, Python ``round`` = half-to-even), and the size of the global
+    view inside its single block (``0, 0`` when there is only one crop)."""
+    hb, wb = select_grid(h, w, patch_num, block)
+
+    def fit(bh, bw):
+        h_ratio, w_ratio = bh / h, bw / w
+        if h_ratio <= w_ratio:
+            return bh, min(bw, round(w * h_ratio))
+        return min(bh, round(h * w_ratio)), bw
+    h_res, w_res = fit(block * hb, block * wb)
+    hg, wg = fit(block, block) if hb * wb > 1 else (0, 0)
+    return hb, wb, h_res, w_res, hg, wg
+
+
+def slice_image(image: torch.Tensor, patch_num: int = 9, block: int = 336):
+    """``image [3, H, W]`` fp32 on the GPU (normalised pixels) -> ``(crops [n, 3, block, block] fp32, h_block,
+    w_block)`` exactly as the reference's data loader builds ``image_tensor`` in ``'slice'`` mode
+    (train.py:695-731): resize + zero-pad + tile, plus the global view when there is more than one crop."""
+    if not image.is_cuda:
+        raise RuntimeError("slice_image runs only on an AMD GPU (HIP kernel); there is no CPU fallback")
+    if image.dim() == 4 and image.shape[0] == 1:
+        image = image[0]
+    if image.dim() != 3 or image.shape[0] != 3 or image.dtype != torch.float32:
+        raise ValueError("image must be a float32 [3, H, W] tensor")
+    image = image.contiguous()
+    H, W = int(image.shape[1]), int(image.shape[2])
+    hb, wb, h_res, w_res, hg, wg = slice_plan(H, W, patch_num, block)
+    n = hd_crop_count(hb, wb)
+    crops = torch.empty(n, 3, block, block, dtype=torch.float32, device=image.device)
+    lib = _capi.load_library()
+    with torch.cuda.device(image.device):
+        _capi.check(lib.tp_hd_slice(image.data_ptr(), H, W, hb, wb, h_res, w_res, hg, wg, crops.data_ptr(), block,
+                                    torch.cuda.current_stream(image.device).cuda_stream), "tp_hd_slice")
+    return crops, hb, wb
+
+
 def hd_token_rows(h_block: int, w_block: int, num_queries: int) -> int:
     """Rows of one image's visual-token block: ``h*w`` crops of ``M`` tokens, a separator after every crop
     (',' inside a row, '\\n' at its end), and — when there is more than one crop — the global view + '\\n'."""
