@@ -13,7 +13,7 @@ from tokenpacker_amd import TokenPacker, build_vision_projector, synth
 
 pytestmark = pytest.mark.gpu
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "s[0-9]_D*.npz")))
 IDS = [os.path.basename(p)[:-4] for p in GOLDEN]
 
 # Gates.  Metric: max|y - y_ref| / max|y_ref|, y_ref = exact (fp64) math on the SAME

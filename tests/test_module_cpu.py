@@ -70,7 +70,7 @@ def test_product_never_imports_the_oracle():
 
 
 def test_golden_param_digests_are_reproducible():
-    for path in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")):
+    for path in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "s[0-9]_D*.npz")):
         z = np.load(path)
         p = synth.make_params(int(z["param_seed"]), int(z["hidden_size"]))
         assert synth.tensor_digest(*p.values()) == str(z["params_sha256"])

@@ -10,7 +10,7 @@ import torch
 from oracle import tokenpacker_oracle as orc
 from tokenpacker_amd import synth
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "s[0-9]_D*.npz")))
 
 
 def _load(path):
