@@ -78,3 +78,33 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     monkeypatch.setattr(_capi, "_lib", None)
     with pytest.raises(_capi.TokenPackerLibraryError, match="no CPU fallback"):
         _capi.load_library(str(tmp_path / "libtokenpacker_hip.so"))
+
+
+def test_train_hd_and_parts_entry_points_reject_bad_arguments():
+    """The round's newer entry points validate before they touch the device, like tp_forward does."""
+    lib = _capi.load_library()
+    d = _capi.make_desc(1, 24, 2, 256, _capi.TP_BF16)
+    st = _capi.strides3((576 * 1024, 1024, 1))
+    E = _capi.TP_ERR_INVALID_ARG
+    assert lib.tp_forward_train(ctypes.byref(d), None, st, None, st, None, None, None, 0, None) == E
+    assert lib.tp_forward_parts(ctypes.byref(d), None, st, None, st, None, None, None, 0, None) == E
+    assert lib.tp_forward_train_parts(ctypes.byref(d), None, st, None, st, None, None, None, 0, None) == E
+    assert lib.tp_backward(ctypes.byref(d), None, st, None, None, None, None, None, None, 0, None) == E
+    assert lib.tp_backward_parts(ctypes.byref(d), None, st, None, None, None, None, None, None, 0, None) == E
+    assert _capi.last_error()
+    # sizes: the training workspace extends the inference one by the two pre-GELU buffers
+    ws, tws, bws = (f(ctypes.byref(d)) for f in (lib.tp_workspace_bytes, lib.tp_train_workspace_bytes,
+                                                 lib.tp_backward_workspace_bytes))
+    assert 0 < ws < tws and bws > 0
+    bad = _capi.make_desc(1, 24, 5, 256, _capi.TP_BF16)
+    assert lib.tp_train_workspace_bytes(ctypes.byref(bad)) == 0
+    assert lib.tp_backward_workspace_bytes(ctypes.byref(bad)) == 0
+    # HD helpers
+    assert lib.tp_hd_rows(1, 1, 144) == 145            # one crop: its tokens + '\n', no global view
+    assert lib.tp_hd_rows(2, 3, 144) == (6 * 144 + 6) + 145
+    assert lib.tp_hd_assemble(None, 1, None, None, None, None, 144, 256, _capi.TP_BF16, None) == E
+    plan = (_capi.tp_hd_image * 1)(_capi.tp_hd_image(0, 1, 1, 0, 0))
+    assert lib.tp_hd_assemble(plan, 0, None, None, None, None, 144, 256, _capi.TP_BF16, None) in (E, _capi.TP_OK)
+    assert lib.tp_hd_assemble(plan, 1, None, None, None, None, 144, 256, _capi.TP_BF16, None) == E
+    assert lib.tp_hd_slice(None, 100, 100, 1, 1, 336, 336, 0, 0, None, 336, None) == E
+    assert lib.tp_test_occupy_cus(0, 1, None, None) == E
