@@ -198,12 +198,35 @@ def main():
             for i in range(_capi.TP_NUM_STAGES):
                 stage_ms[i] += evs[i].elapsed_time(evs[i + 1]) / n_prof
 
+        # N>1 diagnostics, outside the timed region: the same shard without the gather (what DDP training sees) and
+        # the gather alone on a fixed shard, so the scaling numbers can be split into compute and xGMI time
+        extra = {}
+        if gather:
+            n_x = min(max(args.steps, 3), 10)
+            y_loc = model((x, xm))
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(n_x):
+                y_loc = model((x, xm))
+            fence()
+            extra["forward_only_ms"] = 1e3 * (time.perf_counter() - t1) / n_x
+            gp = pipe if pipe is not None else shard.TokenGatherPipeline(total, depth=2)
+            gp.submit(y_loc)
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(n_x):
+                gp.submit(y_loc)
+            gp.drain()
+            fence()
+            extra["gather_only_ms"] = 1e3 * (time.perf_counter() - t1) / n_x
+
     assert y.shape == ((total if gather else B), M, D) and torch.isfinite(y[:2].float()).all()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed, extra.get("forward_only_ms", 0.0), extra.get("gather_only_ms", 0.0)],
+                     dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = float(t[0].item())
     ms_per_step = 1e3 * elapsed / args.steps
     images_per_s = total * args.steps / elapsed
 
@@ -252,6 +275,12 @@ def main():
                          "algorithmic_bytes": float(B * 576 * 4096 * 2 + 2048 * 4096 * 2 + B * 576 * 2048 * 2)},
             "stages_ms": {n: round(v, 4) for n, v in zip(_capi.STAGE_NAMES, stage_ms)},
         }
+        if gather:
+            # max over ranks; gather_only moves (N-1)/N of [total, M, D] into every rank per step
+            out["multi_gpu"] = {"forward_only_ms": round(float(t[1].item()), 4),
+                                "forward_only_images_per_s": round(total / (float(t[1].item()) * 1e-3), 1),
+                                "gather_only_ms": round(float(t[2].item()), 4),
+                                "gather_bytes_received_per_rank": int((world - 1) * B * M * D * y.element_size())}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, s, D)
         print(json.dumps(out), flush=True)

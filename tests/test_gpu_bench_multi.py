@@ -33,3 +33,8 @@ def test_two_rank_bench_line(extra):
     assert d["value"] > 0 and abs(d["value"] - 8 * 3 / (d["ms_per_step"] * 3 * 1e-3)) / d["value"] < 1e-3
     assert ("all_gather" in d["config"]["parallelism"]) == ("--no-gather" not in extra)
     assert "roofline" in d and "cpu_baseline" not in d
+    assert ("multi_gpu" in d) == ("--no-gather" not in extra)
+    if "multi_gpu" in d:
+        mg = d["multi_gpu"]
+        assert mg["forward_only_ms"] > 0 and mg["gather_only_ms"] > 0
+        assert mg["gather_bytes_received_per_rank"] == 4 * 144 * 4096 * 2
