@@ -28,6 +28,9 @@ fi
 if has gemm; then
   echo "== gemm bench =="; timeout 600 python tools/gemm_bench.py --out $OUT/gemm_bench.json > $OUT/gemm_bench.log 2>&1; echo "exit $?"; tail -30 $OUT/gemm_bench.log
 fi
+if has kfit; then
+  echo "== per-tile fixed cost fit =="; timeout 600 python tools/ktile_fit.py > $OUT/ktile_fit.txt 2>&1; echo "exit $?"; cat $OUT/ktile_fit.txt
+fi
 if has bench; then
   echo "== bench =="; timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; cat $OUT/bench.json; tail -5 $OUT/bench.err
 fi
