@@ -220,6 +220,14 @@ int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stre
         set_error("tp gemm: unsupported shape M=%d N=%d K=%d (need N%%128==0, K%%64==0)", a.M, a.N, a.K);
         return TP_ERR_INVALID_ARG;
     }
+    {   // the epilogue stores through a 32-bit-ranged buffer descriptor (tp_gemm_common.h)
+        const long long out_bytes = (long long)a.M * a.ldc * (out_dtype == TP_F32 ? 4 : 2);
+        if (out_bytes >= (1ll << 32)) {
+            set_error("tp gemm: output of %lld bytes per group exceeds the 4 GiB a single launch can address "
+                      "(M=%d ldc=%lld): split the rows over several calls", out_bytes, a.M, (long long)a.ldc);
+            return TP_ERR_INVALID_ARG;
+        }
+    }
     if ((a.flags & TP_LINEAR_ROW_STATS) && out_dtype == TP_F32) {
         set_error("tp gemm: ROW_STATS with fp32 output is not supported");
         return TP_ERR_INVALID_ARG;

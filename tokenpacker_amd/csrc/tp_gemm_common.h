@@ -95,6 +95,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
     const float* __restrict__ bias = p.bias ? p.bias + g * p.bias_gs : nullptr;
     const float* __restrict__ colsum = p.colsum ? p.colsum + g * p.colsum_gs : nullptr;
     char* __restrict__ Cg = p.C + g * p.c_gs;
+    // The output goes out through a buffer descriptor that ends after row M - 1: rows past the end are dropped by
+    // the hardware range check, so every wave issues the SAME number of store instructions for every tile (the
+    // persistent kernel's counted s_waitcnt at the tile seam relies on that) and no branch guards the stores.
+    const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)Cg, 0, (int)(unsigned)((long long)p.M * p.ldc * (long long)sizeof(TO)), 0x00020000);
 
     f32x4 bias_v[FN], csum_v[FN];
     if constexpr (LDS_PARAMS) {
@@ -163,16 +168,14 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { v0[r] = gelu_erf(v0[r]); v1[r] = gelu_erf(v1[r]); }
                 }
-                const long long coff = (long long)m * p.ldc + col_base;
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                 if constexpr (OUT_F32) {
-                    if (row_ok) {
-                        *(f32x4*)((float*)Cg + coff + j0 * 16) = v0;
-                        *(f32x4*)((float*)Cg + coff + j1 * 16) = v1;
-                    }
+                    const unsigned coff = (unsigned)(((long long)m * p.ldc + col_base) * 4);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), rsrc_c, (int)(coff + j0 * 64), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), rsrc_c, (int)(coff + j1 * 64), 0, 0);
                 } else {
                     using O4 = typename Vec<TO>::x4;
                     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                     if constexpr (std::is_same<TO, f16_t>::value) {     // saturate instead of producing inf
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -196,7 +199,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
                     // odd rows columns (g-1)*4 .. (g-1)*4+7 of fragment j1 (lower neighbour's | own)
                     const int gq = lane >> 4;
                     const int col = n0 + wn * WN + (j0 + (gq & 1)) * 16 + (gq >> 1) * 8;
-                    if (row_ok) *(u32x4*)((TO*)Cg + (long long)m * p.ldc + col) = u32x4{sx[0], sy[0], sx[1], sy[1]};
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{sx[0], sy[0], sx[1], sy[1]}, rsrc_c,
+                                                           (int)(unsigned)(((long long)m * p.ldc + col) * (long long)sizeof(TO)), 0, 0);
                 }
                 if constexpr (OUT_F32) {
                     if (flags & TP_LINEAR_ROW_STATS) {                  // (rejected by gemm_launch; kept for completeness)

@@ -15,7 +15,7 @@ G, S, F = _capi.TP_LINEAR_GELU, _capi.TP_LINEAR_ROW_STATS, _capi.TP_LINEAR_LN_FO
 
 
 def main():
-    lib = _capi.load_library()
+    lib = _capi.load_library(sys.argv[1]) if len(sys.argv) > 1 else _capi.load_library()   # (a probe build)
     st = torch.cuda.current_stream().cuda_stream
     M, N = 147456, 1024
     KS = (256, 512, 1024, 2048, 4096)
