@@ -222,7 +222,8 @@ int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stre
     }
     {   // the epilogue stores through a 32-bit-ranged buffer descriptor (tp_gemm_common.h)
         const long long out_bytes = (long long)a.M * a.ldc * (out_dtype == TP_F32 ? 4 : 2);
-        if (out_bytes >= (1ll << 32)) {
+        // (+ one tile of rows: the offsets of the dropped rows past M must not wrap around 32 bits either)
+        if ((long long)(a.M + 256) * a.ldc * (out_dtype == TP_F32 ? 4 : 2) >= (1ll << 32)) {
             set_error("tp gemm: output of %lld bytes per group exceeds the 4 GiB a single launch can address "
                       "(M=%d ldc=%lld): split the rows over several calls", out_bytes, a.M, (long long)a.ldc);
             return TP_ERR_INVALID_ARG;

@@ -15,7 +15,9 @@ G, S, F = _capi.TP_LINEAR_GELU, _capi.TP_LINEAR_ROW_STATS, _capi.TP_LINEAR_LN_FO
 
 
 def main():
-    lib = _capi.load_library(sys.argv[1]) if len(sys.argv) > 1 else _capi.load_library()   # (a probe build)
+    args = dict(a.split("=", 1) for a in sys.argv[1:])           # lib=<path to a probe build> for A/B runs on one box
+    lib = _capi.load_library(args["lib"]) if "lib" in args else _capi.load_library()
+    print("args", args)
     st = torch.cuda.current_stream().cuda_stream
     M, N = 147456, 1024
     KS = (256, 512, 1024, 2048, 4096)
