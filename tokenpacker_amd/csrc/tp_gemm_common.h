@@ -22,11 +22,11 @@ template <> struct Mma<f16_t> {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
-// erf-form GELU (nn.GELU() default).  erf by Abramowitz–Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32
-// round-off class next to the 1.0 it is added to): 1 rcp + 1 exp + ~12 FMA-class ops per element instead
-// of ocml erff's ~45 with divergent branches — the epilogue runs with the matrix pipe idle, so its VALU
-// time is pure cost (measured: ~0.1 ms per GELU layer at B=256 with erff).
-// d/dv of the erf-form GELU:  Phi(v) + v phi(v)
+// erf-form GELU (nn.GELU() default) by Abramowitz–Stegun rational forms (|abs err| <= 1.5e-7 / 3e-7, i.e. fp32
+// round-off class next to the 1.0 it is added to) instead of ocml erff's ~45 ops with divergent branches — the
+// epilogue runs with the matrix pipe idle, so its VALU time is pure cost (measured: ~0.1 ms per GELU layer at
+// B=256 with erff; 5.5 us per 256x256 tile with 7.1.26, profiles/r01w_ktile_fit.txt).
+// d/dv of the erf-form GELU:  Phi(v) + v phi(v)   (7.1.26: the exp(-v^2/2) it needs is shared with the pdf term)
 __device__ __forceinline__ float gelu_erf_grad(float v) {
     const float x = fabsf(v) * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
@@ -42,17 +42,39 @@ __device__ __forceinline__ float gelu_erf_grad(float v) {
 }
 
 __device__ __forceinline__ float gelu_erf(float v) {
+    // Abramowitz & Stegun 7.1.28:  erf(x) = 1 - (1 + a1 x + ... + a6 x^6)^-16,  |err| <= 3e-7 — one transcendental
+    // (v_rcp_f32) per element instead of the rcp + exp of 7.1.26, and the Horner chain and the four squarings pack
+    // two elements per v_pk_* instruction.  Overflow of the 16th power gives rcp(inf) = 0, i.e. erf = 1.
     const float x = fabsf(v) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    poly *= t;
-    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);      // exp(-x^2)
-    const float erf_abs = fmaf(-poly, e, 1.0f);                                  // erf(|v|/sqrt2)
-    const float half_v = 0.5f * v;
-    return fmaf(half_v, copysignf(erf_abs, v), half_v);                          // 0.5 v (1 + erf)
+    float p = fmaf(0.0000430638f, x, 0.0002765672f);
+    p = fmaf(p, x, 0.0001520143f);
+    p = fmaf(p, x, 0.0092705272f);
+    p = fmaf(p, x, 0.0422820123f);
+    p = fmaf(p, x, 0.0705230784f);
+    p = fmaf(p, x, 1.0f);
+    p *= p; p *= p; p *= p; p *= p;
+    const float r = __builtin_amdgcn_rcpf(p);                                    // 1 - erf(|v|/sqrt2)
+    return fmaf(-0.5f * fabsf(v), r, fmaxf(v, 0.0f));                            // 0.5 v (1 + erf(v/sqrt2))
+}
+
+// the same on two elements at once, written on 2-vectors so that hipcc emits v_pk_fma_f32 / v_pk_mul_f32 (two
+// elements per instruction at the scalar instruction's issue cost) for the Horner chain and the squarings
+typedef float f32x2_ev __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_ev gelu_erf2(f32x2_ev v) {
+    const f32x2_ev av = __builtin_elementwise_abs(v);
+    const f32x2_ev x = av * 0.70710678118654752440f;
+    f32x2_ev p = __builtin_elementwise_fma(x, (f32x2_ev)(0.0000430638f), (f32x2_ev)(0.0002765672f));
+    p = __builtin_elementwise_fma(p, x, (f32x2_ev)(0.0001520143f));
+    p = __builtin_elementwise_fma(p, x, (f32x2_ev)(0.0092705272f));
+    p = __builtin_elementwise_fma(p, x, (f32x2_ev)(0.0422820123f));
+    p = __builtin_elementwise_fma(p, x, (f32x2_ev)(0.0705230784f));
+    p = __builtin_elementwise_fma(p, x, (f32x2_ev)(1.0f));
+    p *= p; p *= p; p *= p; p *= p;
+    f32x2_ev r;
+    r[0] = __builtin_amdgcn_rcpf(p[0]); r[1] = __builtin_amdgcn_rcpf(p[1]);
+    // 0.5 v (1 + erf(v/sqrt2)) = relu(v) - 0.5 |v| (1 - erf(|v|/sqrt2)):  no cancellation in the negative tail
+    // (relu as 0.5 (v + |v|): exact, and packed — fmaxf would cost a canonicalising v_max_f32 besides the max)
+    return __builtin_elementwise_fma(av * -0.5f, r, (v + av) * 0.5f);
 }
 
 constexpr int BK = 64;             // K-slab in elements
@@ -166,7 +188,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
                 }
                 if (flags & TP_LINEAR_GELU) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { v0[r] = gelu_erf(v0[r]); v1[r] = gelu_erf(v1[r]); }
+                    for (int r = 0; r < 4; r += 2) {
+                        const f32x2_ev g0 = gelu_erf2(f32x2_ev{v0[r], v0[r + 1]}), g1 = gelu_erf2(f32x2_ev{v1[r], v1[r + 1]});
+                        v0[r] = g0[0]; v0[r + 1] = g0[1]; v1[r] = g1[0]; v1[r + 1] = g1[1];
+                    }
                 }
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                 if constexpr (OUT_F32) {
@@ -179,8 +204,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
                     if constexpr (std::is_same<TO, f16_t>::value) {     // saturate instead of producing inf
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            v0[r] = fminf(fmaxf(v0[r], -65504.f), 65504.f);
-                            v1[r] = fminf(fmaxf(v1[r], -65504.f), 65504.f);
+                            // (v_med3_f32 straight: fminf/fmaxf on an MFMA result make hipcc add a canonicalising
+                            // v_max_f32 per element — 128 extra VALU instructions per wave and tile)
+                            v0[r] = __builtin_amdgcn_fmed3f(v0[r], -65504.f, 65504.f);
+                            v1[r] = __builtin_amdgcn_fmed3f(v1[r], -65504.f, 65504.f);
                         }
                     }
                     const O4 o0 = __builtin_convertvector(v0, O4), o1 = __builtin_convertvector(v1, O4);
