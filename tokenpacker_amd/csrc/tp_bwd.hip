@@ -119,40 +119,50 @@ reduce_parts_kernel(const float* __restrict__ part, long long part_stride, int n
     out[i] = sat_cast<TD>(s);
 }
 
-// Same sum, many parts (column-sum / LayerNorm partials: hundreds to thousands of parts of a few thousand values):
-// 16 columns per workgroup, 16 part-lanes per column walking the parts with stride 16, then a fixed 16 -> 1 tree.
-template <typename TD>
+// Same sum, many parts (column-sum / LayerNorm partials: hundreds to thousands of parts of a few thousand values),
+// in two stages so that the whole chip streams the partials with 16-byte loads: stage 1 — grid (n / 256 column
+// blocks, S part slices), a thread owns 4 consecutive columns and every 4th part of its slice, the 4 part-lanes
+// combine through LDS in a fixed order -> scratch[S][n]; stage 2 — reduce_parts_kernel over the S slices.  The
+// summation tree depends on (nparts, S) only: deterministic.
 __global__ void __launch_bounds__(256)
-reduce_many_parts_kernel(const float* __restrict__ part, long long part_stride, int nparts, int n, TD* __restrict__ out) {
-    __shared__ float red[16][17];
-    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
-    float s = 0.f;
-    if (c < n)
-        for (int k = pl; k < nparts; k += 16) s += part[(long long)k * part_stride + c];
-    red[pl][cl] = s;
-    __syncthreads();
-    if (pl == 0 && c < n) {
-        float t[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t[i] = red[i][cl];
-#pragma unroll
-        for (int w = 8; w >= 1; w >>= 1)
-#pragma unroll
-            for (int i = 0; i < w; ++i) t[i] += t[i + w];
-        out[c] = sat_cast<TD>(t[0]);
+reduce_cols_stage1_kernel(const float* __restrict__ part, long long part_stride, int nparts, int n,
+                          float* __restrict__ scratch) {
+    __shared__ f32x4 red[4][64];
+    const int cq = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + cq) * 4;
+    const int S = gridDim.y, slice = blockIdx.y;
+    const int per = (nparts + S - 1) / S;
+    const int k0 = slice * per, k1 = (k0 + per < nparts) ? k0 + per : nparts;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (c < n) {
+        const float* b = part + c;
+        int k = k0 + pl;
+        for (; k + 12 < k1; k += 16) {                   // four independent 16-byte loads in flight per thread
+            s0 += *(const f32x4*)(b + (long long)k * part_stride);
+            s1 += *(const f32x4*)(b + (long long)(k + 4) * part_stride);
+            s2 += *(const f32x4*)(b + (long long)(k + 8) * part_stride);
+            s3 += *(const f32x4*)(b + (long long)(k + 12) * part_stride);
+        }
+        for (; k < k1; k += 4) s0 += *(const f32x4*)(b + (long long)k * part_stride);
     }
+    red[pl][cq] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (pl == 0 && c < n)
+        *(f32x4*)(scratch + (long long)slice * n + c) = (red[0][cq] + red[1][cq]) + (red[2][cq] + red[3][cq]);
 }
 
 int bw_reduce_many_parts_launch(int dst_dtype, const float* part, long long part_stride, int nparts, int n, void* out,
-                                hipStream_t stream) {
-    const unsigned blocks = (unsigned)((n + 15) / 16);
-    if (dst_dtype == TP_BF16)
-        hipLaunchKernelGGL(reduce_many_parts_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, part, part_stride, nparts, n, (bf16_t*)out);
-    else if (dst_dtype == TP_F16)
-        hipLaunchKernelGGL(reduce_many_parts_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream, part, part_stride, nparts, n, (f16_t*)out);
-    else { set_error("bw reduce: unsupported dtype %d", dst_dtype); return TP_ERR_INVALID_ARG; }
-    return check_launch("reduce_many_parts_kernel");
+                                float* scratch, hipStream_t stream) {
+    if ((n & 3) || (part_stride & 3) || ((uintptr_t)part & 15)) {
+        set_error("bw reduce: n / part stride must be multiples of 4 floats, partials 16-byte aligned");
+        return TP_ERR_INVALID_ARG;
+    }
+    int S = kReduceSlices;
+    while (S > 1 && nparts < 8 * S) S >>= 1;              // at least 8 parts per slice
+    hipLaunchKernelGGL(reduce_cols_stage1_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)S), dim3(256), 0, stream,
+                       part, part_stride, nparts, n, scratch);
+    if (int rc = check_launch("reduce_cols_stage1_kernel")) return rc;
+    return bw_reduce_parts_launch(dst_dtype, scratch, n, S, n, out, stream);
 }
 
 int bw_reduce_parts_launch(int dst_dtype, const float* part, long long part_stride, int nparts, long long n, void* out,

@@ -119,8 +119,9 @@ int bw_transpose_launch(int src_dtype, int dst_dtype, const void* src, long long
                         const float* gamma, const float* beta, float* colsum_part, hipStream_t stream);
 int bw_reduce_parts_launch(int dst_dtype, const float* part, long long part_stride, int nparts, long long n, void* out,
                            hipStream_t stream);
+constexpr int kReduceSlices = 32;                  // stage-1 slices of the many-parts reduction: scratch = kReduceSlices * n floats
 int bw_reduce_many_parts_launch(int dst_dtype, const float* part, long long part_stride, int nparts, int n, void* out,
-                                hipStream_t stream);
+                                float* scratch, hipStream_t stream);
 int bw_ln_backward_launch(int gdtype, const void* dy, const void* x_f16, const float* mean_rstd, const float* gamma,
                           void* dx, float* part, int nblocks, long long rows, hipStream_t stream);
 int bw_region_attention_launch(int gdtype, const void* q, const void* k, const void* v, const void* dout, void* dq,

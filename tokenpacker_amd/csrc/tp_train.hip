@@ -32,6 +32,7 @@ struct BwLayout {
     size_t dKV, dKVT, kv1T, dkv1, dH2, dH2T, hkvT, dZ1, dZ1T, xmT;
     size_t counters;                                  // tile-queue heads of the persistent GEMM launches (zeroed once)
     size_t part, colpart, lnpart;                     // fp32 partials: split-K wgrad, column sums, LN affine grads
+    size_t redscratch;                                // stage-1 output of the many-parts reduction
     size_t part_bytes;
     size_t total;
     int Rp, Rqp;
@@ -64,6 +65,7 @@ static BwLayout bw_layout(int B, int grid, int s, int D) {
     const size_t cmax = (size_t)D > 2 * E ? (size_t)D : 2 * E;
     L.colpart = take((Rp / 64) * cmax * 4);
     L.lnpart = take((size_t)256 * 2 * E * 4);
+    L.redscratch = take((size_t)kReduceSlices * cmax * 4);
     L.counters = take(64 * 32 * 4);
     L.total = off;
     return L;
@@ -140,6 +142,7 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
     const int Rp = L.Rp, Rqp = L.Rqp;
     float* part = (float*)(bw + L.part);
     float* colpart = (float*)(bw + L.colpart);
+    float* redscratch = (float*)(bw + L.redscratch);
     const long long kvE = (long long)R * E;
 
     int* counters = tuning(TP_TUNE_DYNAMIC_TILES) ? (int*)(bw + L.counters) : nullptr;
@@ -160,7 +163,7 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
     };
     // bias gradient from the column-sum partials the last transpose left behind
     auto bias_grad = [&](int rpad, int cols, void* out) -> int {
-        return bw_reduce_many_parts_launch(GT, colpart, cols, rpad / 64, cols, out, stream);
+        return bw_reduce_many_parts_launch(GT, colpart, cols, rpad / 64, cols, out, redscratch, stream);
     };
     // dX[rows, Kin] = dY[rows, Nout] · W[Nout, Kin]  with W^T [Kin, Nout] given
     auto dgrad = [&](const void* dY, long long ldy, int rows, int Nout, const void* WT, int Kin, void* dX, long long ldx,
@@ -248,16 +251,16 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
     {
         const int nb = 256;
         TP_TRY(bw_ln_backward_launch(GT, bw + L.dq1, fw + W.q1pre, (const float*)(fw + W.mr_q), ln_g, bw + L.dQ1pre, lnpart, nb, Rq, stream));
-        TP_TRY(bw_reduce_many_parts_launch(GT, lnpart, 2 * E, nb, E, grads->ln_q_1_weight, stream));
-        TP_TRY(bw_reduce_many_parts_launch(GT, lnpart + E, 2 * E, nb, E, grads->ln_q_1_bias, stream));
+        TP_TRY(bw_reduce_many_parts_launch(GT, lnpart, 2 * E, nb, E, grads->ln_q_1_weight, redscratch, stream));
+        TP_TRY(bw_reduce_many_parts_launch(GT, lnpart + E, 2 * E, nb, E, grads->ln_q_1_bias, redscratch, stream));
         void* gw[2] = {grads->ln_k_1_weight, grads->ln_v_1_weight};
         void* gb[2] = {grads->ln_k_1_bias, grads->ln_v_1_bias};
         for (int t = 0; t < 2; ++t) {
             TP_TRY(bw_ln_backward_launch(GT, bw + L.dkv1 + (size_t)t * kvE * 2, fw + W.h2 + (size_t)t * kvE * 2,
                                          (const float*)(fw + W.mr_kv) + (size_t)t * R * 2, ln_g + (1 + t) * E,
                                          bw + L.dH2 + (size_t)t * kvE * 2, lnpart, nb, R, stream));
-            TP_TRY(bw_reduce_many_parts_launch(GT, lnpart, 2 * E, nb, E, gw[t], stream));
-            TP_TRY(bw_reduce_many_parts_launch(GT, lnpart + E, 2 * E, nb, E, gb[t], stream));
+            TP_TRY(bw_reduce_many_parts_launch(GT, lnpart, 2 * E, nb, E, gw[t], redscratch, stream));
+            TP_TRY(bw_reduce_many_parts_launch(GT, lnpart + E, 2 * E, nb, E, gb[t], redscratch, stream));
         }
     }
     // ---- q_proj_1 (no bias) ---------------------------------------------------------------------------------------
@@ -282,8 +285,8 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
     }
     // ---- k/v_proj_1[0] -----------------------------------------------------------------------------------------------
     TP_TRY(T(GT, bw + L.dZ1, 2 * E, R, 2 * E, bw + L.dZ1T, Rp, nullptr, nullptr, nullptr, colpart));
-    TP_TRY(bw_reduce_many_parts_launch(GT, colpart, 2 * E, Rp / 64, E, grads->k_proj_1_0_bias, stream));
-    TP_TRY(bw_reduce_many_parts_launch(GT, colpart + E, 2 * E, Rp / 64, E, grads->v_proj_1_0_bias, stream));
+    TP_TRY(bw_reduce_many_parts_launch(GT, colpart, 2 * E, Rp / 64, E, grads->k_proj_1_0_bias, redscratch, stream));
+    TP_TRY(bw_reduce_many_parts_launch(GT, colpart + E, 2 * E, Rp / 64, E, grads->v_proj_1_0_bias, redscratch, stream));
     if (xm_parts) {                                     // four [B, N, 1024] sources -> rows part*1024 .. of x_multi^T
         for (int i = 0; i < 4; ++i)
             TP_TRY(bw_transpose_launch(GT, GT, xm_parts[i], xm_strides[1], N, xm_strides[0], R, kMulti / 4,

@@ -31,6 +31,20 @@ fi
 if has kfit; then
   echo "== per-tile fixed cost fit =="; timeout 600 python tools/ktile_fit.py > $OUT/ktile_fit.txt 2>&1; echo "exit $?"; cat $OUT/ktile_fit.txt
 fi
+if has btests; then
+  echo "== pytest gpu (backward only) =="
+  timeout 900 python -m pytest tests/test_gpu_backward.py -m gpu -x -q -s -p no:cacheprovider > $OUT/pytest_bwd.log 2>&1
+  echo "pytest exit $?"; tail -8 $OUT/pytest_bwd.log
+fi
+if has train; then
+  echo "== train bench =="; timeout 900 python tools/train_bench.py --out $OUT/train_bench.json > $OUT/train_bench.log 2>&1; echo "exit $?"; tail -6 $OUT/train_bench.log
+fi
+if has trainprof; then
+  echo "== rocprof kernel trace of the training step =="
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/rocprof_train -o train -- python $R/tools/train_bench.py --batches 256 --hip-only --out $R/$OUT/train_bench_prof.json > $R/$OUT/rocprof_train.log 2>&1 ); echo "rocprof exit $?"
+  F=$(find $OUT/rocprof_train -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && head -16 "$F" | cut -c1-200
+  find $OUT/rocprof_train -name "*kernel_trace.csv" -size +20M -delete
+fi
 if has bench; then
   echo "== bench =="; timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; cat $OUT/bench.json; tail -5 $OUT/bench.err
 fi
