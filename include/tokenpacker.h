@@ -254,6 +254,17 @@ int tp_backward_parts(const tp_desc* desc, const void* const xm_parts[4], const 
                       const tp_weights* raw, const void* packed_weights, const void* train_workspace, const void* dy,
                       const tp_grads* grads, void* bw_workspace, size_t bw_workspace_bytes, void* stream);
 
+/* The backward's weight-gradient contraction on its own (what autograd computes for every nn.Linear of
+ * builder.py:59-83):  dw[n_out, k_in] = sum over the `rows` token rows of dy[r, n] * x[r, k], read from the ROW-MAJOR
+ * activations — no transposed copies.  dy [rows, n_out] and x [rows, k_in] are `dtype` with row strides ldy / ldx
+ * (elements, multiples of 8); x may be batch-strided like x_multi (x_rows_per_batch a multiple of 64 and >= 128, or 0).
+ * dw is `out_dtype` (TP_BF16 / TP_F16 / TP_F32), contiguous; fp32 accumulation, deterministic.
+ * Needs k_in % 256 == 0 and n_out % 8 == 0.  workspace: tp_wgrad_workspace_bytes(n_out, k_in) bytes, 256-byte aligned. */
+size_t tp_wgrad_workspace_bytes(int n_out, int k_in);
+int tp_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, int x_rows_per_batch, int64_t x_batch_stride,
+             int64_t rows, int n_out, int k_in, int dtype, void* dw, int out_dtype, void* workspace,
+             size_t workspace_bytes, void* stream);
+
 /* ---- TokenPacker-HD token assembly (the step right after the projector) --------------------------------
  * Replaces the Python loop + torch.cat of `prepare_inputs_labels_for_multimodal` in mode 'slice'
  * (llava_arch.py:140-154): per image, the h_block x w_block crops in row-major order, the ',' embedding after

@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = (
     "tp_ln_finalize", "tp_linear_stats_parts", "tp_set_tuning", "tp_hd_rows", "tp_hd_assemble",
     "tp_train_workspace_bytes", "tp_backward_workspace_bytes", "tp_forward_train", "tp_backward",
     "tp_forward_parts", "tp_forward_train_parts", "tp_backward_parts", "tp_test_occupy_cus", "tp_hd_slice",
+    "tp_wgrad", "tp_wgrad_workspace_bytes",
 )
 
 # state-dict name -> tp_weights field order (include/tokenpacker.h)
@@ -145,6 +146,11 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.tp_backward_parts.restype = c_int
     lib.tp_backward_parts.argtypes = [POINTER(tp_desc), POINTER(c_void_p), POINTER(c_int64), POINTER(tp_weights), c_void_p,
                                       c_void_p, c_void_p, POINTER(tp_grads), c_void_p, c_size_t, c_void_p]
+    lib.tp_wgrad_workspace_bytes.restype = c_size_t
+    lib.tp_wgrad_workspace_bytes.argtypes = [c_int, c_int]
+    lib.tp_wgrad.restype = c_int
+    lib.tp_wgrad.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int64, c_int, c_int, c_int, c_void_p,
+                             c_int, c_void_p, c_size_t, c_void_p]
     lib.tp_hd_slice.restype = c_int
     lib.tp_hd_slice.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]
     lib.tp_test_occupy_cus.restype = c_int

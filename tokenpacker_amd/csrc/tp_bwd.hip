@@ -15,6 +15,7 @@ template <typename T> __device__ __forceinline__ float ld1(const T* p) { return 
 template <typename T> __device__ __forceinline__ T sat_cast(float v);
 template <> __device__ __forceinline__ f16_t sat_cast<f16_t>(float v) { return (f16_t)fminf(fmaxf(v, -65504.f), 65504.f); }
 template <> __device__ __forceinline__ bf16_t sat_cast<bf16_t>(float v) { return (bf16_t)v; }
+template <> __device__ __forceinline__ float sat_cast<float>(float v) { return v; }
 
 // ---------------------------------------------------------------------------------------------------
 // dst[c][r] = cast( f(src[r][c]) )  for r < R (zero for R <= r < Rpad), c < C.   f = identity, or the LayerNorm
@@ -165,6 +166,72 @@ int bw_reduce_many_parts_launch(int dst_dtype, const float* part, long long part
     return bw_reduce_parts_launch(dst_dtype, scratch, n, S, n, out, stream);
 }
 
+// Column sums of a row-major 16-bit matrix (bias gradients of the layers whose weight gradient reads dY in place):
+// part[slice][c] = sum over the slice's rows of src[r][c].  A thread owns 8 consecutive columns (one 16-byte load per
+// row) and every 4th row of its slice; the 4 row-lanes combine through LDS in a fixed order.
+template <typename TS>
+__global__ void __launch_bounds__(256)
+colsum_rows_kernel(const TS* __restrict__ src, long long ld, long long R, int C, float* __restrict__ part) {
+    using S8 = typename Vec<TS>::x8;
+    __shared__ float red[4][64][8];
+    const int co = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + co) * 8;
+    const int S = gridDim.y, slice = blockIdx.y;
+    const long long per = (R + S - 1) / S;
+    const long long r0 = slice * per, r1 = (r0 + per < R) ? r0 + per : R;
+    float acc[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[u][e] = 0.f;
+    if (c < C) {
+        const TS* b = src + c;
+        long long r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {                   // four independent 16-byte loads in flight per thread
+            S8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const S8*)(b + (r + 4 * u) * ld);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[u][e] += (float)v[u][e];
+        }
+        for (; r < r1; r += 4) {
+            const S8 v = *(const S8*)(b + r * ld);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[0][e] += (float)v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl][co][e] = (acc[0][e] + acc[1][e]) + (acc[2][e] + acc[3][e]);
+    __syncthreads();
+    if (rl == 0 && c < C) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            part[(long long)slice * C + c + e] = (red[0][co][e] + red[1][co][e]) + (red[2][co][e] + red[3][co][e]);
+    }
+}
+
+// -> part[slices][C]; returns the number of slices written (a fixed function of R and C), or a negative status
+int bw_colsum_rows_launch(int dtype, const void* src, long long ld, long long R, int C, float* part, hipStream_t stream) {
+    if ((C & 7) || (ld & 7) || ((uintptr_t)src & 15)) {
+        set_error("bw colsum: columns / row stride must be multiples of 8 elements, the source 16-byte aligned");
+        return TP_ERR_INVALID_ARG;
+    }
+    const int gx = (C + 511) / 512;
+    long long S = 512 / gx;                              // ~512 workgroups
+    if (S > R / 64) S = R / 64;
+    if (S < 1) S = 1;
+    if (S > kColsumMaxSlices) S = kColsumMaxSlices;
+    if (dtype == TP_BF16)
+        hipLaunchKernelGGL(colsum_rows_kernel<bf16_t>, dim3((unsigned)gx, (unsigned)S), dim3(256), 0, stream, (const bf16_t*)src, ld, R, C, part);
+    else if (dtype == TP_F16)
+        hipLaunchKernelGGL(colsum_rows_kernel<f16_t>, dim3((unsigned)gx, (unsigned)S), dim3(256), 0, stream, (const f16_t*)src, ld, R, C, part);
+    else { set_error("bw colsum: unsupported dtype %d", dtype); return TP_ERR_INVALID_ARG; }
+    if (int rc = check_launch("colsum_rows_kernel")) return rc;
+    return (int)S;
+}
+
 int bw_reduce_parts_launch(int dst_dtype, const float* part, long long part_stride, int nparts, long long n, void* out,
                            hipStream_t stream) {
     const unsigned blocks = (unsigned)((n + 255) / 256);
@@ -172,6 +239,8 @@ int bw_reduce_parts_launch(int dst_dtype, const float* part, long long part_stri
         hipLaunchKernelGGL(reduce_parts_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, part, part_stride, nparts, n, (bf16_t*)out);
     else if (dst_dtype == TP_F16)
         hipLaunchKernelGGL(reduce_parts_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream, part, part_stride, nparts, n, (f16_t*)out);
+    else if (dst_dtype == TP_F32)
+        hipLaunchKernelGGL(reduce_parts_kernel<float>, dim3(blocks), dim3(256), 0, stream, part, part_stride, nparts, n, (float*)out);
     else { set_error("bw reduce: unsupported dtype %d", dst_dtype); return TP_ERR_INVALID_ARG; }
     return check_launch("reduce_parts_kernel");
 }

@@ -233,6 +233,13 @@ int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stre
         set_error("tp gemm: ROW_STATS with fp32 output is not supported");
         return TP_ERR_INVALID_ARG;
     }
+    if (a.tt_rows > 0) {                                // K-major operands: the ping-pong kernel only
+        if (a.N % 256 != 0 || (a.lda_bytes & 15) || (a.ldw_bytes & 15) || a.ldw_bytes == 0 || a.flags != 0) {
+            set_error("tp gemm: K-major operands need N %% 256 == 0, 16-byte aligned row strides and no epilogue flags");
+            return TP_ERR_INVALID_ARG;
+        }
+        return gemm8_launch(in_dtype, out_dtype, a, stream);
+    }
     if (gemm_pick_tile(a.M, a.N, a.tile, a.groups) == 256 && tuning(TP_TUNE_GEMM_KERNEL) != 1)
         return gemm8_launch(in_dtype, out_dtype, a, stream);
     if (in_dtype == TP_BF16) {

@@ -70,7 +70,15 @@ constexpr int G8_DEPTH = 3;                        // DMA groups left in flight 
 }  // namespace
 
 // AMODE: 0 = A rows contiguous (lda), 1 = rows in batches with a batch stride (the CLIP tower's [:,1:] slices),
-//        2 = like 1 with K split over four source tensors (the tower's hidden states consumed without torch.cat)
+//        2 = like 1 with K split over four source tensors (the tower's hidden states consumed without torch.cat),
+//        3 = "TT": both operands K-MAJOR — A[k][m], W[k][n], the contraction index is the row of both (weight
+//            gradients dW = dY^T · X straight from the row-major activations, no transposed copies).  A DMA
+//            instruction moves 4 k-rows x 128 contiguous columns (whole cache lines, like the K-contiguous modes) as
+//            eight [4 k][16 col] chunks of 128 B; ds_read_b64_tr_b16 turns one chunk per 16-lane group into the
+//            MFMA operand layout (lane = column, 4 consecutive k per read, two reads per 32-k MFMA step — the same
+//            k permutation on both operands, so the contraction is unchanged).  Chunk slots are XOR-ed with the
+//            k-quad's parity so that the two lane groups an LDS cycle serves hit different bank halves.  Rows past
+//            the end of the contraction range read as zero (descriptor range check, rebuilt per K-tile).
 template <typename TI, typename TO, int AMODE, bool PERSIST, bool TRAIN_EPI>
 __global__ void __launch_bounds__(512, 2)
 gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int xcd_swizzle) {
@@ -109,6 +117,8 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
     int m0, n0, tile_n;
     __amdgpu_buffer_rsrc_t rsrc_a, rsrc_w;
     long long a_tile_off_cur = 0;                      // AMODE 2: the descriptor of a K-part is rebuilt from its base
+    const char* tt_w_base = nullptr;                   // AMODE 3: W base of this tile's columns (group / part resolved)
+    int tt_n_loc_bytes = 0;
     int voff_a[2][2], voff_w[2][2];                    // [sub][q] per-lane DMA source offsets
     const int kslot = (lane & 7) ^ (lane >> 3);
 
@@ -131,6 +141,31 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         const int tm = Lt / tiles_n;
         tile_n = Lt - tm * tiles_n;
         m0 = tm * BM; n0 = tile_n * BN;
+        if constexpr (AMODE == 3) {
+            // per-lane source offsets of DMA instruction idx = 2 wave + q of a group: k rows 4 idx .. 4 idx + 3, chunk
+            // slot lane / 8 holds column block (lane / 8) ^ q, row (lane % 8) / 2, 16-byte half lane % 2
+            tt_w_base = p.W + g * p.w_gs;
+            int n_loc = n0;
+            if (p.W_parts[0]) {                         // N split over four source tensors (hidden states, no torch.cat)
+                const int part = n0 / p.n_part;
+                n_loc = n0 - part * p.n_part;
+                tt_w_base = part == 0 ? p.W_parts[0] : part == 1 ? p.W_parts[1] : part == 2 ? p.W_parts[2] : p.W_parts[3];
+            }
+            tt_w_base += (long long)n_loc * 2;
+            tt_n_loc_bytes = n_loc * 2;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int krow = 4 * (2 * wave + q) + ((lane & 7) >> 1);
+                    const int cb = (lane >> 3) ^ q;
+                    const int acol = (cb >> 2) * 128 + sub * 64 + (cb & 3) * 16 + (lane & 1) * 8;
+                    const int wcol = (cb >> 1) * 64 + sub * 32 + (cb & 1) * 16 + (lane & 1) * 8;
+                    voff_a[sub][q] = (int)(krow * p.lda_bytes) + acol * 2;
+                    voff_w[sub][q] = (int)(krow * ldw) + wcol * 2;
+                }
+            return;
+        }
         const long long a_tile_off = a_row_off(m0);
         rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + g * p.a_gs + a_tile_off), 0, 0x7fffffff, 0x00020000);
         a_tile_off_cur = a_tile_off;
@@ -155,6 +190,38 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         constexpr bool is_a = (grp == 0 || grp == 3);
         constexpr int sub = (grp == 2 || grp == 3) ? 1 : 0;
         char* dst = smem + (kt & 1) * G8_BUF + grp * G8_GROUP + wave * 2048;
+        if constexpr (AMODE == 3) {
+            // K-tile kt = contraction rows r0 .. r0 + 63 of this group's range; the descriptor starts at the tile's
+            // first column of row r0 and ends after the last valid row (soffset is not range-checked, so K advances
+            // through the base address)
+            const int r0 = kt * BK;                                         // row inside the group's range
+            long long rows_left = (long long)p.tt_rows - (long long)g * p.K - r0;
+            rows_left = rows_left < 0 ? 0 : (rows_left > BK ? BK : rows_left);
+            const char* base; long long ld, nrec;
+            if constexpr (is_a) {
+                ld = p.lda_bytes;
+                base = p.A + g * p.a_gs + (long long)r0 * ld + (long long)m0 * 2;
+                nrec = rows_left * ld - (long long)m0 * 2;
+            } else {
+                ld = ldw;
+                const unsigned ktg = (unsigned)(g * nk + kt);               // K-tile index over all groups
+                const unsigned bidx = __umulhi(ktg, (unsigned)p.tt_bmagic); // batch = ktg / tiles_per_batch (host magic)
+                const unsigned tin = ktg - bidx * (unsigned)p.tt_tpb;
+                base = tt_w_base + (long long)bidx * p.w_batch_stride_bytes + (long long)tin * BK * ld;
+                nrec = rows_left * ld - tt_n_loc_bytes;
+            }
+            nrec = nrec < 0 ? 0 : nrec;
+            const unsigned long long addr = (unsigned long long)base;
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)addr);
+            const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(addr >> 32));
+            const int nr = __builtin_amdgcn_readfirstlane((int)(unsigned)nrec);
+            const auto r = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, nr, 0x00020000);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst + q * 1024), 16,
+                                                         is_a ? voff_a[sub][q] : voff_w[sub][q], 0, 0, 0);
+            return;
+        }
         const int soff = kt * ROW_BYTES;
         if constexpr (is_a && AMODE == 2) {
             // K-tile kt lives in source kt / tpp: pick that source's base with scalar selects and rebuild the
@@ -196,6 +263,55 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
     X8 fa[4][2];            // A fragments of the current M-quadrant  [i][k-half]
     X8 fb[2][2][2];         // W fragments                            [b][j][k-half]
 
+    // AMODE 3 fragment reads.  Column block cb (16 columns) of a group, 32-k step kh -> two transposing reads (k 0..15
+    // and 16..31 of the step).  Per-lane base = the lane group's k-quad (rows 4g..4g+3 of a 16-k block = DMA block g of
+    // that k block) + this wave's first column block + the slot XOR (+/- 128 B for odd k-quads, by the block's parity).
+    // The reads are inline asm: hipcc guards the ds_read_tr builtin with s_waitcnt vmcnt(0) whenever an LDS-DMA is in
+    // flight (it cannot tell that the ring regions differ), which would drain the queue every phase.  Nothing touches
+    // the destination registers before the phase's own s_waitcnt lgkmcnt(0).
+    const int tt_g = lane >> 4, tt_c = (lane & 15) * 8;
+    const int tt_a_even = tt_g * 1024 + tt_c + (tt_g & 1) * 128 + wm * 512;
+    const int tt_a_odd = tt_g * 1024 + tt_c - (tt_g & 1) * 128 + wm * 512;
+    const int tt_w_even = tt_g * 1024 + tt_c + (tt_g & 1) * 128 + wn * 256;
+    const int tt_w_odd = tt_g * 1024 + tt_c - (tt_g & 1) * 128 + wn * 256;
+    auto tt_read = [&](const unsigned addr, auto OFF_) __attribute__((always_inline)) -> X8 {
+        constexpr int OFF = decltype(OFF_)::value;
+        typedef int i32x2 __attribute__((ext_vector_type(2)));
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        i32x2 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(OFF));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(OFF + 4096));
+        return __builtin_bit_cast(X8, (i32x4)__builtin_shufflevector(lo, hi, 0, 1, 2, 3));
+    };
+    // A fragments i = 0..3 of group GRP into fa[i][kh], W fragments j = 0, 1 of group GRP into fb[B][j][kh]
+    auto tt_read_a = [&](const unsigned ring, auto GRP_) __attribute__((always_inline)) {
+        constexpr int GRP = decltype(GRP_)::value;
+        const unsigned ae = ring + tt_a_even, ao = ring + tt_a_odd;
+        fa[0][0] = tt_read(ae, std::integral_constant<int, GRP * G8_GROUP + 0 * 128 + 0 * 8192>{});
+        fa[0][1] = tt_read(ae, std::integral_constant<int, GRP * G8_GROUP + 0 * 128 + 1 * 8192>{});
+        fa[1][0] = tt_read(ao, std::integral_constant<int, GRP * G8_GROUP + 1 * 128 + 0 * 8192>{});
+        fa[1][1] = tt_read(ao, std::integral_constant<int, GRP * G8_GROUP + 1 * 128 + 1 * 8192>{});
+        fa[2][0] = tt_read(ae, std::integral_constant<int, GRP * G8_GROUP + 2 * 128 + 0 * 8192>{});
+        fa[2][1] = tt_read(ae, std::integral_constant<int, GRP * G8_GROUP + 2 * 128 + 1 * 8192>{});
+        fa[3][0] = tt_read(ao, std::integral_constant<int, GRP * G8_GROUP + 3 * 128 + 0 * 8192>{});
+        fa[3][1] = tt_read(ao, std::integral_constant<int, GRP * G8_GROUP + 3 * 128 + 1 * 8192>{});
+    };
+    auto tt_read_w = [&](const unsigned ring, auto GRP_, auto B_) __attribute__((always_inline)) {
+        constexpr int GRP = decltype(GRP_)::value, B = decltype(B_)::value;
+        const unsigned we = ring + tt_w_even, wo = ring + tt_w_odd;
+        fb[B][0][0] = tt_read(we, std::integral_constant<int, GRP * G8_GROUP + 0 * 128 + 0 * 8192>{});
+        fb[B][0][1] = tt_read(we, std::integral_constant<int, GRP * G8_GROUP + 0 * 128 + 1 * 8192>{});
+        fb[B][1][0] = tt_read(wo, std::integral_constant<int, GRP * G8_GROUP + 1 * 128 + 0 * 8192>{});
+        fb[B][1][1] = tt_read(wo, std::integral_constant<int, GRP * G8_GROUP + 1 * 128 + 1 * 8192>{});
+    };
+    auto read_a = [&](const char* sb, const int grp, const int i, const int kh) __attribute__((always_inline)) -> X8 {
+        return *(const X8*)(sb + grp * G8_GROUP + rd_a + i * 2048 + (kh ? slot1 : slot0));
+    };
+    auto read_w = [&](const char* sb, const int grp, const int j, const int kh) __attribute__((always_inline)) -> X8 {
+        return *(const X8*)(sb + grp * G8_GROUP + rd_w + j * 2048 + (kh ? slot1 : slot0));
+    };
+
+
     // One phase.  P: 0..3;  ISSUE: whether this phase's DMA group exists;  WAIT: vmcnt to leave in flight
     // (-1: no wait).  The DMA target of phase P in tile t is fixed by the schedule in the file header.
     auto phase = [&](auto P_, auto ISSUE_, auto WAIT_, const int t) __attribute__((always_inline)) {
@@ -204,29 +320,22 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         constexpr int WAIT = decltype(WAIT_)::value;
         const char* sb = smem + (t & 1) * G8_BUF;
         // -- memory segment ---------------------------------------------------------------------------
-        if constexpr (P == 0) {
+        if constexpr (AMODE == 3) {
+            const unsigned ring = (unsigned)(t & 1) * G8_BUF;       // (dynamic LDS starts at address 0: no static __shared__)
+            if constexpr (P == 0) { tt_read_w(ring, I1{}, I0{}); tt_read_a(ring, I0{}); }
+            else if constexpr (P == 1) tt_read_w(ring, I2{}, I1{});
+            else if constexpr (P == 2) tt_read_a(ring, I3{});
+        } else if constexpr (P == 0) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                fb[0][j][0] = *(const X8*)(sb + 1 * G8_GROUP + rd_w + j * 2048 + slot0);
-                fb[0][j][1] = *(const X8*)(sb + 1 * G8_GROUP + rd_w + j * 2048 + slot1);
-            }
+            for (int j = 0; j < 2; ++j) { fb[0][j][0] = read_w(sb, 1, j, 0); fb[0][j][1] = read_w(sb, 1, j, 1); }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fa[i][0] = *(const X8*)(sb + 0 * G8_GROUP + rd_a + i * 2048 + slot0);
-                fa[i][1] = *(const X8*)(sb + 0 * G8_GROUP + rd_a + i * 2048 + slot1);
-            }
+            for (int i = 0; i < 4; ++i) { fa[i][0] = read_a(sb, 0, i, 0); fa[i][1] = read_a(sb, 0, i, 1); }
         } else if constexpr (P == 1) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                fb[1][j][0] = *(const X8*)(sb + 2 * G8_GROUP + rd_w + j * 2048 + slot0);
-                fb[1][j][1] = *(const X8*)(sb + 2 * G8_GROUP + rd_w + j * 2048 + slot1);
-            }
+            for (int j = 0; j < 2; ++j) { fb[1][j][0] = read_w(sb, 2, j, 0); fb[1][j][1] = read_w(sb, 2, j, 1); }
         } else if constexpr (P == 2) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fa[i][0] = *(const X8*)(sb + 3 * G8_GROUP + rd_a + i * 2048 + slot0);
-                fa[i][1] = *(const X8*)(sb + 3 * G8_GROUP + rd_a + i * 2048 + slot1);
-            }
+            for (int i = 0; i < 4; ++i) { fa[i][0] = read_a(sb, 3, i, 0); fa[i][1] = read_a(sb, 3, i, 1); }
         }
         if constexpr (ISSUE) {
             if constexpr (P == 0) issue(I2{}, t + 1);
@@ -425,6 +534,11 @@ template <typename TI, typename TO, bool PERSIST>
 static int launch8_var(const GemmArgs& a, hipStream_t stream) {
     constexpr bool HALF_OUT = !std::is_same<TO, float>::value;
     const bool train_epi = (a.flags & (TP_LINEAR_SAVE_PRE | TP_LINEAR_GELU_BWD)) != 0;
+    if (a.tt_rows > 0) {                                // K-major operands (weight gradients): fp32 partials only
+        if constexpr (std::is_same<TO, float>::value && PERSIST) return launch8_cfg<TI, TO, 3, PERSIST, false>(a, stream);
+        set_error("tp gemm8: K-major operands are supported with fp32 output on the persistent kernel only");
+        return TP_ERR_INVALID_ARG;
+    }
     if (a.A_parts[0]) {                                // K split over four sources: the forward's first layer only
         if constexpr (std::is_same<TO, f16_t>::value && PERSIST)
             return train_epi ? launch8_cfg<TI, TO, 2, PERSIST, true>(a, stream) : launch8_cfg<TI, TO, 2, PERSIST, false>(a, stream);

@@ -50,6 +50,16 @@ struct GemmArgs {
     const char* A_parts[4];           // K split over 4 source tensors of k_part columns each (NULL: A alone)
     int k_part;
     int* tile_counters;               // persistent kernel: [groups][8] zeroed ints -> dynamic per-XCD tile queue (NULL: static)
+    // "TT" mode (tt_rows > 0; tp_gemm8.hip AMODE 3): C[g][M,N] = sum over rows r of group g's range of A[r][m] W[r][n] —
+    // both operands K-major, row strides lda_bytes / ldw_bytes; group g covers contraction rows g*K .. g*K + K - 1 of
+    // tt_rows valid ones (rows beyond read as zero).  W rows may live in batches of tt_tpb K-tiles (64 rows each) with
+    // w_batch_stride_bytes between batches (tt_bmagic = ceil(2^32 / tt_tpb); 0 = one batch), and its N columns may be
+    // split over W_parts[4] tensors of n_part columns each.
+    long long tt_rows;
+    long long w_batch_stride_bytes;
+    unsigned tt_bmagic; int tt_tpb;
+    const char* W_parts[4];
+    int n_part;
     // per-group strides (bytes for A/W/C, floats for the fp32 side arrays)
     long long a_gs, w_gs, c_gs, bias_gs, stats_in_gs, colsum_gs, stats_out_gs;
     int M, N, K;
@@ -119,6 +129,23 @@ int bw_transpose_launch(int src_dtype, int dst_dtype, const void* src, long long
                         const float* gamma, const float* beta, float* colsum_part, hipStream_t stream);
 int bw_reduce_parts_launch(int dst_dtype, const float* part, long long part_stride, int nparts, long long n, void* out,
                            hipStream_t stream);
+// Weight gradient straight from the row-major activations (tp_gemm8.hip, K-major operands):
+//   dW[Nout, Kin] = sum over the R token rows of dY[r, n] * X[r, k],   split over the rows, fp32 partials -> out_dtype.
+// X may be batch-strided (rows_per_batch % 64 == 0) and its Kin columns split over four tensors of n_part columns.
+struct WgradX {
+    const void* x; long long ldx;                     // elements
+    int rows_per_batch; long long batch_stride;       // 0 / 0: contiguous rows
+    const void* const* parts; int n_part;             // NULL / 0: one tensor
+};
+bool wgrad_tt_supported(long long R, int Nout, int Kin, const WgradX& X, long long ldy);
+// rows [0, split_row) of dW go to grad_out, rows [split_row, Nout) to grad_out_hi (split_row = 0: all to grad_out)
+int wgrad_tt_launch(int dtype, const void* dY, long long ldy, const WgradX& X, long long R, int Nout, int Kin,
+                    float* part, size_t part_bytes, int out_dtype, void* grad_out, int* counters, hipStream_t stream,
+                    void* grad_out_hi = nullptr, int split_row = 0);
+size_t wgrad_tt_part_bytes(int Nout, int Kin);
+
+constexpr int kColsumMaxSlices = 512;              // row slices of the column-sum kernel: scratch = slices * C floats
+int bw_colsum_rows_launch(int dtype, const void* src, long long ld, long long R, int C, float* part, hipStream_t stream);
 constexpr int kReduceSlices = 32;                  // stage-1 slices of the many-parts reduction: scratch = kReduceSlices * n floats
 int bw_reduce_many_parts_launch(int dst_dtype, const float* part, long long part_stride, int nparts, int n, void* out,
                                 float* scratch, hipStream_t stream);

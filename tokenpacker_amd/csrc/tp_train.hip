@@ -71,13 +71,84 @@ static BwLayout bw_layout(int B, int grid, int s, int D) {
     return L;
 }
 
+#define TP_TRY(expr) do { int rc_ = (expr); if (rc_ != TP_OK) return rc_; } while (0)
+
+// ---- weight gradients from K-major operands ---------------------------------------------------------------------
+static int wgrad_splits(long long R, int Nout, int Kin) {
+    const long long tiles = (long long)((Nout + 255) / 256) * (Kin / 256);
+    int S = 1;
+    while (S < 16 && tiles * S < 256 && R / (S * 2) >= 512) S *= 2;
+    return S;
+}
+size_t wgrad_tt_part_bytes(int Nout, int Kin) { return (size_t)16 * Nout * Kin * 4; }
+
+bool wgrad_tt_supported(long long R, int Nout, int Kin, const WgradX& X, long long ldy) {
+    if (R <= 0 || Nout <= 0 || Kin <= 0 || Kin % 256 != 0 || Nout % 8 != 0 || ldy % 8 != 0 || X.ldx % 8 != 0) return false;
+    if (X.rows_per_batch > 0 && X.rows_per_batch < R &&
+        (X.rows_per_batch % 64 != 0 || X.rows_per_batch < 128 || X.batch_stride % 8 != 0)) return false;
+    if (X.parts && (X.n_part <= 0 || X.n_part % 256 != 0 || Kin != 4 * X.n_part)) return false;
+    return true;
+}
+
+int wgrad_tt_launch(int dtype, const void* dY, long long ldy, const WgradX& X, long long R, int Nout, int Kin,
+                    float* part, size_t part_bytes, int out_dtype, void* grad_out, int* counters, hipStream_t stream,
+                    void* grad_out_hi, int split_row) {
+    if (!wgrad_tt_supported(R, Nout, Kin, X, ldy)) {
+        set_error("tp wgrad: unsupported shape R=%lld Nout=%d Kin=%d (need Kin %% 256 == 0, strides %% 8 == 0, batches of a multiple of 64 rows)",
+                  R, Nout, Kin);
+        return TP_ERR_INVALID_ARG;
+    }
+    const int S = wgrad_splits(R, Nout, Kin);
+    if ((size_t)S * Nout * Kin * 4 > part_bytes) { set_error("tp wgrad: split partial buffer too small"); return TP_ERR_WORKSPACE; }
+    const long long Ks = ((R + S - 1) / S + 63) / 64 * 64;          // contraction rows per split, whole K-tiles
+    GemmArgs a{};
+    a.A = (const char*)dY; a.lda_bytes = ldy * 2; a.a_gs = Ks * ldy * 2;
+    a.W = X.parts ? (const char*)X.parts[0] : (const char*)X.x; a.ldw_bytes = X.ldx * 2; a.w_gs = 0;
+    if (X.parts) { for (int i = 0; i < 4; ++i) a.W_parts[i] = (const char*)X.parts[i]; a.n_part = X.n_part; }
+    if (X.rows_per_batch > 0 && X.rows_per_batch < R) {
+        a.tt_tpb = X.rows_per_batch / 64;                // K-tiles per batch (>= 2), divided by with a 32-bit magic number
+        a.tt_bmagic = (unsigned)(((1ull << 32) + a.tt_tpb - 1) / a.tt_tpb);
+        a.w_batch_stride_bytes = X.batch_stride * 2;
+    }
+    a.C = (char*)part; a.ldc = Kin; a.c_gs = (long long)Nout * Kin * 4;
+    a.M = Nout; a.N = Kin; a.K = (int)Ks; a.groups = S; a.tt_rows = R; a.rows_per_batch = Nout; a.tile = 256;
+    a.tile_counters = S <= 4 ? counters : nullptr;       // (a queue slot holds [4 groups][8 XCDs] heads)
+    TP_TRY(gemm_launch(dtype, TP_F32, a, stream));
+    if (!grad_out_hi || split_row <= 0 || split_row >= Nout)
+        return bw_reduce_parts_launch(out_dtype, part, (long long)Nout * Kin, S, (long long)Nout * Kin, grad_out, stream);
+    TP_TRY(bw_reduce_parts_launch(out_dtype, part, (long long)Nout * Kin, S, (long long)split_row * Kin, grad_out, stream));
+    return bw_reduce_parts_launch(out_dtype, part + (size_t)split_row * Kin, (long long)Nout * Kin, S,
+                                  (long long)(Nout - split_row) * Kin, grad_out_hi, stream);
+}
+
 }  // namespace tp
 
 using namespace tp;
 
-#define TP_TRY(expr) do { int rc_ = (expr); if (rc_ != TP_OK) return rc_; } while (0)
 
 extern "C" {
+
+size_t tp_wgrad_workspace_bytes(int n_out, int k_in) {
+    if (n_out <= 0 || k_in <= 0) { set_error("tp_wgrad_workspace_bytes: bad shape %d x %d", n_out, k_in); return 0; }
+    return wgrad_tt_part_bytes(n_out, k_in);
+}
+
+int tp_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, int x_rows_per_batch, int64_t x_batch_stride,
+             int64_t rows, int n_out, int k_in, int dtype, void* dw, int out_dtype, void* workspace,
+             size_t workspace_bytes, void* stream) {
+    if (!dy || !x || !dw || !workspace) { set_error("tp_wgrad: NULL argument"); return TP_ERR_INVALID_ARG; }
+    if ((dtype != TP_BF16 && dtype != TP_F16) || (out_dtype != TP_BF16 && out_dtype != TP_F16 && out_dtype != TP_F32)) {
+        set_error("tp_wgrad: unsupported dtypes in=%d out=%d", dtype, out_dtype);
+        return TP_ERR_INVALID_ARG;
+    }
+    if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15) || ((uintptr_t)dw & 15) || ((uintptr_t)workspace & 255)) {
+        set_error("tp_wgrad: dy / x / dw must be 16-byte aligned, the workspace 256-byte aligned");
+        return TP_ERR_INVALID_ARG;
+    }
+    WgradX X{x, ldx, x_rows_per_batch, x_batch_stride, nullptr, 0};
+    return wgrad_tt_launch(dtype, dy, ldy, X, rows, n_out, k_in, (float*)workspace, workspace_bytes, out_dtype, dw, nullptr,
+                           (hipStream_t)stream);
+}
 
 size_t tp_train_workspace_bytes(const tp_desc* desc) {
     if (validate_desc(desc) != TP_OK) return 0;
@@ -284,6 +355,18 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
         }
     }
     // ---- k/v_proj_1[0] -----------------------------------------------------------------------------------------------
+    // dW0 [2E, 4096] = dZ1^T · x_multi (rows 0..E-1: k_proj_1[0], E..2E-1: v_proj_1[0]).  Both operands are in the model
+    // dtype and row-major, so the contraction reads them in place (K-major GEMM operands): no dZ1^T, no x_multi^T.
+    const WgradX XM{x_multi, xm_strides[1], N, xm_strides[0], xm_parts, kMulti / 4};
+    if (wgrad_tt_supported(R, 2 * E, kMulti, XM, 2 * E)) {
+        const int slices = bw_colsum_rows_launch(GT, bw + L.dZ1, 2 * E, R, 2 * E, colpart, stream);
+        if (slices < 0) return slices;
+        TP_TRY(bw_reduce_many_parts_launch(GT, colpart, 2 * E, slices, E, grads->k_proj_1_0_bias, redscratch, stream));
+        TP_TRY(bw_reduce_many_parts_launch(GT, colpart + E, 2 * E, slices, E, grads->v_proj_1_0_bias, redscratch, stream));
+        int* ctr = (counters && launch_no < 64) ? counters + 32 * launch_no++ : nullptr;
+        return wgrad_tt_launch(GT, bw + L.dZ1, 2 * E, XM, R, 2 * E, kMulti, part, L.part_bytes, GT, grads->k_proj_1_0_weight,
+                               ctr, stream, grads->v_proj_1_0_weight, E);
+    }
     TP_TRY(T(GT, bw + L.dZ1, 2 * E, R, 2 * E, bw + L.dZ1T, Rp, nullptr, nullptr, nullptr, colpart));
     TP_TRY(bw_reduce_many_parts_launch(GT, colpart, 2 * E, Rp / 64, E, grads->k_proj_1_0_bias, redscratch, stream));
     TP_TRY(bw_reduce_many_parts_launch(GT, colpart + E, 2 * E, Rp / 64, E, grads->v_proj_1_0_bias, redscratch, stream));
