@@ -259,10 +259,14 @@ int tp_backward_parts(const tp_desc* desc, const void* const xm_parts[4], const 
  * activations — no transposed copies.  dy [rows, n_out] and x [rows, k_in] are `dtype` with row strides ldy / ldx
  * (elements, multiples of 8); x may be batch-strided like x_multi (x_rows_per_batch a multiple of 64 and >= 128, or 0).
  * dw is `out_dtype` (TP_BF16 / TP_F16 / TP_F32), contiguous; fp32 accumulation, deterministic.
- * Needs k_in % 256 == 0 and n_out % 8 == 0.  workspace: tp_wgrad_workspace_bytes(n_out, k_in) bytes, 256-byte aligned. */
+ * Needs k_in % 256 == 0 and n_out % 8 == 0.  workspace: tp_wgrad_workspace_bytes(n_out, k_in) bytes, 256-byte aligned.
+ * With TP_WGRAD_X_TRANSPOSED the activation operand is given transposed instead, x = X^T [k_in, ldx] with ldx a
+ * multiple of 1024 and zeros in columns rows .. ldx - 1 (an operand a cast or LayerNorm pass rewrote anyway);
+ * dy is still read in place. */
+enum { TP_WGRAD_X_TRANSPOSED = 1 };
 size_t tp_wgrad_workspace_bytes(int n_out, int k_in);
 int tp_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, int x_rows_per_batch, int64_t x_batch_stride,
-             int64_t rows, int n_out, int k_in, int dtype, void* dw, int out_dtype, void* workspace,
+             int64_t rows, int n_out, int k_in, int dtype, void* dw, int out_dtype, int flags, void* workspace,
              size_t workspace_bytes, void* stream);
 
 /* ---- TokenPacker-HD token assembly (the step right after the projector) --------------------------------

@@ -17,6 +17,7 @@ TP_OK, TP_ERR_INVALID_ARG, TP_ERR_BAD_SCALE, TP_ERR_WORKSPACE, TP_ERR_LAUNCH = 0
 TP_LINEAR_GELU, TP_LINEAR_LN_FOLD, TP_LINEAR_ROW_STATS = 1, 2, 4
 TP_TUNE_GEMM_TILE, TP_TUNE_XCD_SWIZZLE, TP_TUNE_GEMM_KERNEL, TP_TUNE_FOLD_OUT_PROJ, TP_TUNE_DYNAMIC_TILES = 0, 1, 2, 3, 4
 TP_TUNE_Q_SIDE_STREAM = 5
+TP_WGRAD_X_TRANSPOSED = 1
 TP_NUM_STAGES = 10
 STAGE_NAMES = ("point_queries", "kv_layer0_gelu", "kv_layer2_stats", "kv_inproj_lnfold", "q_proj_1_stats",
                "q_inproj_lnfold", "region_attention", "out_proj", "mlp0_gelu", "mlp2")
@@ -150,7 +151,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.tp_wgrad_workspace_bytes.argtypes = [c_int, c_int]
     lib.tp_wgrad.restype = c_int
     lib.tp_wgrad.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int64, c_int, c_int, c_int, c_void_p,
-                             c_int, c_void_p, c_size_t, c_void_p]
+                             c_int, c_int, c_void_p, c_size_t, c_void_p]
     lib.tp_hd_slice.restype = c_int
     lib.tp_hd_slice.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]
     lib.tp_test_occupy_cus.restype = c_int

@@ -79,11 +79,14 @@ constexpr int G8_DEPTH = 3;                        // DMA groups left in flight 
 //            k permutation on both operands, so the contraction is unchanged).  Chunk slots are XOR-ed with the
 //            k-quad's parity so that the two lane groups an LDS cycle serves hit different bank halves.  Rows past
 //            the end of the contraction range read as zero (descriptor range check, rebuilt per K-tile).
+//        4 = A K-major as in 3, W K-contiguous as in 0 (a weight gradient whose activation operand had to be
+//            transposed anyway — cast, LayerNorm applied — while dY is read in place)
 template <typename TI, typename TO, int AMODE, bool PERSIST, bool TRAIN_EPI>
 __global__ void __launch_bounds__(512, 2)
 gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int xcd_swizzle) {
     using X8 = typename Vec<TI>::x8;
     constexpr int BM = G8_BM, BN = G8_BN, WM = G8_WM, WN = G8_WN;
+    constexpr bool A_KMAJOR = (AMODE == 3 || AMODE == 4), W_KMAJOR = (AMODE == 3);
     constexpr int FM = WM / 16, FN = WN / 16;          // 8 x 4 accumulator fragments per wave
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -141,9 +144,9 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         const int tm = Lt / tiles_n;
         tile_n = Lt - tm * tiles_n;
         m0 = tm * BM; n0 = tile_n * BN;
-        if constexpr (AMODE == 3) {
-            // per-lane source offsets of DMA instruction idx = 2 wave + q of a group: k rows 4 idx .. 4 idx + 3, chunk
-            // slot lane / 8 holds column block (lane / 8) ^ q, row (lane % 8) / 2, 16-byte half lane % 2
+        // K-major operands: per-lane source offsets of DMA instruction idx = 2 wave + q of a group — k rows 4 idx ..
+        // 4 idx + 3, chunk slot lane / 8 holds column block (lane / 8) ^ (wave & 1), row (lane % 8) / 2, half lane % 2
+        if constexpr (W_KMAJOR) {
             tt_w_base = p.W + g * p.w_gs;
             int n_loc = n0;
             if (p.W_parts[0]) {                         // N split over four source tensors (hidden states, no torch.cat)
@@ -153,34 +156,38 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
             }
             tt_w_base += (long long)n_loc * 2;
             tt_n_loc_bytes = n_loc * 2;
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int krow = 4 * (2 * wave + q) + ((lane & 7) >> 1);
-                    const int cb = (lane >> 3) ^ q;
-                    const int acol = (cb >> 2) * 128 + sub * 64 + (cb & 3) * 16 + (lane & 1) * 8;
-                    const int wcol = (cb >> 1) * 64 + sub * 32 + (cb & 1) * 16 + (lane & 1) * 8;
-                    voff_a[sub][q] = (int)(krow * p.lda_bytes) + acol * 2;
-                    voff_w[sub][q] = (int)(krow * ldw) + wcol * 2;
-                }
-            return;
+        } else {
+            rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + g * p.w_gs + (long long)n0 * ldw), 0, 0x7fffffff,
+                                                       0x00020000);
         }
-        const long long a_tile_off = a_row_off(m0);
-        rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + g * p.a_gs + a_tile_off), 0, 0x7fffffff, 0x00020000);
-        a_tile_off_cur = a_tile_off;
-        rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + g * p.w_gs + (long long)n0 * ldw), 0, 0x7fffffff,
-                                                   0x00020000);
+        long long a_tile_off = 0;
+        if constexpr (!A_KMAJOR) {
+            a_tile_off = a_row_off(m0);
+            rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + g * p.a_gs + a_tile_off), 0, 0x7fffffff, 0x00020000);
+            a_tile_off_cur = a_tile_off;
+        }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int rho = 16 * wave + 8 * q + (lane >> 3);
-                int row = m0 + (rho >> 6) * 128 + sub * 64 + (rho & 63);
-                row = row < p.M ? row : p.M - 1;
-                voff_a[sub][q] = (int)(a_row_off(row) - a_tile_off) + kslot * 16;
-                const int col = (rho >> 5) * 64 + sub * 32 + (rho & 31);
-                voff_w[sub][q] = (int)(col * ldw) + kslot * 16;
+                const int krow = 4 * (2 * wave + q) + ((lane & 7) >> 1);        // K-major forms
+                const int cb = (lane >> 3) ^ (wave & 1);
+                const int rho = 16 * wave + 8 * q + (lane >> 3);                // K-contiguous forms
+                if constexpr (A_KMAJOR) {
+                    const int acol = (cb >> 2) * 128 + sub * 64 + (cb & 3) * 16 + (lane & 1) * 8;
+                    voff_a[sub][q] = (int)(krow * p.lda_bytes) + acol * 2;
+                } else {
+                    int row = m0 + (rho >> 6) * 128 + sub * 64 + (rho & 63);
+                    row = row < p.M ? row : p.M - 1;
+                    voff_a[sub][q] = (int)(a_row_off(row) - a_tile_off) + kslot * 16;
+                }
+                if constexpr (W_KMAJOR) {
+                    const int wcol = (cb >> 1) * 64 + sub * 32 + (cb & 1) * 16 + (lane & 1) * 8;
+                    voff_w[sub][q] = (int)(krow * ldw) + wcol * 2;
+                } else {
+                    const int col = (rho >> 5) * 64 + sub * 32 + (rho & 31);
+                    voff_w[sub][q] = (int)(col * ldw) + kslot * 16;
+                }
             }
     };
 
@@ -190,7 +197,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         constexpr bool is_a = (grp == 0 || grp == 3);
         constexpr int sub = (grp == 2 || grp == 3) ? 1 : 0;
         char* dst = smem + (kt & 1) * G8_BUF + grp * G8_GROUP + wave * 2048;
-        if constexpr (AMODE == 3) {
+        if constexpr (is_a ? A_KMAJOR : W_KMAJOR) {
             // K-tile kt = contraction rows r0 .. r0 + 63 of this group's range; the descriptor starts at the tile's
             // first column of row r0 and ends after the last valid row (soffset is not range-checked, so K advances
             // through the base address)
@@ -263,24 +270,25 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
     X8 fa[4][2];            // A fragments of the current M-quadrant  [i][k-half]
     X8 fb[2][2][2];         // W fragments                            [b][j][k-half]
 
-    // AMODE 3 fragment reads.  Column block cb (16 columns) of a group, 32-k step kh -> two transposing reads (k 0..15
-    // and 16..31 of the step).  Per-lane base = the lane group's k-quad (rows 4g..4g+3 of a 16-k block = DMA block g of
-    // that k block) + this wave's first column block + the slot XOR (+/- 128 B for odd k-quads, by the block's parity).
+    // K-major fragment reads.  Column block cb (16 columns) of a group, 32-k step kh -> two transposing reads: lane
+    // group g takes k-quads 2g and 2g + 1 of the step (DMA blocks 8 kh + 2g, + 1), i.e. k = 8g .. 8g + 7 — the very k
+    // a lane holds in the K-contiguous layout, so a K-major A can meet a K-contiguous W in one MFMA.  Per-lane base =
+    // that DMA block + this wave's first column block + the slot XOR (+/- 128 B for odd g, by the block's parity).
     // The reads are inline asm: hipcc guards the ds_read_tr builtin with s_waitcnt vmcnt(0) whenever an LDS-DMA is in
     // flight (it cannot tell that the ring regions differ), which would drain the queue every phase.  Nothing touches
     // the destination registers before the phase's own s_waitcnt lgkmcnt(0).
     const int tt_g = lane >> 4, tt_c = (lane & 15) * 8;
-    const int tt_a_even = tt_g * 1024 + tt_c + (tt_g & 1) * 128 + wm * 512;
-    const int tt_a_odd = tt_g * 1024 + tt_c - (tt_g & 1) * 128 + wm * 512;
-    const int tt_w_even = tt_g * 1024 + tt_c + (tt_g & 1) * 128 + wn * 256;
-    const int tt_w_odd = tt_g * 1024 + tt_c - (tt_g & 1) * 128 + wn * 256;
+    const int tt_a_even = tt_g * 2048 + tt_c + (tt_g & 1) * 128 + wm * 512;
+    const int tt_a_odd = tt_g * 2048 + tt_c - (tt_g & 1) * 128 + wm * 512;
+    const int tt_w_even = tt_g * 2048 + tt_c + (tt_g & 1) * 128 + wn * 256;
+    const int tt_w_odd = tt_g * 2048 + tt_c - (tt_g & 1) * 128 + wn * 256;
     auto tt_read = [&](const unsigned addr, auto OFF_) __attribute__((always_inline)) -> X8 {
         constexpr int OFF = decltype(OFF_)::value;
         typedef int i32x2 __attribute__((ext_vector_type(2)));
         typedef int i32x4 __attribute__((ext_vector_type(4)));
         i32x2 lo, hi;
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(OFF));
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(OFF + 4096));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(OFF + 1024));
         return __builtin_bit_cast(X8, (i32x4)__builtin_shufflevector(lo, hi, 0, 1, 2, 3));
     };
     // A fragments i = 0..3 of group GRP into fa[i][kh], W fragments j = 0, 1 of group GRP into fb[B][j][kh]
@@ -320,22 +328,24 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         constexpr int WAIT = decltype(WAIT_)::value;
         const char* sb = smem + (t & 1) * G8_BUF;
         // -- memory segment ---------------------------------------------------------------------------
-        if constexpr (AMODE == 3) {
-            const unsigned ring = (unsigned)(t & 1) * G8_BUF;       // (dynamic LDS starts at address 0: no static __shared__)
-            if constexpr (P == 0) { tt_read_w(ring, I1{}, I0{}); tt_read_a(ring, I0{}); }
-            else if constexpr (P == 1) tt_read_w(ring, I2{}, I1{});
-            else if constexpr (P == 2) tt_read_a(ring, I3{});
-        } else if constexpr (P == 0) {
+        const unsigned ring = (unsigned)(t & 1) * G8_BUF;           // (dynamic LDS starts at address 0: no static __shared__)
+        if constexpr (P == 0 || P == 1) {                           // W fragments of b0 (group 1) / b1 (group 2)
+            constexpr int B = P;
+            if constexpr (W_KMAJOR) {
+                if constexpr (P == 0) tt_read_w(ring, I1{}, I0{}); else tt_read_w(ring, I2{}, I1{});
+            } else {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) { fb[0][j][0] = read_w(sb, 1, j, 0); fb[0][j][1] = read_w(sb, 1, j, 1); }
+                for (int j = 0; j < 2; ++j) { fb[B][j][0] = read_w(sb, 1 + B, j, 0); fb[B][j][1] = read_w(sb, 1 + B, j, 1); }
+            }
+        }
+        if constexpr (P == 0 || P == 2) {                           // A fragments of a0 (group 0) / a1 (group 3)
+            constexpr int GA = P == 0 ? 0 : 3;
+            if constexpr (A_KMAJOR) {
+                if constexpr (P == 0) tt_read_a(ring, I0{}); else tt_read_a(ring, I3{});
+            } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { fa[i][0] = read_a(sb, 0, i, 0); fa[i][1] = read_a(sb, 0, i, 1); }
-        } else if constexpr (P == 1) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) { fb[1][j][0] = read_w(sb, 2, j, 0); fb[1][j][1] = read_w(sb, 2, j, 1); }
-        } else if constexpr (P == 2) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { fa[i][0] = read_a(sb, 3, i, 0); fa[i][1] = read_a(sb, 3, i, 1); }
+                for (int i = 0; i < 4; ++i) { fa[i][0] = read_a(sb, GA, i, 0); fa[i][1] = read_a(sb, GA, i, 1); }
+            }
         }
         if constexpr (ISSUE) {
             if constexpr (P == 0) issue(I2{}, t + 1);
@@ -535,7 +545,8 @@ static int launch8_var(const GemmArgs& a, hipStream_t stream) {
     constexpr bool HALF_OUT = !std::is_same<TO, float>::value;
     const bool train_epi = (a.flags & (TP_LINEAR_SAVE_PRE | TP_LINEAR_GELU_BWD)) != 0;
     if (a.tt_rows > 0) {                                // K-major operands (weight gradients): fp32 partials only
-        if constexpr (std::is_same<TO, float>::value && PERSIST) return launch8_cfg<TI, TO, 3, PERSIST, false>(a, stream);
+        if constexpr (std::is_same<TO, float>::value && PERSIST)
+            return a.tt_w_kcontig ? launch8_cfg<TI, TO, 4, PERSIST, false>(a, stream) : launch8_cfg<TI, TO, 3, PERSIST, false>(a, stream);
         set_error("tp gemm8: K-major operands are supported with fp32 output on the persistent kernel only");
         return TP_ERR_INVALID_ARG;
     }

@@ -56,6 +56,7 @@ struct GemmArgs {
     // w_batch_stride_bytes between batches (tt_bmagic = ceil(2^32 / tt_tpb); 0 = one batch), and its N columns may be
     // split over W_parts[4] tensors of n_part columns each.
     long long tt_rows;
+    int tt_w_kcontig;                 // 1: only A is K-major; W is an ordinary K-contiguous [N, K] operand (ldw_bytes, w_gs)
     long long w_batch_stride_bytes;
     unsigned tt_bmagic; int tt_tpb;
     const char* W_parts[4];
@@ -143,6 +144,8 @@ int wgrad_tt_launch(int dtype, const void* dY, long long ldy, const WgradX& X, l
                     float* part, size_t part_bytes, int out_dtype, void* grad_out, int* counters, hipStream_t stream,
                     void* grad_out_hi = nullptr, int split_row = 0);
 size_t wgrad_tt_part_bytes(int Nout, int Kin);
+int wgrad_tn_launch(int dtype, const void* dY, long long ldy, const void* XT, long long rpad, long long R, int Nout, int Kin,
+                    float* part, size_t part_bytes, int out_dtype, void* grad_out, int* counters, hipStream_t stream);
 
 constexpr int kColsumMaxSlices = 512;              // row slices of the column-sum kernel: scratch = slices * C floats
 int bw_colsum_rows_launch(int dtype, const void* src, long long ld, long long R, int C, float* part, hipStream_t stream);

@@ -27,9 +27,9 @@ struct BwLayout {
     size_t wt_m2, wt_m0, wt_out, wt_in, wt_2;        // wt_in: [3][E,E] (q,k,v);  wt_2: [2][E,E] (k,v)
     size_t ln_g, ln_b;                                // [3][E] fp32 each (q,k,v)
     // coarse-token side
-    size_t dyT, a2T, dz2, dz2T, a1T, da1, da1T, oT, dO, dQ, dQT, q1T, dq1, dQ1pre, dQ1preT, q0T;
+    size_t dyT, a2T, dz2, dz2T, a1T, da1, oT, dO, dQ, q1T, dq1, dQ1pre, q0T;
     // fine-token side ([2] = k, v)
-    size_t dKV, dKVT, kv1T, dkv1, dH2, dH2T, hkvT, dZ1, dZ1T, xmT;
+    size_t dKV, kv1T, dkv1, dH2, hkvT, dZ1, dZ1T, xmT;
     size_t counters;                                  // tile-queue heads of the persistent GEMM launches (zeroed once)
     size_t part, colpart, lnpart;                     // fp32 partials: split-K wgrad, column sums, LN affine grads
     size_t redscratch;                                // stage-1 output of the many-parts reduction
@@ -50,11 +50,11 @@ static BwLayout bw_layout(int B, int grid, int s, int D) {
     L.wt_in = take(3 * E * E * 2); L.wt_2 = take(2 * E * E * 2);
     L.ln_g = take(3 * E * 4); L.ln_b = take(3 * E * 4);
     L.dyT = take(D * Rqp * 2); L.a2T = take(D * Rqp * 2); L.dz2 = take(Rq * D * 2); L.dz2T = take(D * Rqp * 2);
-    L.a1T = take(E * Rqp * 2); L.da1 = take(Rq * E * 2); L.da1T = take(E * Rqp * 2); L.oT = take(E * Rqp * 2);
-    L.dO = take(Rq * E * 2); L.dQ = take(Rq * E * 2); L.dQT = take(E * Rqp * 2); L.q1T = take(E * Rqp * 2);
-    L.dq1 = take(Rq * E * 2); L.dQ1pre = take(Rq * E * 2); L.dQ1preT = take(E * Rqp * 2); L.q0T = take(E * Rqp * 2);
-    L.dKV = take(2 * R * E * 2); L.dKVT = take(2 * E * Rp * 2); L.kv1T = take(2 * E * Rp * 2); L.dkv1 = take(2 * R * E * 2);
-    L.dH2 = take(2 * R * E * 2); L.dH2T = take(2 * E * Rp * 2); L.hkvT = take(2 * E * Rp * 2);
+    L.a1T = take(E * Rqp * 2); L.da1 = take(Rq * E * 2); L.oT = take(E * Rqp * 2);
+    L.dO = take(Rq * E * 2); L.dQ = take(Rq * E * 2); L.q1T = take(E * Rqp * 2);
+    L.dq1 = take(Rq * E * 2); L.dQ1pre = take(Rq * E * 2); L.q0T = take(E * Rqp * 2);
+    L.dKV = take(2 * R * E * 2); L.kv1T = take(2 * E * Rp * 2); L.dkv1 = take(2 * R * E * 2);
+    L.dH2 = take(2 * R * E * 2); L.hkvT = take(2 * E * Rp * 2);
     L.dZ1 = take(R * 2 * E * 2); L.dZ1T = take(2 * E * Rp * 2); L.xmT = take((size_t)kMulti * Rp * 2);
     // split-K partials: S splits of an [Nout, Kin] weight with S * tiles(256^2) <= ~512
     size_t wmax = (size_t)D * D;
@@ -121,6 +121,29 @@ int wgrad_tt_launch(int dtype, const void* dY, long long ldy, const WgradX& X, l
                                   (long long)(Nout - split_row) * Kin, grad_out_hi, stream);
 }
 
+// dW[Nout, Kin] = dY^T · X with dY [R, Nout] read in place (K-major) and X given TRANSPOSED, XT [Kin, rpad] (zero beyond
+// column R; rpad a multiple of 1024): the operand a cast / LayerNorm pass had to rewrite anyway.
+int wgrad_tn_launch(int dtype, const void* dY, long long ldy, const void* XT, long long rpad, long long R, int Nout, int Kin,
+                    float* part, size_t part_bytes, int out_dtype, void* grad_out, int* counters, hipStream_t stream) {
+    if (R <= 0 || Nout <= 0 || Kin % 256 != 0 || Nout % 8 != 0 || ldy % 8 != 0 || rpad % 1024 != 0 || rpad < R) {
+        set_error("tp wgrad: unsupported shape R=%lld rpad=%lld Nout=%d Kin=%d", R, rpad, Nout, Kin);
+        return TP_ERR_INVALID_ARG;
+    }
+    const long long tiles = (long long)((Nout + 255) / 256) * (Kin / 256);
+    int S = 1;
+    while (S < 16 && tiles * S < 256 && (rpad / (S * 2)) % 64 == 0 && rpad / (S * 2) >= 256) S *= 2;
+    if ((size_t)S * Nout * Kin * 4 > part_bytes) { set_error("tp wgrad: split partial buffer too small"); return TP_ERR_WORKSPACE; }
+    const long long Ks = rpad / S;
+    GemmArgs a{};
+    a.A = (const char*)dY; a.lda_bytes = ldy * 2; a.a_gs = Ks * ldy * 2;
+    a.W = (const char*)XT; a.ldw_bytes = rpad * 2; a.w_gs = Ks * 2;
+    a.C = (char*)part; a.ldc = Kin; a.c_gs = (long long)Nout * Kin * 4;
+    a.M = Nout; a.N = Kin; a.K = (int)Ks; a.groups = S; a.tt_rows = R; a.tt_w_kcontig = 1; a.rows_per_batch = Nout; a.tile = 256;
+    a.tile_counters = S <= 4 ? counters : nullptr;
+    TP_TRY(gemm_launch(dtype, TP_F32, a, stream));
+    return bw_reduce_parts_launch(out_dtype, part, (long long)Nout * Kin, S, (long long)Nout * Kin, grad_out, stream);
+}
+
 }  // namespace tp
 
 using namespace tp;
@@ -134,7 +157,7 @@ size_t tp_wgrad_workspace_bytes(int n_out, int k_in) {
 }
 
 int tp_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, int x_rows_per_batch, int64_t x_batch_stride,
-             int64_t rows, int n_out, int k_in, int dtype, void* dw, int out_dtype, void* workspace,
+             int64_t rows, int n_out, int k_in, int dtype, void* dw, int out_dtype, int flags, void* workspace,
              size_t workspace_bytes, void* stream) {
     if (!dy || !x || !dw || !workspace) { set_error("tp_wgrad: NULL argument"); return TP_ERR_INVALID_ARG; }
     if ((dtype != TP_BF16 && dtype != TP_F16) || (out_dtype != TP_BF16 && out_dtype != TP_F16 && out_dtype != TP_F32)) {
@@ -145,6 +168,10 @@ int tp_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, int x_rows
         set_error("tp_wgrad: dy / x / dw must be 16-byte aligned, the workspace 256-byte aligned");
         return TP_ERR_INVALID_ARG;
     }
+    if (flags & ~TP_WGRAD_X_TRANSPOSED) { set_error("tp_wgrad: unknown flags %d", flags); return TP_ERR_INVALID_ARG; }
+    if (flags & TP_WGRAD_X_TRANSPOSED)
+        return wgrad_tn_launch(dtype, dy, ldy, x, ldx, rows, n_out, k_in, (float*)workspace, workspace_bytes, out_dtype, dw,
+                               nullptr, (hipStream_t)stream);
     WgradX X{x, ldx, x_rows_per_batch, x_batch_stride, nullptr, 0};
     return wgrad_tt_launch(dtype, dy, ldy, X, rows, n_out, k_in, (float*)workspace, workspace_bytes, out_dtype, dw, nullptr,
                            (hipStream_t)stream);
@@ -257,6 +284,27 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
         return bw_reduce_parts_launch(GT, part, (long long)Nout * Kin, S, (long long)Nout * Kin, grad_out, stream);
     };
 
+    // The same from dY in place (K-major GEMM operand, no dY^T): bias gradient by a column-sum pass over dY, weight
+    // gradient with the activation operand either in place as well (`X` row-major in the model dtype) or transposed
+    // (`XT` [Kin, rpad]: fp16 activations of a bf16 model are cast, LayerNorm inputs normalised, by that transpose).
+    auto next_counters = [&]() -> int* { return (counters && launch_no < 64) ? counters + 32 * launch_no++ : nullptr; };
+    auto bias_grad_rows = [&](const void* dY, long long ldy, long long rows, int cols, void* out) -> int {
+        const int slices = bw_colsum_rows_launch(GT, dY, ldy, rows, cols, colpart, stream);
+        if (slices < 0) return slices;
+        return bw_reduce_many_parts_launch(GT, colpart, cols, slices, cols, out, redscratch, stream);
+    };
+    auto wgrad_rows = [&](const void* dY, long long ldy, long long rows, int rpad, int Nout, int Kin, const void* X, long long ldx,
+                          int x_dtype, char* XT_scratch, void* grad_out, const float* mr = nullptr, const float* gam = nullptr,
+                          const float* bet = nullptr) -> int {
+        const WgradX XR{X, ldx, 0, 0, nullptr, 0};
+        if (x_dtype == GT && !mr && wgrad_tt_supported(rows, Nout, Kin, XR, ldy))
+            return wgrad_tt_launch(GT, dY, ldy, XR, rows, Nout, Kin, part, L.part_bytes, GT, grad_out, next_counters(), stream);
+        TP_TRY(T(x_dtype, X, ldx, (int)rows, Kin, XT_scratch, rpad, mr, gam, bet));
+        return wgrad_tn_launch(GT, dY, ldy, XT_scratch, rpad, rows, Nout, Kin, part, L.part_bytes, GT, grad_out, next_counters(),
+                               stream);
+    };
+    const bool inplace = (D % 256 == 0);                // (E = 1024 always is): every weight's Kin is a multiple of 256
+
     // ---- operands the backward needs in its own layout --------------------------------------------------------
     // transposed weights (model dtype): W [out, in] -> W^T [in, out]
     TP_TRY(T(GT, raw->mlp_2_weight, D, D, D, bw + L.wt_m2, D));
@@ -276,22 +324,30 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
     }
 
     // ---- mlp[2] ---------------------------------------------------------------------------------------------
-    TP_TRY(T(GT, dy, D, Rq, D, bw + L.dyT, Rqp, nullptr, nullptr, nullptr, colpart));
-    TP_TRY(bias_grad(Rqp, D, grads->mlp_2_bias));
-    TP_TRY(T(TP_F16, fw + W.a2, D, Rq, D, bw + L.a2T, Rqp));
-    TP_TRY(wgrad(bw + L.dyT, bw + L.a2T, D, D, Rqp, grads->mlp_2_weight));
+    if (inplace) {
+        TP_TRY(bias_grad_rows(dy, D, Rq, D, grads->mlp_2_bias));
+        TP_TRY(wgrad_rows(dy, D, Rq, Rqp, D, D, fw + W.a2, D, TP_F16, bw + L.a2T, grads->mlp_2_weight));
+    } else {
+        TP_TRY(T(GT, dy, D, Rq, D, bw + L.dyT, Rqp, nullptr, nullptr, nullptr, colpart));
+        TP_TRY(bias_grad(Rqp, D, grads->mlp_2_bias));
+        TP_TRY(T(TP_F16, fw + W.a2, D, Rq, D, bw + L.a2T, Rqp));
+        TP_TRY(wgrad(bw + L.dyT, bw + L.a2T, D, D, Rqp, grads->mlp_2_weight));
+    }
     TP_TRY(dgrad(dy, D, Rq, D, bw + L.wt_m2, D, bw + L.dz2, D, TP_LINEAR_GELU_BWD, fw + W.z2, D));
     // ---- mlp[0] ---------------------------------------------------------------------------------------------
-    TP_TRY(T(GT, bw + L.dz2, D, Rq, D, bw + L.dz2T, Rqp, nullptr, nullptr, nullptr, colpart));
-    TP_TRY(bias_grad(Rqp, D, grads->mlp_0_bias));
-    TP_TRY(T(TP_F16, fw + W.a1, E, Rq, E, bw + L.a1T, Rqp));
-    TP_TRY(wgrad(bw + L.dz2T, bw + L.a1T, D, E, Rqp, grads->mlp_0_weight));
+    if (inplace) {
+        TP_TRY(bias_grad_rows(bw + L.dz2, D, Rq, D, grads->mlp_0_bias));
+        TP_TRY(wgrad_rows(bw + L.dz2, D, Rq, Rqp, D, E, fw + W.a1, E, TP_F16, bw + L.a1T, grads->mlp_0_weight));
+    } else {
+        TP_TRY(T(GT, bw + L.dz2, D, Rq, D, bw + L.dz2T, Rqp, nullptr, nullptr, nullptr, colpart));
+        TP_TRY(bias_grad(Rqp, D, grads->mlp_0_bias));
+        TP_TRY(T(TP_F16, fw + W.a1, E, Rq, E, bw + L.a1T, Rqp));
+        TP_TRY(wgrad(bw + L.dz2T, bw + L.a1T, D, E, Rqp, grads->mlp_0_weight));
+    }
     TP_TRY(dgrad(bw + L.dz2, D, Rq, D, bw + L.wt_m0, E, bw + L.da1, E));
     // ---- out_proj ---------------------------------------------------------------------------------------------
-    TP_TRY(T(GT, bw + L.da1, E, Rq, E, bw + L.da1T, Rqp, nullptr, nullptr, nullptr, colpart));
-    TP_TRY(bias_grad(Rqp, E, grads->clip_attn_out_proj_bias));
-    TP_TRY(T(TP_F16, fw + W.o, E, Rq, E, bw + L.oT, Rqp));
-    TP_TRY(wgrad(bw + L.da1T, bw + L.oT, E, E, Rqp, grads->clip_attn_out_proj_weight));
+    TP_TRY(bias_grad_rows(bw + L.da1, E, Rq, E, grads->clip_attn_out_proj_bias));
+    TP_TRY(wgrad_rows(bw + L.da1, E, Rq, Rqp, E, E, fw + W.o, E, TP_F16, bw + L.oT, grads->clip_attn_out_proj_weight));
     TP_TRY(dgrad(bw + L.da1, E, Rq, E, bw + L.wt_out, E, bw + L.dO, E));
     // ---- region attention ---------------------------------------------------------------------------------------
     TP_TRY(bw_region_attention_launch(GT, fw + W.q, fw + W.kv, fw + W.kv + kvE * 2, bw + L.dO, bw + L.dQ, bw + L.dKV,
@@ -300,21 +356,17 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
     char* g_inw = (char*)grads->clip_attn_in_proj_weight;
     char* g_inb = (char*)grads->clip_attn_in_proj_bias;
     //   q
-    TP_TRY(T(GT, bw + L.dQ, E, Rq, E, bw + L.dQT, Rqp, nullptr, nullptr, nullptr, colpart));
-    TP_TRY(bias_grad(Rqp, E, g_inb));
-    TP_TRY(T(TP_F16, fw + W.q1pre, E, Rq, E, bw + L.q1T, Rqp, (const float*)(fw + W.mr_q), ln_g, ln_b));
-    TP_TRY(wgrad(bw + L.dQT, bw + L.q1T, E, E, Rqp, g_inw));
+    TP_TRY(bias_grad_rows(bw + L.dQ, E, Rq, E, g_inb));
+    TP_TRY(wgrad_rows(bw + L.dQ, E, Rq, Rqp, E, E, fw + W.q1pre, E, TP_F16, bw + L.q1T, g_inw, (const float*)(fw + W.mr_q), ln_g, ln_b));
     TP_TRY(dgrad(bw + L.dQ, E, Rq, E, bw + L.wt_in, E, bw + L.dq1, E));
     //   k, v
     for (int t = 0; t < 2; ++t) {
         const char* dX = bw + L.dKV + (size_t)t * kvE * 2;
-        char* dXT = bw + L.dKVT + (size_t)t * E * Rp * 2;
         char* x1T = bw + L.kv1T + (size_t)t * E * Rp * 2;
         const float* mr = (const float*)(fw + W.mr_kv) + (size_t)t * R * 2;
-        TP_TRY(T(GT, dX, E, R, E, dXT, Rp, nullptr, nullptr, nullptr, colpart));
-        TP_TRY(bias_grad(Rp, E, g_inb + (size_t)(1 + t) * E * 2));
-        TP_TRY(T(TP_F16, fw + W.h2 + (size_t)t * kvE * 2, E, R, E, x1T, Rp, mr, ln_g + (1 + t) * E, ln_b + (1 + t) * E));
-        TP_TRY(wgrad(dXT, x1T, E, E, Rp, g_inw + (size_t)(1 + t) * E * E * 2));
+        TP_TRY(bias_grad_rows(dX, E, R, E, g_inb + (size_t)(1 + t) * E * 2));
+        TP_TRY(wgrad_rows(dX, E, R, Rp, E, E, fw + W.h2 + (size_t)t * kvE * 2, E, TP_F16, x1T, g_inw + (size_t)(1 + t) * E * E * 2,
+                          mr, ln_g + (1 + t) * E, ln_b + (1 + t) * E));
         TP_TRY(dgrad(dX, E, R, E, bw + L.wt_in + (size_t)(1 + t) * E * E * 2, E, bw + L.dkv1 + (size_t)t * kvE * 2, E));
     }
     // ---- LayerNorms ---------------------------------------------------------------------------------------------
@@ -335,21 +387,16 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
         }
     }
     // ---- q_proj_1 (no bias) ---------------------------------------------------------------------------------------
-    TP_TRY(T(GT, bw + L.dQ1pre, E, Rq, E, bw + L.dQ1preT, Rqp));
-    TP_TRY(T(TP_F16, fw + W.q0, E, Rq, E, bw + L.q0T, Rqp));
-    TP_TRY(wgrad(bw + L.dQ1preT, bw + L.q0T, E, E, Rqp, grads->q_proj_1_weight));
+    TP_TRY(wgrad_rows(bw + L.dQ1pre, E, Rq, Rqp, E, E, fw + W.q0, E, TP_F16, bw + L.q0T, grads->q_proj_1_weight));
     // ---- k/v_proj_1[2] -----------------------------------------------------------------------------------------------
     {
         void* gw[2] = {grads->k_proj_1_2_weight, grads->v_proj_1_2_weight};
         void* gb[2] = {grads->k_proj_1_2_bias, grads->v_proj_1_2_bias};
         for (int t = 0; t < 2; ++t) {
             const char* dH = bw + L.dH2 + (size_t)t * kvE * 2;
-            char* dHT = bw + L.dH2T + (size_t)t * E * Rp * 2;
             char* hT = bw + L.hkvT + (size_t)t * E * Rp * 2;
-            TP_TRY(T(GT, dH, E, R, E, dHT, Rp, nullptr, nullptr, nullptr, colpart));
-            TP_TRY(bias_grad(Rp, E, gb[t]));
-            TP_TRY(T(TP_F16, fw + W.hkv + (size_t)t * E * 2, 2 * E, R, E, hT, Rp));
-            TP_TRY(wgrad(dHT, hT, E, E, Rp, gw[t]));
+            TP_TRY(bias_grad_rows(dH, E, R, E, gb[t]));
+            TP_TRY(wgrad_rows(dH, E, R, Rp, E, E, fw + W.hkv + (size_t)t * E * 2, 2 * E, TP_F16, hT, gw[t]));
             TP_TRY(dgrad(dH, E, R, E, bw + L.wt_2 + (size_t)t * E * E * 2, E, bw + L.dZ1 + (size_t)t * E * 2, 2 * E,
                          TP_LINEAR_GELU_BWD, fw + W.z1 + (size_t)t * E * 2, 2 * E));
         }

@@ -41,16 +41,25 @@ def main():
 
         def ours():
             assert lib.tp_wgrad(dy.data_ptr(), N, x.data_ptr(), K, 0, 0, R, N, K, _capi.TP_BF16, dw.data_ptr(), _capi.TP_BF16,
-                                ws.data_ptr(), ws.numel(), st) == 0
+                                0, ws.data_ptr(), ws.numel(), st) == 0
+
+        rpad = (R + 1023) // 1024 * 1024
+        xt = torch.zeros(K, rpad, dtype=torch.bfloat16, device="cuda")
+        xt[:, :R] = x.t()
+
+        def ours_tn():
+            assert lib.tp_wgrad(dy.data_ptr(), N, xt.data_ptr(), rpad, 0, 0, R, N, K, _capi.TP_BF16, dw.data_ptr(), _capi.TP_BF16,
+                                _capi.TP_WGRAD_X_TRANSPOSED, ws.data_ptr(), ws.numel(), st) == 0
 
         ms = timed(ours)
+        ms_tn = timed(ours_tn)
         ms_t = timed(lambda: torch.matmul(dy.t(), x))
         fl = 2.0 * R * N * K
         row = {"shape": name, "rows": R, "n_out": N, "k_in": K, "tp_wgrad_ms": round(ms, 4), "tp_wgrad_tflops": round(fl / ms / 1e9, 1),
-               "torch_tn_ms": round(ms_t, 4), "torch_tn_tflops": round(fl / ms_t / 1e9, 1)}
+               "tp_wgrad_xT_ms": round(ms_tn, 4), "torch_tn_ms": round(ms_t, 4), "torch_tn_tflops": round(fl / ms_t / 1e9, 1)}
         print(json.dumps(row), flush=True)
         out.append(row)
-        del dy, x, dw, ws
+        del dy, x, dw, ws, xt
     if len(sys.argv) > 1:
         json.dump(out, open(sys.argv[1], "w"), indent=1)
 
