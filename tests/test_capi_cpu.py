@@ -108,3 +108,7 @@ def test_train_hd_and_parts_entry_points_reject_bad_arguments():
     assert lib.tp_hd_assemble(plan, 1, None, None, None, None, 144, 256, _capi.TP_BF16, None) == E
     assert lib.tp_hd_slice(None, 100, 100, 1, 1, 336, 336, 0, 0, None, 336, None) == E
     assert lib.tp_test_occupy_cus(0, 1, None, None) == E
+    # the weight-gradient contraction on its own
+    assert lib.tp_wgrad_workspace_bytes(1024, 4096) == 16 * 1024 * 4096 * 4
+    assert lib.tp_wgrad_workspace_bytes(0, 4096) == 0
+    assert lib.tp_wgrad(None, 1024, None, 4096, 0, 0, 4096, 1024, 4096, _capi.TP_BF16, None, _capi.TP_F32, 0, None, 0, None) == E

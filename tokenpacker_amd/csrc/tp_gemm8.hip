@@ -328,7 +328,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         constexpr int WAIT = decltype(WAIT_)::value;
         const char* sb = smem + (t & 1) * G8_BUF;
         // -- memory segment ---------------------------------------------------------------------------
-        const unsigned ring = (unsigned)(t & 1) * G8_BUF;           // (dynamic LDS starts at address 0: no static __shared__)
+        const unsigned ring = (unsigned)(size_t)(lds_void*)smem + (unsigned)(t & 1) * G8_BUF;   // LDS byte address
         if constexpr (P == 0 || P == 1) {                           // W fragments of b0 (group 1) / b1 (group 2)
             constexpr int B = P;
             if constexpr (W_KMAJOR) {
