@@ -86,3 +86,37 @@ def test_input_gradients_are_refused():
     xm = torch.zeros(1, 576, 4096, device="cuda", dtype=torch.bfloat16)
     with pytest.raises(NotImplementedError):
         m((x, xm))
+
+
+@pytest.mark.parametrize("grid,s,B", [(16, 2, 3), (16, 4, 5), (12, 3, 2), (8, 2, 7)])
+def test_other_grids_forward_and_gradients(grid, s, B):
+    """Grids other than CLIP-L/336's 24x24: 16x16 (256 tokens per image, a multiple of 64 -> the k/v_proj_1[0] weight
+    gradient reads x_multi in place, batch-strided) and 12x12 / 8x8 (144 / 64 tokens -> the transposed-copy path)."""
+    dtype, D, seed = torch.bfloat16, 256, 77 + grid
+    N, M = grid * grid, (grid // s) ** 2
+    params = synth.make_params(seed, D)
+    g = torch.Generator().manual_seed(seed)
+    hidden = torch.randn(B, N + 1, 4096, generator=g).to(dtype)          # CLS-prefixed, as the tower hands it over
+    xm = hidden[:, 1:]
+    x = torch.randn(B, N, 1024, generator=g).to(dtype)
+    w = torch.randn(B, M, D, generator=g).to(dtype)
+    p_lp = {k: v.to(dtype) for k, v in params.items()}
+
+    m = TokenPacker(raw_grid=grid, hidden_size=D, scale_factor=s)
+    m.load_state_dict(params)
+    m = m.to(device="cuda", dtype=dtype).train()
+    y = m((x.cuda(), hidden.cuda()[:, 1:]))
+    (y.float() * w.cuda().float()).sum().backward()
+    torch.cuda.synchronize()
+
+    ref_p = {k: v.double().requires_grad_(True) for k, v in p_lp.items()}
+    y_ref = orc.forward(ref_p, x, xm, scale_factor=s, raw_grid=grid, compute_dtype=torch.float64, io_dtype=dtype)
+    (y_ref * w.double()).sum().backward()
+    assert orc.rel_err(y, y_ref.detach()) <= 2.0 ** -8
+    rms = {k: float(v.grad.norm()) / v.grad.numel() ** 0.5 for k, v in ref_p.items()}
+    for k, p in m.named_parameters():
+        want = ref_p[k].grad
+        got = p.grad.detach().double().cpu()
+        scale = max(rms[k], 0.1 * max(rms[j] for j in ref_p if ref_p[j].grad.shape == want.shape))
+        err = float((got - want).norm()) / want.numel() ** 0.5 / scale
+        assert err <= GATE_L2[dtype], (grid, s, k, err)
