@@ -37,9 +37,6 @@ transpose_kernel(const TS* __restrict__ src, long long ld, int rows_per_batch, l
     const int tr = threadIdx.x >> 2, seg = (threadIdx.x & 3) * 16;       // 64 rows x 4 segments of 16
     {
         const int r = r0 + tr;
-        float mu = 0.f, rs = 1.f;
-        const bool ln = mean_rstd != nullptr && r < R;
-        if (ln) { mu = mean_rstd[2 * (long long)r]; rs = mean_rstd[2 * (long long)r + 1]; }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int c = c0 + seg + h * 8;

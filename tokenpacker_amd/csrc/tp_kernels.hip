@@ -196,7 +196,11 @@ occupy_cus_kernel(long long cycles, int* sink) {
 int occupy_cus_launch(int blocks, int usec, int* sink, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_cus_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_cus_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                100 * 1024) != hipSuccess) {
+            set_error("occupy_cus: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+            return TP_ERR_LAUNCH;
+        }
         attr_set = true;
     }
     hipLaunchKernelGGL(occupy_cus_kernel, dim3(blocks), dim3(256), 100 * 1024, stream, (long long)usec * 2000, sink);   // s_memtime ticks at the shader clock (~2 GHz)
