@@ -180,7 +180,10 @@ int tp_region_attention(const tp_desc* desc, const void* q, const void* k, const
  * a LayerNorm that precedes the linear: C = rstd_m·(acc − mu_m·colsum_n) + bias_n, with
  * `row_mean_rstd` = fp32 [M][2] (mean, rstd) per row of A, produced by tp_ln_finalize().
  * With TP_LINEAR_ROW_STATS the kernel writes partial (sum, sum of squares) of ITS rounded output to `row_stats_out`
- * ([N/128][M][2]: one slab per 128 output columns; tp_linear_stats_parts() returns N/128). */
+ * ([N/128][M][2]: one slab per 128 output columns; tp_linear_stats_parts() returns N/128).
+ * One call addresses at most 4 GiB of output, (M + 256) * ldc * sizeof(element) < 2^32 (the stores go through a
+ * range-checked 32-bit buffer descriptor); larger problems are rejected with TP_ERR_INVALID_ARG — for the projector
+ * itself that is a batch of about 1800 images per call at hidden_size 4096. */
 enum {
     TP_LINEAR_GELU = 1,        /* exact erf GELU after bias (nn.GELU(), builder.py:63,69,81)      */
     TP_LINEAR_LN_FOLD = 2,
