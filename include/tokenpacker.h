@@ -182,8 +182,9 @@ int tp_region_attention(const tp_desc* desc, const void* q, const void* k, const
  * With TP_LINEAR_ROW_STATS the kernel writes partial (sum, sum of squares) of ITS rounded output to `row_stats_out`
  * ([N/128][M][2]: one slab per 128 output columns; tp_linear_stats_parts() returns N/128).
  * One call addresses at most 4 GiB of output, (M + 256) * ldc * sizeof(element) < 2^32 (the stores go through a
- * range-checked 32-bit buffer descriptor); larger problems are rejected with TP_ERR_INVALID_ARG — for the projector
- * itself that is a batch of about 1800 images per call at hidden_size 4096. */
+ * range-checked 32-bit buffer descriptor); larger problems are rejected with TP_ERR_INVALID_ARG.  tp_forward /
+ * tp_forward_parts split a batch beyond that bound (about 1800 images at hidden_size 4096) into consecutive chunks
+ * themselves — no operation mixes images, the result is bit-identical; the training entry points reject it. */
 enum {
     TP_LINEAR_GELU = 1,        /* exact erf GELU after bias (nn.GELU(), builder.py:63,69,81)      */
     TP_LINEAR_LN_FOLD = 2,

@@ -208,3 +208,24 @@ def test_errors_on_gpu_inputs():
     m.requires_grad_(True)
     with pytest.raises(NotImplementedError):                    # CLIP features come from a frozen tower: no input grads
         m((x.clone().requires_grad_(True), xm))
+
+
+def test_batches_beyond_the_4gib_launch_bound_are_chunked():
+    """A GEMM launch addresses at most 4 GiB of output; tp_forward serves larger batches as consecutive chunks of one
+    call.  s = 1 (576 coarse tokens), D = 5120, fp32 output puts the bound at 363 images: B = 400 must equal the two
+    halves run on their own, bit for bit."""
+    dtype, s, D, B = torch.bfloat16, 1, 5120, 400
+    params = synth.make_params(5, D)
+    m = TokenPacker(hidden_size=D, scale_factor=s)
+    m.load_state_dict(params)
+    m = m.to(device="cuda", dtype=dtype).eval().requires_grad_(False)
+    m.output_fp32 = True
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn(B, 576, 1024, device="cuda", generator=g).to(dtype)
+    xm = torch.randn(B, 576, 4096, device="cuda", generator=g).to(dtype)
+    with torch.no_grad():
+        y = m((x, xm))
+        ya, yb = m((x[:363], xm[:363])), m((x[363:], xm[363:]))
+    torch.cuda.synchronize()
+    assert y.shape == (B, 576, D) and y.dtype == torch.float32
+    assert torch.equal(y[:363], ya) and torch.equal(y[363:], yb)

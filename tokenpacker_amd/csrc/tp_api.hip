@@ -373,6 +373,35 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         TP_TRY(check_strides("x_multi", x_multi, xm_strides));
     }
     if (!packed_weights || !out || !workspace) { set_error("tp_forward: NULL argument"); return TP_ERR_INVALID_ARG; }
+    {
+        // A GEMM launch addresses at most 4 GiB of output (range-checked 32-bit store offsets).  No operation mixes
+        // images, so a batch beyond that is served as consecutive chunks of the same call — bit-identical per image.
+        const long long n_tok = (long long)desc->raw_grid * desc->raw_grid, m_tok = n_tok / ((long long)desc->scale_factor * desc->scale_factor);
+        const long long out_esz = desc->out_dtype == TP_F32 ? 4 : 2;
+        const long long lim = 1ll << 32;
+        long long bc = (lim / (2 * kEmbed * 2) - 256) / n_tok;                                  // Hkv / Z1: [B N, 2E] fp16
+        const long long bq = (lim / ((long long)desc->hidden_size * (out_esz > 2 ? out_esz : 2)) - 256) / m_tok;   // A2 / out: [B M, D]
+        if (bq < bc) bc = bq;
+        if (bc < 1) { set_error("tp_forward: a single image exceeds the 4 GiB a GEMM launch can address"); return TP_ERR_INVALID_ARG; }
+        if (desc->batch > bc) {
+            if (train || stage_events) {
+                set_error("tp_forward: batch %d exceeds %lld images per call for the training / staged entry points", desc->batch, bc);
+                return TP_ERR_INVALID_ARG;
+            }
+            const long long x_esz = 2;
+            for (long long b0 = 0; b0 < desc->batch; b0 += bc) {
+                tp_desc d = *desc;
+                d.batch = (int)((desc->batch - b0) < bc ? (desc->batch - b0) : bc);
+                const void* parts[4];
+                if (xm_parts) for (int i = 0; i < 4; ++i) parts[i] = (const char*)xm_parts[i] + b0 * xm_strides[0] * x_esz;
+                TP_TRY(forward_impl(&d, (const char*)x + b0 * x_strides[0] * x_esz, x_strides,
+                                    xm_parts ? nullptr : (const char*)x_multi + b0 * xm_strides[0] * x_esz, xm_strides, packed_weights,
+                                    (char*)out + b0 * m_tok * desc->hidden_size * out_esz, workspace, workspace_bytes, stream_,
+                                    nullptr, false, xm_parts ? parts : nullptr));
+            }
+            return TP_OK;
+        }
+    }
     const int B = desc->batch, g = desc->raw_grid, s = desc->scale_factor, D = desc->hidden_size, dt = desc->dtype;
     const int N = g * g, G = g / s, M = G * G, E = kEmbed;
     const int rows_kv = B * N, rows_q = B * M;
