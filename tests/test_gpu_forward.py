@@ -229,3 +229,16 @@ def test_batches_beyond_the_4gib_launch_bound_are_chunked():
     torch.cuda.synchronize()
     assert y.shape == (B, 576, D) and y.dtype == torch.float32
     assert torch.equal(y[:363], ya) and torch.equal(y[363:], yb)
+
+
+def test_empty_batch_returns_empty_like_the_reference():
+    m = TokenPacker(hidden_size=256, scale_factor=2).to(device="cuda", dtype=torch.bfloat16)
+    x = torch.zeros(0, 576, 1024, dtype=torch.bfloat16, device="cuda")
+    xm = torch.zeros(0, 576, 4096, dtype=torch.bfloat16, device="cuda")
+    with torch.no_grad():
+        y = m.eval()((x, xm))
+    assert y.shape == (0, 144, 256) and y.dtype == torch.bfloat16
+    y = m.train()((x, xm))                       # gradients live: still differentiable (all-zero gradients)
+    assert y.shape == (0, 144, 256) and y.requires_grad
+    y.sum().backward()
+    assert all(p.grad is not None and not p.grad.any() for p in m.parameters())

@@ -149,6 +149,22 @@ int tp_set_tuning(int key, int value) {
     return TP_OK;
 }
 
+}  // extern "C"
+namespace tp {
+// Images one forward launch sequence can take: every GEMM output of the path must stay below the 4 GiB a launch addresses
+// (range-checked 32-bit store offsets, tp_gemm_common.h) — Hkv / Z1 [B N, 2E] fp16 and A2 / out [B M, D].
+long long max_images_per_launch(const tp_desc* desc) {
+    const long long n_tok = (long long)desc->raw_grid * desc->raw_grid;
+    const long long m_tok = n_tok / ((long long)desc->scale_factor * desc->scale_factor);
+    const long long out_esz = desc->out_dtype == TP_F32 ? 4 : 2, lim = 1ll << 32;
+    const long long bkv = (lim / (2 * kEmbed * 2) - 256) / n_tok;
+    const long long bq = (lim / ((long long)desc->hidden_size * out_esz) - 256) / m_tok;
+    return bq < bkv ? bq : bkv;
+}
+}  // namespace tp
+using namespace tp;
+extern "C" {
+
 size_t tp_packed_weight_bytes(const tp_desc* desc) {
     if (validate_desc(desc) != TP_OK) return 0;
     return packed_layout(desc->hidden_size).total;
@@ -156,7 +172,9 @@ size_t tp_packed_weight_bytes(const tp_desc* desc) {
 
 size_t tp_workspace_bytes(const tp_desc* desc) {
     if (validate_desc(desc) != TP_OK) return 0;
-    return workspace_layout(desc->batch, desc->raw_grid, desc->scale_factor, desc->hidden_size).total;
+    const long long bc = max_images_per_launch(desc);    // larger batches run as chunks of this size through one workspace
+    const int b = (bc >= 1 && desc->batch > bc) ? (int)bc : desc->batch;
+    return workspace_layout(b, desc->raw_grid, desc->scale_factor, desc->hidden_size).total;
 }
 
 int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, size_t packed_bytes,
@@ -378,10 +396,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         // images, so a batch beyond that is served as consecutive chunks of the same call — bit-identical per image.
         const long long n_tok = (long long)desc->raw_grid * desc->raw_grid, m_tok = n_tok / ((long long)desc->scale_factor * desc->scale_factor);
         const long long out_esz = desc->out_dtype == TP_F32 ? 4 : 2;
-        const long long lim = 1ll << 32;
-        long long bc = (lim / (2 * kEmbed * 2) - 256) / n_tok;                                  // Hkv / Z1: [B N, 2E] fp16
-        const long long bq = (lim / ((long long)desc->hidden_size * (out_esz > 2 ? out_esz : 2)) - 256) / m_tok;   // A2 / out: [B M, D]
-        if (bq < bc) bc = bq;
+        const long long bc = max_images_per_launch(desc);
         if (bc < 1) { set_error("tp_forward: a single image exceeds the 4 GiB a GEMM launch can address"); return TP_ERR_INVALID_ARG; }
         if (desc->batch > bc) {
             if (train || stage_events) {

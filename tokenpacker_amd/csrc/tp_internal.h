@@ -159,6 +159,7 @@ int bw_region_attention_launch(int gdtype, const void* q, const void* k, const v
 int validate_desc(const tp_desc* d);
 GemmArgs plain_gemm(const void* A, long long lda_elems, const void* W, void* C, long long ldc, int M, int N, int K,
                     const float* bias, int flags);
+long long max_images_per_launch(const tp_desc* desc);
 int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3], const void* x_multi,
                  const int64_t xm_strides[3], const void* packed_weights, void* out, void* workspace,
                  size_t workspace_bytes, void* stream_, void* const* stage_events, bool train,

@@ -180,6 +180,12 @@ class TokenPacker(nn.Module):
             raise NotImplementedError(
                 "the HIP projector does not differentiate with respect to the CLIP features (the reference's tower is "
                 "frozen and runs under no_grad, clip_encoder.py:46); detach them")
+        if x.shape[0] == 0:                  # empty batch: the reference returns an empty [0, M, D] tensor
+            out_dtype = torch.float32 if self.output_fp32 else x.dtype
+            y = x.new_zeros((0, self.num_queries, self.hidden_size), dtype=out_dtype)
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                y = y + 0.0 * sum(p.sum() for p in self.parameters() if p.requires_grad).to(out_dtype)
+            return y
         # the kernels take element strides (tower outputs are [:,1:] slices); only fix layouts they cannot address
         x = self._addressable(x)
         if parts:
