@@ -22,7 +22,7 @@ TOL_ROUND = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
 # block-tile variants of the MFMA kernel: 128 (two-phase), 256 (ping-pong 8-wave, tp_gemm8.hip), -256 (two-phase 256)
 TILES = [128, 256, -256]
 # TP_TUNE_GEMM_KERNEL values for tile 256: ping-pong persistent 0 / one tile per workgroup 2 (tp_gemm8.hip)
-KERNS = [0, 2]
+KERNS = [0, 2, 3]
 
 
 def _rand(shape, dtype, seed, scale=1.0):

@@ -240,7 +240,53 @@ int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stre
         }
         return gemm8_launch(in_dtype, out_dtype, a, stream);
     }
-    if (gemm_pick_tile(a.M, a.N, a.tile, a.groups) == 256 && tuning(TP_TUNE_GEMM_KERNEL) != 1)
+    if (a.m_begin < 0 || a.m_begin % 128 != 0 || (a.m_begin > 0 && a.m_begin >= a.M) ||
+        (a.m_end != 0 && (a.m_end <= a.m_begin || a.m_end > a.M))) {
+        set_error("tp gemm: bad row window [%d, %d) of %d rows", a.m_begin, a.m_end, a.M);
+        return TP_ERR_INVALID_ARG;
+    }
+    // Tile shape by a round count.  256x256 tiles are the scheduling grain of the persistent kernel: a last round that
+    // fills a fraction of the chip costs a whole tile time.  When the choice is ours (no forced tile / kernel), compare
+    //   (a) all full tiles, (b) the full rounds as full tiles + the remaining rows as 128x256 half tiles (a second
+    //   launch over a row window), (c) all half tiles
+    // with a half tile at 0.75 of a full tile's time (0.60 in a long launch; a one-round tail also pays its first tile's
+    // un-hidden DMA latency) and a second launch at ~8 us (dependent-launch gap) relative to a full tile's
+    // 8.4 + 1.47 K/64 us (profiles/README.md).  Same epilogue, bit-identical results whatever the shape.
+    const bool free_choice = a.tile == 0 && tuning(TP_TUNE_GEMM_TILE) == 0 && tuning(TP_TUNE_GEMM_KERNEL) == 0 &&
+                             a.m_begin == 0 && a.m_end == 0 && !a.half_tiles && !a.A_parts[0] && a.N % 256 == 0 && a.K >= 2 * BK;
+    if (free_choice) {
+        const int cus = gemm8_persistent_cus(), groups = a.groups > 0 ? a.groups : 1;
+        // (one group only: the workgroups of a second group start on the CUs the first group's last round leaves idle,
+        // so a grouped launch has no empty tail to fill — measured: no gain on the two-group K/V GEMMs)
+        if (groups == 1) {
+            const long long per = cus, tiles_n = a.N / 256;
+            const long long T = (long long)((a.M + 255) / 256) * tiles_n, TH = (long long)((a.M + 127) / 128) * tiles_n;
+            auto rounds = [&](long long tiles) { return (tiles + per - 1) / per; };
+            const double half = 0.75, launch = 8.0 / (8.4 + 1.47 * (a.K / BK));
+            const double cost_a = (double)rounds(T), cost_c = half * (double)rounds(TH);
+            double cost_b = 1e30;
+            long long head_rows = 0;
+            if (T > per && per % tiles_n == 0) {
+                const long long full = T / per;
+                head_rows = full * per / tiles_n * 256;
+                const long long tail_half = (long long)((a.M - head_rows + 127) / 128) * tiles_n;
+                if (head_rows < a.M) cost_b = (double)full + half * (double)rounds(tail_half) + launch;
+            }
+            if (TH >= 64 && cost_c < cost_a - 0.05 && cost_c <= cost_b) {
+                GemmArgs h = a; h.half_tiles = 1;
+                return gemm8_launch(in_dtype, out_dtype, h, stream);
+            }
+            if (cost_b < cost_a - 0.05) {
+                GemmArgs head = a, rest = a;
+                head.m_end = (int)head_rows;
+                rest.m_begin = (int)head_rows; rest.half_tiles = 1; rest.tile_counters = nullptr;
+                if (int rc = gemm8_launch(in_dtype, out_dtype, head, stream)) return rc;
+                return gemm8_launch(in_dtype, out_dtype, rest, stream);
+            }
+        }
+    }
+    if ((a.half_tiles && a.N % 256 == 0) ||
+        (gemm_pick_tile(a.M, a.N, a.tile, a.groups) == 256 && tuning(TP_TUNE_GEMM_KERNEL) != 1))
         return gemm8_launch(in_dtype, out_dtype, a, stream);
     if (in_dtype == TP_BF16) {
         if (out_dtype == TP_BF16) return launch_types<bf16_t, bf16_t>(a, stream);

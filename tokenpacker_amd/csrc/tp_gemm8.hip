@@ -56,13 +56,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 }
 
-constexpr int G8_BM = 256, G8_BN = 256, G8_WM = 128, G8_WN = 64;
+constexpr int G8_BM = 256, G8_BN = 256, G8_WN = 64;
 constexpr int G8_GROUP = 128 * ROW_BYTES;          // 16 KiB: one DMA group (128 rows x 128 B)
 constexpr int G8_BUF = 4 * G8_GROUP;               // 64 KiB: one K-tile (G0 | G1 | G2 | G3)
 constexpr int G8_RING = 2 * G8_BUF;                // 128 KiB of K-tile buffers
-constexpr int G8_PAR = G8_RING;                    // persistent kernel: bias[256] | colsum[256] | (mean, rstd)[256]  (4 KiB)
-constexpr int G8_RED = G8_RING + 4096;             // persistent kernel: 8 KiB row-statistics scratch
-constexpr int G8_NEXT = G8_RING + 4096 + 8192;     // persistent kernel: the next tile index drawn from the queue
+// persistent kernel, behind the ring: bias[256] | colsum[256] | (mean, rstd)[256] (4 KiB), 8 KiB row-statistics scratch,
+// the next tile index drawn from the queue
 constexpr int G8_LDS = G8_RING + 4096 + 8192 + 256;
 constexpr int G8_DEPTH = 3;                        // DMA groups left in flight by the in-loop wait (3 or 4 are legal;
                                                    // 4 = the latest legal wait placement measured no faster: r01u)
@@ -81,13 +80,22 @@ constexpr int G8_DEPTH = 3;                        // DMA groups left in flight 
 //            the end of the contraction range read as zero (descriptor range check, rebuilt per K-tile).
 //        4 = A K-major as in 3, W K-contiguous as in 0 (a weight gradient whose activation operand had to be
 //            transposed anyway — cast, LayerNorm applied — while dY is read in place)
-template <typename TI, typename TO, int AMODE, bool PERSIST, bool TRAIN_EPI>
+// HALF: 128 x 256 output tiles (the tail round of a launch, small M).  The wave tile is 64 x 64 — the a0 quadrant alone —
+// so a K-tile is three DMA groups (G0 = the 128 A rows, G1 / G2 = W halves b0 / b1) consumed in TWO phases (a0,b0) (a0,b1)
+// of 16 MFMAs; the ring holds three K-tiles of 48 KiB.  Schedule: phase 0 of tile t issues G2(t+1), phase 1 issues G0(t+2)
+// and G1(t+2) — re-target distance 3 phases, flight time 2..3 phases — and both wait vmcnt(6).
+template <typename TI, typename TO, int AMODE, bool PERSIST, bool TRAIN_EPI, bool HALF = false>
 __global__ void __launch_bounds__(512, 2)
 gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int xcd_swizzle) {
     using X8 = typename Vec<TI>::x8;
-    constexpr int BM = G8_BM, BN = G8_BN, WM = G8_WM, WN = G8_WN;
+    constexpr int BM = HALF ? G8_BM / 2 : G8_BM, BN = G8_BN, WM = BM / 2, WN = G8_WN;
     constexpr bool A_KMAJOR = (AMODE == 3 || AMODE == 4), W_KMAJOR = (AMODE == 3);
-    constexpr int FM = WM / 16, FN = WN / 16;          // 8 x 4 accumulator fragments per wave
+    static_assert(!HALF || (!A_KMAJOR && PERSIST), "half tiles: K-contiguous operands, persistent kernel");
+    constexpr int FM = WM / 16, FN = WN / 16;          // 8 x 4 (HALF: 4 x 4) accumulator fragments per wave
+    constexpr int KBUF = HALF ? 3 * G8_GROUP : G8_BUF;  // one K-tile in the ring
+    constexpr int RING = HALF ? 3 * KBUF : G8_RING;     // HALF: 144 KiB (three K-tiles), else 128 KiB (two)
+    constexpr int L_PAR = RING, L_RED = RING + 4096, L_NEXT = RING + 4096 + 8192;
+    auto ring_of = [](const int kt) __attribute__((always_inline)) -> int { if constexpr (HALF) return kt % 3; else return kt & 1; };
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -143,7 +151,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
     auto setup_tile = [&](const int Lt) __attribute__((always_inline)) {
         const int tm = Lt / tiles_n;
         tile_n = Lt - tm * tiles_n;
-        m0 = tm * BM; n0 = tile_n * BN;
+        m0 = p.m_begin + tm * BM; n0 = tile_n * BN;
         // K-major operands: per-lane source offsets of DMA instruction idx = 2 wave + q of a group — k rows 4 idx ..
         // 4 idx + 3, chunk slot lane / 8 holds column block (lane / 8) ^ (wave & 1), row (lane % 8) / 2, half lane % 2
         if constexpr (W_KMAJOR) {
@@ -177,7 +185,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
                     const int acol = (cb >> 2) * 128 + sub * 64 + (cb & 3) * 16 + (lane & 1) * 8;
                     voff_a[sub][q] = (int)(krow * p.lda_bytes) + acol * 2;
                 } else {
-                    int row = m0 + (rho >> 6) * 128 + sub * 64 + (rho & 63);
+                    int row = HALF ? m0 + rho : m0 + (rho >> 6) * 128 + sub * 64 + (rho & 63);
                     row = row < p.M ? row : p.M - 1;
                     voff_a[sub][q] = (int)(a_row_off(row) - a_tile_off) + kslot * 16;
                 }
@@ -196,7 +204,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         constexpr int grp = decltype(grp_)::value;
         constexpr bool is_a = (grp == 0 || grp == 3);
         constexpr int sub = (grp == 2 || grp == 3) ? 1 : 0;
-        char* dst = smem + (kt & 1) * G8_BUF + grp * G8_GROUP + wave * 2048;
+        char* dst = smem + ring_of(kt) * KBUF + grp * G8_GROUP + wave * 2048;
         if constexpr (is_a ? A_KMAJOR : W_KMAJOR) {
             // K-tile kt = contraction rows r0 .. r0 + 63 of this group's range; the descriptor starts at the tile's
             // first column of row r0 and ends after the last valid row (soffset is not range-checked, so K advances
@@ -257,8 +265,12 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
     // K-tile 0 complete + G0, G1 of K-tile 1: what the first phases of a tile consume
     auto issue_prologue = [&]() __attribute__((always_inline)) {
-        issue(I0{}, 0); issue(I1{}, 0); issue(I2{}, 0); issue(I3{}, 0);
-        if (nk >= 2) { issue(I0{}, 1); issue(I1{}, 1); }
+        if constexpr (HALF) {                              // (nk >= 2, checked on the host)
+            issue(I0{}, 0); issue(I1{}, 0); issue(I2{}, 0); issue(I0{}, 1); issue(I1{}, 1);
+        } else {
+            issue(I0{}, 0); issue(I1{}, 0); issue(I2{}, 0); issue(I3{}, 0);
+            if (nk >= 2) { issue(I0{}, 1); issue(I1{}, 1); }
+        }
     };
 
     // ---- fragment read offsets (swizzled; fragment rows are 16-aligned inside a group, so row & 7 == lane & 7)
@@ -326,9 +338,9 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         constexpr int P = decltype(P_)::value;
         constexpr bool ISSUE = decltype(ISSUE_)::value;
         constexpr int WAIT = decltype(WAIT_)::value;
-        const char* sb = smem + (t & 1) * G8_BUF;
+        const char* sb = smem + ring_of(t) * KBUF;
         // -- memory segment ---------------------------------------------------------------------------
-        const unsigned ring = (unsigned)(size_t)(lds_void*)smem + (unsigned)(t & 1) * G8_BUF;   // LDS byte address
+        const unsigned ring = (unsigned)(size_t)(lds_void*)smem + (unsigned)ring_of(t) * KBUF;   // LDS byte address
         if constexpr (P == 0 || P == 1) {                           // W fragments of b0 (group 1) / b1 (group 2)
             constexpr int B = P;
             if constexpr (W_KMAJOR) {
@@ -347,7 +359,10 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
                 for (int i = 0; i < 4; ++i) { fa[i][0] = read_a(sb, GA, i, 0); fa[i][1] = read_a(sb, GA, i, 1); }
             }
         }
-        if constexpr (ISSUE) {
+        if constexpr (ISSUE && HALF) {
+            if constexpr (P == 0) issue(I2{}, t + 1);
+            if constexpr (P == 1) { issue(I0{}, t + 2); issue(I1{}, t + 2); }
+        } else if constexpr (ISSUE) {
             if constexpr (P == 0) issue(I2{}, t + 1);
             if constexpr (P == 1) issue(I3{}, t + 1);
             if constexpr (P == 2) issue(I0{}, t + 2);
@@ -392,6 +407,15 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         if (wm == 1) __builtin_amdgcn_s_barrier();         // the late half runs one barrier behind
         __builtin_amdgcn_sched_barrier(0);
         int t = 0;
+        if constexpr (HALF) {
+            using W2_ = std::integral_constant<int, 2>; using W0_ = std::integral_constant<int, 0>;
+            for (; t < nk - 2; ++t) { phase(I0{}, T_{}, WS_{}, t); phase(I1{}, T_{}, WS_{}, t); }
+            phase(I0{}, T_{}, WS_{}, t); phase(I1{}, F_{}, W2_{}, t); ++t;     // tile nk-2: G2(nk-1) is the last group issued
+            phase(I0{}, F_{}, W0_{}, t); phase(I1{}, F_{}, WN_{}, t);          // tile nk-1: drain
+            if (wm == 0) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            return;
+        }
         for (; t < nk - 2; ++t) {                           // steady state: every phase issues, 3 groups stay in flight
             phase(I0{}, T_{}, WS_{}, t);
             phase(I1{}, T_{}, WS_{}, t);
@@ -454,7 +478,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
             }
         };
         auto publish_params = [&]() __attribute__((always_inline)) {
-            float* par = (float*)(smem + G8_PAR);
+            float* par = (float*)(smem + L_PAR);
             if (tid < 256) { par[tid] = pf_bias; par[BN + tid] = pf_csum; }
             else *(float2*)(par + 2 * BN + 2 * (tid - 256)) = pf_mr;
         };
@@ -470,7 +494,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
             int drawn = 0;
             if (queue && tid == 0) drawn = __hip_atomic_fetch_add(queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             publish_params();                               // (hipcc waits for `pf` here)
-            if (queue && tid == 0) *(int*)(smem + G8_NEXT) = drawn;
+            if (queue && tid == 0) *(int*)(smem + L_NEXT) = drawn;
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // DMA prologue landed, earlier stores retired
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -478,7 +502,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
             // the ring is free now: request the next tile before finishing this one
             const int m0c = m0, n0c = n0, tile_nc = tile_n;
             int Ln = L + L_step;
-            if (queue) Ln = queue_base + __builtin_amdgcn_readfirstlane(*(const int*)(smem + G8_NEXT));
+            if (queue) Ln = queue_base + __builtin_amdgcn_readfirstlane(*(const int*)(smem + L_NEXT));
             const bool has_next = Ln < L_end;               // wave-uniform
             if (has_next) {
                 setup_tile(Ln);
@@ -491,11 +515,11 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
             for (int i = 0; i < FM; ++i)
             {   // (ext_vector LDS reads: a struct-typed LDS load next to an in-flight LDS-DMA makes hipcc drain vmcnt)
                 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-                const f32x2_t v = *(const f32x2_t*)(smem + G8_PAR + 2 * BN * 4 + (wm * WM + i * 16 + (lane & 15)) * 8);
+                const f32x2_t v = *(const f32x2_t*)(smem + L_PAR + 2 * BN * 4 + (wm * WM + i * 16 + (lane & 15)) * 8);
                 mean_rstd[i] = make_float2(v[0], v[1]);
             }
             gemm_epilogue<TO, BM, BN, WM, WN, true, TRAIN_EPI>(acc, p, g, m0c, n0c, tile_nc, wm, wn, lane, tid, mean_rstd,
-                                                               smem + G8_RED, smem + G8_PAR);
+                                                               smem + L_RED, smem + L_PAR);
             if (!has_next) break;
             L = Ln;
             block_sync_lds();                               // everyone is done with this tile's parameters
@@ -514,10 +538,13 @@ static int g8_num_cus() {
     return cus;
 }
 
-template <typename TI, typename TO, int AMODE, bool PERSIST, bool TRAIN_EPI>
+int gemm8_persistent_cus() { return g8_num_cus() / 8 * 8; }
+
+template <typename TI, typename TO, int AMODE, bool PERSIST, bool TRAIN_EPI, bool HALF = false>
 static int launch8_cfg(const GemmArgs& a, hipStream_t stream) {
-    auto kern = gemm8_kernel<TI, TO, AMODE, PERSIST, TRAIN_EPI>;
-    constexpr int lds = PERSIST ? G8_LDS : G8_RING;
+    auto kern = gemm8_kernel<TI, TO, AMODE, PERSIST, TRAIN_EPI, HALF>;
+    constexpr int lds = HALF ? 9 * G8_GROUP + 4096 + 8192 + 256 : (PERSIST ? G8_LDS : G8_RING);
+    constexpr int TBM = HALF ? G8_BM / 2 : G8_BM;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [&] {
@@ -528,7 +555,8 @@ static int launch8_cfg(const GemmArgs& a, hipStream_t stream) {
         set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", lds, hipGetErrorString(attr_err));
         return TP_ERR_LAUNCH;
     }
-    const int tiles_m = (a.M + G8_BM - 1) / G8_BM, tiles_n = a.N / G8_BN;
+    const int m_end = a.m_end > 0 ? a.m_end : a.M;
+    const int tiles_m = (m_end - a.m_begin + TBM - 1) / TBM, tiles_n = a.N / G8_BN;
     const int ntiles = tiles_m * tiles_n;
     int nwg = ntiles;
     if (PERSIST) {                                     // one workgroup per CU (140 KiB of LDS each), a multiple of the 8 XCDs
@@ -551,17 +579,30 @@ static int launch8_var(const GemmArgs& a, hipStream_t stream) {
         return TP_ERR_INVALID_ARG;
     }
     if (a.A_parts[0]) {                                // K split over four sources: the forward's first layer only
+        if (a.half_tiles) { set_error("tp gemm8: half tiles do not take a multi-part A operand"); return TP_ERR_INVALID_ARG; }
         if constexpr (std::is_same<TO, f16_t>::value && PERSIST)
             return train_epi ? launch8_cfg<TI, TO, 2, PERSIST, true>(a, stream) : launch8_cfg<TI, TO, 2, PERSIST, false>(a, stream);
         set_error("tp gemm8: a multi-part A operand is supported for fp16 output on the persistent kernel only");
         return TP_ERR_INVALID_ARG;
     }
+    const bool half = a.half_tiles != 0;
+    if (half && (!PERSIST || a.K < 2 * BK)) {
+        set_error("tp gemm8: half tiles need the persistent kernel and K >= 128");
+        return TP_ERR_INVALID_ARG;
+    }
     if (train_epi) {
-        if constexpr (HALF_OUT && PERSIST)
+        if constexpr (HALF_OUT && PERSIST) {
+            if (half) return a.rows_per_batch < a.M ? launch8_cfg<TI, TO, 1, PERSIST, true, true>(a, stream)
+                                                    : launch8_cfg<TI, TO, 0, PERSIST, true, true>(a, stream);
             return a.rows_per_batch < a.M ? launch8_cfg<TI, TO, 1, PERSIST, true>(a, stream)
                                           : launch8_cfg<TI, TO, 0, PERSIST, true>(a, stream);
+        }
         set_error("tp gemm8: training epilogues need a 16-bit output on the persistent kernel");
         return TP_ERR_INVALID_ARG;
+    }
+    if constexpr (PERSIST) {
+        if (half) return a.rows_per_batch < a.M ? launch8_cfg<TI, TO, 1, PERSIST, false, true>(a, stream)
+                                                : launch8_cfg<TI, TO, 0, PERSIST, false, true>(a, stream);
     }
     return a.rows_per_batch < a.M ? launch8_cfg<TI, TO, 1, PERSIST, false>(a, stream)
                                   : launch8_cfg<TI, TO, 0, PERSIST, false>(a, stream);
@@ -571,6 +612,10 @@ static int launch8_var(const GemmArgs& a, hipStream_t stream) {
 template <typename TI, typename TO>
 static int launch8_types(const GemmArgs& a, hipStream_t stream) {
     if (tuning(TP_TUNE_GEMM_KERNEL) == 2) return launch8_var<TI, TO, false>(a, stream);
+    if (tuning(TP_TUNE_GEMM_KERNEL) == 3 && !a.half_tiles && !a.A_parts[0] && a.tt_rows == 0 && a.K >= 2 * BK) {
+        GemmArgs h = a; h.half_tiles = 1;               // (A/B and tests: every tile of the launch as a half tile)
+        return launch8_var<TI, TO, true>(h, stream);
+    }
     return launch8_var<TI, TO, true>(a, stream);
 }
 

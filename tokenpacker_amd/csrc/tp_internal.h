@@ -64,6 +64,9 @@ struct GemmArgs {
     // per-group strides (bytes for A/W/C, floats for the fp32 side arrays)
     long long a_gs, w_gs, c_gs, bias_gs, stats_in_gs, colsum_gs, stats_out_gs;
     int M, N, K;
+    int m_begin, m_end;               // ping-pong kernel: tiles cover rows [m_begin, m_end) (m_end 0: M); row indices, the
+                                      // bound M and every per-row array stay those of the whole problem
+    int half_tiles;                   // ping-pong kernel: 128 x 256 tiles (tp_gemm8.hip HALF) instead of 256 x 256
     int rows_per_batch;
     int flags;                        // TP_LINEAR_*
     int groups;
@@ -73,6 +76,7 @@ int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stre
 int gemm_pick_tile(int M, int N, int forced, int groups = 1);     // -> 128 or 256
 // 256x256x64 ping-pong kernel (tp_gemm8.hip); gemm_launch routes tile-256 problems to it
 int gemm8_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream);
+int gemm8_persistent_cus();                            // workgroups of a persistent launch (CUs rounded down to 8)
 inline int gemm_stats_parts(int N) { return N / 128; }   // one (sum, sumsq) slab per 128 output columns
 
 // ---- small kernels (tp_kernels.hip) -----------------------------------------------------------

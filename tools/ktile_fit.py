@@ -17,6 +17,8 @@ G, S, F = _capi.TP_LINEAR_GELU, _capi.TP_LINEAR_ROW_STATS, _capi.TP_LINEAR_LN_FO
 def main():
     args = dict(a.split("=", 1) for a in sys.argv[1:])           # lib=<path to a probe build> for A/B runs on one box
     lib = _capi.load_library(args["lib"]) if "lib" in args else _capi.load_library()
+    if "kernel" in args:                                             # TP_TUNE_GEMM_KERNEL (3: half tiles)
+        _capi.set_tuning(_capi.TP_TUNE_GEMM_KERNEL, int(args["kernel"]))
     print("args", args)
     st = torch.cuda.current_stream().cuda_stream
     M, N = 147456, 1024
