@@ -305,10 +305,11 @@ int tp_hd_slice(const float* image, int H, int W, int h_block, int w_block, int 
 int tp_test_occupy_cus(int workgroups, int microseconds, void* scratch_int, void* stream);
 
 /* ---- tuning knobs (benchmarks only; defaults are what tp_forward ships with) ------------------ */
-enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto | 128 | 256                                              */
+enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all half tiles by CU rounds) | 128 | 256 */
        TP_TUNE_XCD_SWIZZLE = 1, /* 1 (default) | 0                                                 */
-       TP_TUNE_GEMM_KERNEL = 2, /* 256-tile main loop: 0 persistent ping-pong (default) | 1 two-phase
-                                   | 2 ping-pong, one tile per workgroup                              */
+       TP_TUNE_GEMM_KERNEL = 2, /* 256-tile main loop: 0 persistent ping-pong (default; tile shape by round count)
+                                   | 1 two-phase | 2 ping-pong, one tile per workgroup
+                                   | 3 persistent ping-pong, every tile a 128x256 half tile            */
        TP_TUNE_Q_SIDE_STREAM = 5, /* 1 (default): the query side runs on a forked side stream | 0: one stream */
        TP_TUNE_DYNAMIC_TILES = 4, /* 1 (default): persistent GEMMs draw tiles from per-XCD queues | 0: static striding */
        TP_TUNE_FOLD_OUT_PROJ = 3, /* 0 (default): out_proj and mlp[0] as two GEMMs | 1: folded (W = Wm0·Wout) */
