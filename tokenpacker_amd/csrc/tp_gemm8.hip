@@ -559,7 +559,7 @@ static int launch8_cfg(const GemmArgs& a, hipStream_t stream) {
     const int tiles_m = (m_end - a.m_begin + TBM - 1) / TBM, tiles_n = a.N / G8_BN;
     const int ntiles = tiles_m * tiles_n;
     int nwg = ntiles;
-    if (PERSIST) {                                     // one workgroup per CU (140 KiB of LDS each), a multiple of the 8 XCDs
+    if (PERSIST) {                                     // one workgroup per CU (140 KiB of LDS each, 156 KiB with half tiles), a multiple of the 8 XCDs
         const int cap = g8_num_cus() / 8 * 8;
         if (nwg > cap && cap > 0) nwg = cap;
     }
