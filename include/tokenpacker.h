@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TP_ABI_VERSION 1
+#define TP_ABI_VERSION 2
 
 typedef enum tp_status {
     TP_OK = 0,
@@ -96,6 +96,12 @@ const char* tp_last_error(void);              /* thread-local, never NULL       
 /* ---- sizes ----------------------------------------------------------------------------------- */
 /* Bytes of the packed-weight buffer for (hidden_size, dtype); 0 on invalid arguments. */
 size_t tp_packed_weight_bytes(const tp_desc* desc);
+/* Byte offset, inside the packed-weight buffer, of an int32[64] status block written by tp_pack_weights():
+ * [0] = number of weight elements that did not fit the fp16 range the kernels keep every post-first-layer weight in
+ *       and were clamped to +-65504 (a bf16 model can hold such values; results would silently differ from the
+ *       reference, so the Python wrapper raises OverflowError when it is non-zero),
+ * [1] = 1 when the out_proj∘mlp[0] fold was built (TP_TUNE_FOLD_OUT_PROJ set at pack time).  0 on invalid args. */
+size_t tp_packed_status_offset(const tp_desc* desc);
 /* Bytes of scratch tp_forward() needs for this descriptor (depends on batch); 0 on invalid args. */
 size_t tp_workspace_bytes(const tp_desc* desc);
 
@@ -277,8 +283,14 @@ int tp_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, int x_rows
  * Replaces the Python loop + torch.cat of `prepare_inputs_labels_for_multimodal` in mode 'slice'
  * (llava_arch.py:140-154): per image, the h_block x w_block crops in row-major order, the ',' embedding after
  * every crop that is not the last of its row, the '\n' embedding after every row, then (more than one crop)
- * the global-view crop and '\n'.  tokens [n_crops, M, D], sep / ret [D], out [rows, D]; all of `dtype`.
- * Image i reads crops first_crop .. and writes rows out_row .. out_row + tp_hd_rows(h, w, M). */
+ * the global-view crop and '\n'.  tokens [n_crops, M, D], sep / ret [D], out [out_rows, D]; all of `dtype`.
+ * Image i reads crops first_crop .. and writes rows out_row .. out_row + tp_hd_rows(h, w, M).  Images are listed in
+ * order; their crop and row ranges must not overlap and must lie inside `tokens` / `out` (validated).  Rows of `out`
+ * between two images are left untouched, so `out` can be the `inputs_embeds` buffer itself with the text embeddings
+ * already in place (llava_arch.py:172-191) — the visual tokens then land where the LLM reads them.
+ * `crop_map` (device int32[n_crops], or NULL): logical crop c lives in row block crop_map[c] of `tokens` — lets the
+ * kernel read the b_max-strided buffer of a RAGGED all-gather in place (tokenpacker_amd.shard.GatheredTokens); the
+ * caller guarantees the mapped blocks exist (values are not readable from the host side). */
 typedef struct tp_hd_image {
     int32_t first_crop;
     int32_t h_block;
@@ -287,8 +299,8 @@ typedef struct tp_hd_image {
     int64_t out_row;
 } tp_hd_image;
 int64_t tp_hd_rows(int h_block, int w_block, int M);
-int tp_hd_assemble(const tp_hd_image* plan, int n_images, const void* tokens, const void* sep, const void* ret,
-                   void* out, int M, int D, int dtype, void* stream);
+int tp_hd_assemble(const tp_hd_image* plan, int n_images, const void* tokens, int64_t n_crops, const int32_t* crop_map,
+                   const void* sep, const void* ret, void* out, int64_t out_rows, int M, int D, int dtype, void* stream);
 
 /* ---- TokenPacker-HD image slicing (the step before the CLIP tower) ---------------------------------------------
  * Replaces the resize / zero-pad / tile code of the data loader and the eval drivers (llava/train/train.py:695-731):
@@ -299,6 +311,15 @@ int tp_hd_assemble(const tp_hd_image* plan, int n_images, const void* tokens, co
  * (tokenpacker_amd.hd.slice_plan). */
 int tp_hd_slice(const float* image, int H, int W, int h_block, int w_block, int h_res, int w_res, int hg, int wg,
                 float* crops, int block, void* stream);
+
+/* ---- debug: fp16 saturation scan ---------------------------------------------------------------------------------
+ * Every activation between the kernels of tp_forward is fp16 and every epilogue CLAMPS to +-65504 instead of producing
+ * inf.  After a tp_forward on `stream` with the same desc / workspace, this scans the nine intermediate
+ * buffers — q0, Hkv, H2, KV, Q1pre, Q, O, A1, A2 in this order — and writes into counts[i] (device int32[9]) the
+ * number of elements at the clamp bound (or NaN).  All zeros = no activation of that forward left the fp16 range. */
+#define TP_NUM_DEBUG_BUFFERS 9
+int tp_debug_count_saturated(const tp_desc* desc, const void* workspace, size_t workspace_bytes, int32_t* counts,
+                             void* stream);
 
 /* ---- test hook: occupy `workgroups` CUs for ~`microseconds` on `stream` (100 KiB LDS each; `scratch_int`: any
  * device int).  Stands in for another stream's kernels when the GEMM tile queue is measured (tools/hog_bench.py). */

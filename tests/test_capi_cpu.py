@@ -102,10 +102,24 @@ def test_train_hd_and_parts_entry_points_reject_bad_arguments():
     # HD helpers
     assert lib.tp_hd_rows(1, 1, 144) == 145            # one crop: its tokens + '\n', no global view
     assert lib.tp_hd_rows(2, 3, 144) == (6 * 144 + 6) + 145
-    assert lib.tp_hd_assemble(None, 1, None, None, None, None, 144, 256, _capi.TP_BF16, None) == E
+    assert lib.tp_hd_assemble(None, 1, None, 1, None, None, None, None, 145, 144, 256, _capi.TP_BF16, None) == E
     plan = (_capi.tp_hd_image * 1)(_capi.tp_hd_image(0, 1, 1, 0, 0))
-    assert lib.tp_hd_assemble(plan, 0, None, None, None, None, 144, 256, _capi.TP_BF16, None) in (E, _capi.TP_OK)
-    assert lib.tp_hd_assemble(plan, 1, None, None, None, None, 144, 256, _capi.TP_BF16, None) == E
+    assert lib.tp_hd_assemble(plan, 0, None, 1, None, None, None, None, 145, 144, 256, _capi.TP_BF16, None) in (E, _capi.TP_OK)
+    assert lib.tp_hd_assemble(plan, 1, None, 1, None, None, None, None, 145, 144, 256, _capi.TP_BF16, None) == E
+    # plan validation (host-side, before anything is enqueued): overlap, out-of-order, reads / writes past the buffers
+    fake = ctypes.c_void_p(4096)                                   # non-NULL, 16-byte aligned; never dereferenced on a rejected plan
+    two = (_capi.tp_hd_image * 2)(_capi.tp_hd_image(0, 2, 2, 0, 0), _capi.tp_hd_image(4, 1, 1, 0, 725))   # 2x2 uses 5 crops
+    assert lib.tp_hd_assemble(two, 2, fake, 6, None, fake, fake, fake, 2000, 144, 256, _capi.TP_BF16, None) == E
+    assert "overlaps" in lib.tp_last_error().decode()
+    two = (_capi.tp_hd_image * 2)(_capi.tp_hd_image(0, 2, 2, 0, 0), _capi.tp_hd_image(5, 1, 1, 0, 700))   # rows 0..724 taken
+    assert lib.tp_hd_assemble(two, 2, fake, 6, None, fake, fake, fake, 2000, 144, 256, _capi.TP_BF16, None) == E
+    two = (_capi.tp_hd_image * 2)(_capi.tp_hd_image(0, 2, 2, 0, 0), _capi.tp_hd_image(5, 1, 1, 0, 900))   # gap 725..899 is fine ...
+    assert lib.tp_hd_assemble(two, 2, fake, 5, None, fake, fake, fake, 2000, 144, 256, _capi.TP_BF16, None) == E   # ... but crop 5 of 5 is not
+    assert "crops up to 6 of 5" in lib.tp_last_error().decode()
+    assert lib.tp_hd_assemble(two, 2, fake, 6, None, fake, fake, fake, 1000, 144, 256, _capi.TP_BF16, None) == E   # rows up to 1045 of 1000
+    # status block of the packed weights, debug scan
+    assert 0 < lib.tp_packed_status_offset(ctypes.byref(d)) < lib.tp_packed_weight_bytes(ctypes.byref(d))
+    assert lib.tp_debug_count_saturated(ctypes.byref(d), None, 0, None, None) == E
     assert lib.tp_hd_slice(None, 100, 100, 1, 1, 336, 336, 0, 0, None, 336, None) == E
     assert lib.tp_test_occupy_cus(0, 1, None, None) == E
     # the weight-gradient contraction on its own

@@ -11,7 +11,7 @@ import os
 from ctypes import (POINTER, Structure, byref, c_char_p, c_float, c_int, c_int32, c_int64,
                     c_size_t, c_void_p)
 
-TP_ABI_VERSION = 1
+TP_ABI_VERSION = 2
 TP_BF16, TP_F16, TP_F32 = 0, 1, 2
 TP_OK, TP_ERR_INVALID_ARG, TP_ERR_BAD_SCALE, TP_ERR_WORKSPACE, TP_ERR_LAUNCH = 0, -1, -2, -3, -4
 TP_LINEAR_GELU, TP_LINEAR_LN_FOLD, TP_LINEAR_ROW_STATS = 1, 2, 4
@@ -19,6 +19,8 @@ TP_TUNE_GEMM_TILE, TP_TUNE_XCD_SWIZZLE, TP_TUNE_GEMM_KERNEL, TP_TUNE_FOLD_OUT_PR
 TP_TUNE_Q_SIDE_STREAM = 5
 TP_WGRAD_X_TRANSPOSED = 1
 TP_NUM_STAGES = 10
+TP_NUM_DEBUG_BUFFERS = 9
+DEBUG_BUFFER_NAMES = ("q0", "Hkv", "H2", "KV", "Q1pre", "Q", "O", "A1", "A2")
 STAGE_NAMES = ("point_queries", "kv_layer0_gelu", "kv_layer2_stats", "kv_inproj_lnfold", "q_proj_1_stats",
                "q_inproj_lnfold", "region_attention", "out_proj", "mlp0_gelu", "mlp2")
 
@@ -32,7 +34,7 @@ EXPORTED_SYMBOLS = (
     "tp_ln_finalize", "tp_linear_stats_parts", "tp_set_tuning", "tp_hd_rows", "tp_hd_assemble",
     "tp_train_workspace_bytes", "tp_backward_workspace_bytes", "tp_forward_train", "tp_backward",
     "tp_forward_parts", "tp_forward_train_parts", "tp_backward_parts", "tp_test_occupy_cus", "tp_hd_slice",
-    "tp_wgrad", "tp_wgrad_workspace_bytes",
+    "tp_wgrad", "tp_wgrad_workspace_bytes", "tp_packed_status_offset", "tp_debug_count_saturated",
 )
 
 # state-dict name -> tp_weights field order (include/tokenpacker.h)
@@ -111,6 +113,10 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.tp_packed_weight_bytes.argtypes = [POINTER(tp_desc)]
     lib.tp_workspace_bytes.restype = c_size_t
     lib.tp_workspace_bytes.argtypes = [POINTER(tp_desc)]
+    lib.tp_packed_status_offset.restype = c_size_t
+    lib.tp_packed_status_offset.argtypes = [POINTER(tp_desc)]
+    lib.tp_debug_count_saturated.restype = c_int
+    lib.tp_debug_count_saturated.argtypes = [POINTER(tp_desc), c_void_p, c_size_t, c_void_p, c_void_p]
     lib.tp_pack_weights.restype = c_int
     lib.tp_pack_weights.argtypes = [POINTER(tp_desc), POINTER(tp_weights), c_void_p, c_size_t, c_void_p]
     lib.tp_forward.restype = c_int
@@ -159,8 +165,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.tp_hd_rows.restype = c_int64
     lib.tp_hd_rows.argtypes = [c_int, c_int, c_int]
     lib.tp_hd_assemble.restype = c_int
-    lib.tp_hd_assemble.argtypes = [POINTER(tp_hd_image), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                   c_int, c_void_p]
+    lib.tp_hd_assemble.argtypes = [POINTER(tp_hd_image), c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_int64, c_int, c_int, c_int, c_void_p]
 
     if lib.tp_version() != TP_ABI_VERSION:
         raise TokenPackerLibraryError(
@@ -194,10 +200,22 @@ def strides3(st) -> "ctypes.Array":
     return (c_int64 * 3)(int(st[0]), int(st[1]), int(st[2]))
 
 
+_TUNING_DEFAULTS = {TP_TUNE_GEMM_TILE: 0, TP_TUNE_XCD_SWIZZLE: 1, TP_TUNE_GEMM_KERNEL: 0, TP_TUNE_FOLD_OUT_PROJ: 0,
+                    TP_TUNE_DYNAMIC_TILES: 1, TP_TUNE_Q_SIDE_STREAM: 1}
+_tuning_values = dict(_TUNING_DEFAULTS)
+
+
 def set_tuning(key: int, value: int) -> None:
+    """Process-wide tuning table of the library (benchmarks / tests; NOT reentrant: include/tokenpacker.h)."""
     check(load_library().tp_set_tuning(key, value), "tp_set_tuning")
+    _tuning_values[key] = value
+
+
+def get_tuning(key: int) -> int:
+    """Last value set through :func:`set_tuning` in this process (the library's default otherwise)."""
+    return _tuning_values.get(key, 0)
 
 
 __all__ = [n for n in dir() if n.startswith(("TP_", "tp_"))] + [
-    "load_library", "last_error", "check", "make_desc", "strides3", "set_tuning",
+    "load_library", "last_error", "check", "make_desc", "strides3", "set_tuning", "get_tuning",
     "TokenPackerLibraryError", "WEIGHT_FIELDS", "EXPORTED_SYMBOLS", "LIB_PATH", "byref"]

@@ -60,6 +60,7 @@ PackedLayout packed_layout(int D) {
     L.w_m2 = take((size_t)D * D * 2);    L.b_m2 = take((size_t)D * 4);
     L.w_om = take((size_t)D * E * 2);    L.b_om = take((size_t)D * 4);
     L.scratch_t = take(E * E * 2);       L.scratch_p = take((size_t)D * E * 4);
+    L.status = take(256);
     L.total = off;
     return L;
 }
@@ -170,6 +171,11 @@ size_t tp_packed_weight_bytes(const tp_desc* desc) {
     return packed_layout(desc->hidden_size).total;
 }
 
+size_t tp_packed_status_offset(const tp_desc* desc) {
+    if (validate_desc(desc) != TP_OK) return 0;
+    return packed_layout(desc->hidden_size).status;
+}
+
 size_t tp_workspace_bytes(const tp_desc* desc) {
     if (validate_desc(desc) != TP_OK) return 0;
     const long long bc = max_images_per_launch(desc);    // larger batches run as chunks of this size through one workspace
@@ -200,6 +206,12 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
         return TP_OK;
     };
 #define TP_TRY(expr) do { int rc_ = (expr); if (rc_ != TP_OK) return rc_; } while (0)
+    int* status = (int*)(P + L.status);
+    int* sat = status;                                   // [0]: weight elements clamped to the fp16 range
+    {
+        hipError_t e = hipMemsetAsync(status, 0, 256, stream);
+        if (e != hipSuccess) { set_error("tp_pack_weights: hipMemsetAsync: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
+    }
     // K/V first layers concatenated: one GEMM reads x_multi once
     TP_TRY(copy(L.w_kv0, raw->k_proj_1_0_weight, E * kMulti * 2));
     TP_TRY(copy(L.w_kv0 + E * kMulti * 2, raw->v_proj_1_0_weight, E * kMulti * 2));
@@ -207,38 +219,43 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
     TP_TRY(pack_cast_f32_launch(dt, raw->v_proj_1_0_bias, (float*)(P + L.b_kv0) + E, (int)E, stream));
     // everything after the first layer runs on fp16 activations: widen those weights to fp16 (exact for
     // in-range bf16 values; identity for fp16 models)
-    TP_TRY(pack_cast_f16_launch(dt, raw->k_proj_1_2_weight, P + L.w_kv2, (long long)(E * E), stream));
-    TP_TRY(pack_cast_f16_launch(dt, raw->v_proj_1_2_weight, P + L.w_kv2 + E * E * 2, (long long)(E * E), stream));
+    TP_TRY(pack_cast_f16_launch(dt, raw->k_proj_1_2_weight, P + L.w_kv2, (long long)(E * E), stream, sat));
+    TP_TRY(pack_cast_f16_launch(dt, raw->v_proj_1_2_weight, P + L.w_kv2 + E * E * 2, (long long)(E * E), stream, sat));
     TP_TRY(pack_cast_f32_launch(dt, raw->k_proj_1_2_bias, (float*)(P + L.b_kv2), (int)E, stream));
     TP_TRY(pack_cast_f32_launch(dt, raw->v_proj_1_2_bias, (float*)(P + L.b_kv2) + E, (int)E, stream));
-    TP_TRY(pack_cast_f16_launch(dt, raw->q_proj_1_weight, P + L.w_q1, (long long)(E * E), stream));
+    TP_TRY(pack_cast_f16_launch(dt, raw->q_proj_1_weight, P + L.w_q1, (long long)(E * E), stream, sat));
     // LayerNorm affines folded into the q/k/v in-projections (in_proj rows: q | k | v)
     const char* inw = (const char*)raw->clip_attn_in_proj_weight;
     const char* inb = (const char*)raw->clip_attn_in_proj_bias;
     TP_TRY(pack_ln_fold_launch(dt, inw, inb, raw->ln_q_1_weight, raw->ln_q_1_bias, P + L.w_in_q,
-                               (float*)(P + L.c_in_q), (float*)(P + L.b_in_q), (int)E, (int)E, stream));
+                               (float*)(P + L.c_in_q), (float*)(P + L.b_in_q), (int)E, (int)E, stream, sat));
     TP_TRY(pack_ln_fold_launch(dt, inw + E * E * 2, inb + E * 2, raw->ln_k_1_weight, raw->ln_k_1_bias,
-                               P + L.w_in_kv, (float*)(P + L.c_in_kv), (float*)(P + L.b_in_kv), (int)E, (int)E, stream));
+                               P + L.w_in_kv, (float*)(P + L.c_in_kv), (float*)(P + L.b_in_kv), (int)E, (int)E, stream, sat));
     TP_TRY(pack_ln_fold_launch(dt, inw + 2 * E * E * 2, inb + 2 * E * 2, raw->ln_v_1_weight, raw->ln_v_1_bias,
                                P + L.w_in_kv + E * E * 2, (float*)(P + L.c_in_kv) + E, (float*)(P + L.b_in_kv) + E,
-                               (int)E, (int)E, stream));
-    TP_TRY(pack_cast_f16_launch(dt, raw->clip_attn_out_proj_weight, P + L.w_out, (long long)(E * E), stream));
+                               (int)E, (int)E, stream, sat));
+    TP_TRY(pack_cast_f16_launch(dt, raw->clip_attn_out_proj_weight, P + L.w_out, (long long)(E * E), stream, sat));
     TP_TRY(pack_cast_f32_launch(dt, raw->clip_attn_out_proj_bias, (float*)(P + L.b_out), (int)E, stream));
-    TP_TRY(pack_cast_f16_launch(dt, raw->mlp_0_weight, P + L.w_m0, (long long)D * E, stream));
+    TP_TRY(pack_cast_f16_launch(dt, raw->mlp_0_weight, P + L.w_m0, (long long)D * E, stream, sat));
     TP_TRY(pack_cast_f32_launch(dt, raw->mlp_0_bias, (float*)(P + L.b_m0), D, stream));
-    TP_TRY(pack_cast_f16_launch(dt, raw->mlp_2_weight, P + L.w_m2, (long long)D * D, stream));
+    TP_TRY(pack_cast_f16_launch(dt, raw->mlp_2_weight, P + L.w_m2, (long long)D * D, stream, sat));
     TP_TRY(pack_cast_f32_launch(dt, raw->mlp_2_bias, (float*)(P + L.b_m2), D, stream));
     // out_proj folded into mlp[0]:  W_om = Wm0·Wout (fp32 accumulate on the MFMA kernel, rounded once to fp16),
-    // b_om = Wm0·bout + bm0
-    TP_TRY(pack_transpose_f16_launch(P + L.w_out, P + L.scratch_t, (int)E, stream));
-    {
-        GemmArgs a = plain_gemm(P + L.w_m0, E, P + L.scratch_t, P + L.scratch_p, E, D, (int)E, (int)E, nullptr, 0);
-        a.tile = 128;
-        TP_TRY(gemm_launch(TP_F16, TP_F32, a, stream));
+    // b_om = Wm0·bout + bm0 — built only when the fold is switched on AT PACK TIME (TP_TUNE_FOLD_OUT_PROJ, default off:
+    // a training step re-packs every step and must not pay for a product it never uses); status[1] records it.
+    if (tuning(TP_TUNE_FOLD_OUT_PROJ) != 0) {
+        TP_TRY(pack_transpose_f16_launch(P + L.w_out, P + L.scratch_t, (int)E, stream));
+        {
+            GemmArgs a = plain_gemm(P + L.w_m0, E, P + L.scratch_t, P + L.scratch_p, E, D, (int)E, (int)E, nullptr, 0);
+            a.tile = 128;
+            TP_TRY(gemm_launch(TP_F16, TP_F32, a, stream));
+        }
+        TP_TRY(pack_round_f16_launch((const float*)(P + L.scratch_p), P + L.w_om, (long long)D * E, stream, sat));
+        TP_TRY(pack_bias_fold_launch(P + L.w_m0, (const float*)(P + L.b_out), (const float*)(P + L.b_m0),
+                                     (float*)(P + L.b_om), D, (int)E, stream));
+        hipError_t e = hipMemsetD32Async((hipDeviceptr_t)(status + 1), 1, 1, stream);
+        if (e != hipSuccess) { set_error("tp_pack_weights: hipMemsetD32Async(status): %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
     }
-    TP_TRY(pack_round_f16_launch((const float*)(P + L.scratch_p), P + L.w_om, (long long)D * E, stream));
-    TP_TRY(pack_bias_fold_launch(P + L.w_m0, (const float*)(P + L.b_out), (const float*)(P + L.b_m0),
-                                 (float*)(P + L.b_om), D, (int)E, stream));
     return TP_OK;
 }
 
@@ -276,6 +293,26 @@ int tp_hd_slice(const float* image, int H, int W, int h_block, int w_block, int 
     return hd_slice_launch(image, H, W, h_block, w_block, h_res, w_res, hg, wg, crops, block, (hipStream_t)stream);
 }
 
+int tp_debug_count_saturated(const tp_desc* desc, const void* workspace, size_t workspace_bytes, int32_t* counts, void* stream_) {
+    TP_TRY(validate_desc(desc));
+    if (!workspace || !counts) { set_error("tp_debug_count_saturated: NULL argument"); return TP_ERR_INVALID_ARG; }
+    const int B = desc->batch, g = desc->raw_grid, s = desc->scale_factor, D = desc->hidden_size;
+    if (B > max_images_per_launch(desc)) { set_error("tp_debug_count_saturated: batch was served in chunks; scan a smaller batch"); return TP_ERR_INVALID_ARG; }
+    const WorkspaceLayout W = workspace_layout(B, g, s, D, false);
+    if (workspace_bytes < W.total) { set_error("tp_debug_count_saturated: workspace %zu B < %zu B", workspace_bytes, W.total); return TP_ERR_WORKSPACE; }
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long rows_kv = (long long)B * g * g, rows_q = (long long)B * (g / s) * (g / s), E = kEmbed;
+    const char* ws = (const char*)workspace;
+    const struct { size_t off; long long n; } bufs[TP_NUM_DEBUG_BUFFERS] = {
+        {W.q0, rows_q * E}, {W.hkv, rows_kv * 2 * E}, {W.h2, 2 * rows_kv * E}, {W.kv, 2 * rows_kv * E}, {W.q1pre, rows_q * E},
+        {W.q, rows_q * E}, {W.o, rows_q * E}, {W.a1, rows_q * E}, {W.a2, rows_q * (long long)D}};
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * TP_NUM_DEBUG_BUFFERS, stream);
+    if (e != hipSuccess) { set_error("tp_debug_count_saturated: hipMemsetAsync: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
+    for (int i = 0; i < TP_NUM_DEBUG_BUFFERS; ++i)
+        TP_TRY(count_saturated_launch(ws + bufs[i].off, bufs[i].n, counts + i, stream));
+    return TP_OK;
+}
+
 int tp_test_occupy_cus(int workgroups, int microseconds, void* scratch_int, void* stream) {
     if (workgroups <= 0 || microseconds <= 0 || !scratch_int) { set_error("tp_test_occupy_cus: bad argument"); return TP_ERR_INVALID_ARG; }
     return occupy_cus_launch(workgroups, microseconds, (int*)scratch_int, (hipStream_t)stream);
@@ -287,9 +324,9 @@ int64_t tp_hd_rows(int h_block, int w_block, int M) {
     return n * (M + 1) + (n > 1 ? M + 1 : 0);
 }
 
-int tp_hd_assemble(const tp_hd_image* plan, int n_images, const void* tokens, const void* sep, const void* ret,
-                   void* out, int M, int D, int dtype, void* stream) {
-    if (!plan || !tokens || !sep || !ret || !out || n_images <= 0 || M <= 0) {
+int tp_hd_assemble(const tp_hd_image* plan, int n_images, const void* tokens, int64_t n_crops, const int32_t* crop_map,
+                   const void* sep, const void* ret, void* out, int64_t out_rows, int M, int D, int dtype, void* stream) {
+    if (!plan || !tokens || !sep || !ret || !out || n_images <= 0 || M <= 0 || n_crops <= 0 || out_rows <= 0) {
         set_error("tp_hd_assemble: NULL / non-positive argument");
         return TP_ERR_INVALID_ARG;
     }
@@ -298,17 +335,24 @@ int tp_hd_assemble(const tp_hd_image* plan, int n_images, const void* tokens, co
         set_error("tp_hd_assemble: D must be a multiple of 8 and every pointer 16-byte aligned");
         return TP_ERR_INVALID_ARG;
     }
-    int crop = 0;
-    int64_t row = plan[0].out_row;
-    for (int i = 0; i < n_images; ++i) {                  // images must tile the crop list and the output in order
+    // Images come in order; their crop ranges and output row ranges must not overlap and must lie inside
+    // tokens [n_crops, M, D] / out [out_rows, D].  GAPS between the output ranges are allowed and left untouched (the
+    // text embeddings of inputs_embeds live there, llava_arch.py:172-191); gaps in the crop list are allowed too.
+    int64_t crop = 0, row = 0;
+    for (int i = 0; i < n_images; ++i) {
         if (plan[i].h_block < 1 || plan[i].w_block < 1 || plan[i].first_crop < crop || plan[i].out_row < row) {
-            set_error("tp_hd_assemble: plan entry %d is inconsistent", i);
+            set_error("tp_hd_assemble: plan entry %d is inconsistent (overlaps its predecessor or is out of order)", i);
             return TP_ERR_INVALID_ARG;
         }
-        crop = plan[i].first_crop + plan[i].h_block * plan[i].w_block + (plan[i].h_block * plan[i].w_block > 1 ? 1 : 0);
+        crop = (int64_t)plan[i].first_crop + plan[i].h_block * plan[i].w_block + (plan[i].h_block * plan[i].w_block > 1 ? 1 : 0);
         row = plan[i].out_row + tp_hd_rows(plan[i].h_block, plan[i].w_block, M);
+        if (crop > n_crops || row > out_rows) {
+            set_error("tp_hd_assemble: plan entry %d reads crops up to %lld of %lld / writes rows up to %lld of %lld", i,
+                      (long long)crop, (long long)n_crops, (long long)row, (long long)out_rows);
+            return TP_ERR_INVALID_ARG;
+        }
     }
-    return hd_assemble_launch(plan, n_images, tokens, sep, ret, out, M, D, (hipStream_t)stream);
+    return hd_assemble_launch(plan, n_images, tokens, crop_map, sep, ret, out, M, D, (hipStream_t)stream);
 }
 
 int tp_ln_finalize(const float* row_stats, int parts, int64_t M, int ln_dim, float eps, float* row_mean_rstd, void* stream) {

@@ -89,19 +89,22 @@ int region_attention_launch(const void* q, const void* k, const void* v, void* o
 int hd_slice_launch(const float* img, int H, int W, int h_block, int w_block, int h_res, int w_res, int hg, int wg,
                     float* crops, int block, hipStream_t stream);
 int occupy_cus_launch(int blocks, int usec, int* sink, hipStream_t stream);
-int hd_assemble_launch(const tp_hd_image* plan_dev_or_host, int n_images, const void* tokens, const void* sep,
+int hd_assemble_launch(const tp_hd_image* plan_host, int n_images, const void* tokens, const int32_t* crop_map, const void* sep,
                        const void* ret, void* out, int M, int D, hipStream_t stream);
 int ln_finalize_launch(const float* parts, float* mean_rstd, long long M, int nparts, int groups, int ln_dim,
                        float eps, hipStream_t stream);
 int pack_cast_f32_launch(int dtype, const void* src, float* dst, int n, hipStream_t stream);
-int pack_cast_f16_launch(int dtype, const void* src, void* dst_f16, long long n, hipStream_t stream);
+// `sat` (optional): device int incremented once per element that did not fit fp16 and was clamped to +-65504
+int pack_cast_f16_launch(int dtype, const void* src, void* dst_f16, long long n, hipStream_t stream, int* sat = nullptr);
 int pack_transpose_f16_launch(const void* src_f16, void* dst_f16, int n, hipStream_t stream);          // [n,n]
-int pack_round_f16_launch(const float* src, void* dst_f16, long long n, hipStream_t stream);           // saturating
+int pack_round_f16_launch(const float* src, void* dst_f16, long long n, hipStream_t stream, int* sat = nullptr);   // saturating
 int pack_bias_fold_launch(const void* w_f16, const float* v, const float* b, float* out, int n_out, int n_in,
                           hipStream_t stream);                                                          // out = w·v + b
 int pack_ln_fold_launch(int dtype, const void* w, const void* bias, const void* gamma,
                         const void* beta, void* w_out, float* colsum, float* bias_out, int n_out,
-                        int n_in, hipStream_t stream);
+                        int n_in, hipStream_t stream, int* sat = nullptr);
+// debug: counts[i] += number of fp16 elements of buf[i] (n[i] of them) with |v| >= 65504 or NaN (a saturated epilogue)
+int count_saturated_launch(const void* buf, long long n, int* count, hipStream_t stream);
 
 // ---- packed-weight and workspace layouts (tp_api.hip) -----------------------------------------
 struct PackedLayout {
@@ -115,6 +118,8 @@ struct PackedLayout {
     size_t w_m2, b_m2;            // [D,D] f16, [D] f32
     size_t w_om, b_om;            // out_proj folded into mlp[0]: (Wm0·Wout) [D,1024] f16, Wm0·bout + bm0 [D] f32
     size_t scratch_t, scratch_p;  // pack-time scratch: Wout^T [1024,1024] f16, the fp32 product [D,1024]
+    size_t status;                // int32[64]: [0] = weight elements clamped to the fp16 range by tp_pack_weights,
+                                  // [1] = 1 when w_om / b_om were built (TP_TUNE_FOLD_OUT_PROJ at pack time)
     size_t total;
 };
 PackedLayout packed_layout(int D);

@@ -215,29 +215,33 @@ int occupy_cus_launch(int blocks, int usec, int* sink, hipStream_t stream) {
 struct HdPlan { tp_hd_image img[64]; int n; };
 
 __global__ void __launch_bounds__(256)
-hd_assemble_kernel(const HdPlan plan, const uint4* __restrict__ tokens, const uint4* __restrict__ sep,
-                   const uint4* __restrict__ ret, uint4* __restrict__ out, int M, int vecs, long long row0) {
+hd_assemble_kernel(const HdPlan plan, const uint4* __restrict__ tokens, const int* __restrict__ crop_map,
+                   const uint4* __restrict__ sep, const uint4* __restrict__ ret, uint4* __restrict__ out, int M, int vecs,
+                   long long row0) {
     const long long row = row0 + blockIdx.x;
     int i = 0;
     while (i + 1 < plan.n && row >= plan.img[i + 1].out_row) ++i;      // images are in row order
     const tp_hd_image im = plan.img[i];
-    const int r = (int)(row - im.out_row);
+    const long long r64 = row - im.out_row;
     const int n = im.h_block * im.w_block, seg_rows = M + 1;
+    if (r64 >= (long long)n * seg_rows + (n > 1 ? seg_rows : 0)) return;      // a gap between two images: not ours to write
+    const int r = (int)r64;
     const uint4* src;
     if (r < n * seg_rows) {
         const int seg = r / seg_rows, k = r - seg * seg_rows;
-        if (k < M) src = tokens + ((long long)(im.first_crop + seg) * M + k) * vecs;
+        // (crop_map: logical crop -> row block of `tokens`, e.g. the padded slots of a ragged all-gather)
+        if (k < M) { const int c = im.first_crop + seg; src = tokens + ((long long)(crop_map ? crop_map[c] : c) * M + k) * vecs; }
         else src = (seg % im.w_block == im.w_block - 1) ? ret : sep;
     } else {
-        const int k = r - n * seg_rows;
-        src = k < M ? tokens + ((long long)(im.first_crop + n) * M + k) * vecs : ret;
+        const int k = r - n * seg_rows, c = im.first_crop + n;
+        src = k < M ? tokens + ((long long)(crop_map ? crop_map[c] : c) * M + k) * vecs : ret;
     }
     uint4* dst = out + row * vecs;
     for (int v = threadIdx.x; v < vecs; v += blockDim.x) dst[v] = src[v];
 }
 
-int hd_assemble_launch(const tp_hd_image* plan, int n_images, const void* tokens, const void* sep, const void* ret,
-                       void* out, int M, int D, hipStream_t stream) {
+int hd_assemble_launch(const tp_hd_image* plan, int n_images, const void* tokens, const int32_t* crop_map, const void* sep,
+                       const void* ret, void* out, int M, int D, hipStream_t stream) {
     const int vecs = D / 8;
     for (int base = 0; base < n_images; base += 64) {
         HdPlan hp{};
@@ -248,7 +252,7 @@ int hd_assemble_launch(const tp_hd_image* plan, int n_images, const void* tokens
         const long long rows = last.out_row + tp_hd_rows(last.h_block, last.w_block, M) - row0;
         if (rows <= 0) continue;
         hipLaunchKernelGGL(hd_assemble_kernel, dim3((unsigned)rows), dim3(256), 0, stream, hp, (const uint4*)tokens,
-                           (const uint4*)sep, (const uint4*)ret, (uint4*)out, M, vecs, row0);
+                           (const int*)crop_map, (const uint4*)sep, (const uint4*)ret, (uint4*)out, M, vecs, row0);
         const int rc = check_launch("hd_assemble_kernel");
         if (rc != TP_OK) return rc;
     }
@@ -374,19 +378,49 @@ int pack_cast_f32_launch(int dtype, const void* src, float* dst, int n, hipStrea
     return check_launch("pack_cast_f32_kernel");
 }
 
-template <typename T>
-__global__ void pack_cast_f16_kernel(const T* __restrict__ src, f16_t* __restrict__ dst, long long n) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = (f16_t)fminf(fmaxf((float)src[i], -65504.f), 65504.f);   // exact for in-range bf16
+// (a clamped element is an event that never happens with trained weights: one atomic per offender is fine)
+__device__ __forceinline__ float clamp_f16_range(float v, int* sat) {
+    if (sat && !(fabsf(v) <= 65504.f)) atomicAdd(sat, 1);
+    return fminf(fmaxf(v, -65504.f), 65504.f);
 }
 
-int pack_cast_f16_launch(int dtype, const void* src, void* dst, long long n, hipStream_t stream) {
+template <typename T>
+__global__ void pack_cast_f16_kernel(const T* __restrict__ src, f16_t* __restrict__ dst, long long n, int* sat) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (f16_t)clamp_f16_range((float)src[i], sat);   // exact for in-range bf16
+}
+
+int pack_cast_f16_launch(int dtype, const void* src, void* dst, long long n, hipStream_t stream, int* sat) {
     const unsigned blocks = (unsigned)((n + 255) / 256);
     if (dtype == TP_BF16)
-        hipLaunchKernelGGL(pack_cast_f16_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)src, (f16_t*)dst, n);
+        hipLaunchKernelGGL(pack_cast_f16_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)src, (f16_t*)dst, n, sat);
     else
-        hipLaunchKernelGGL(pack_cast_f16_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream, (const f16_t*)src, (f16_t*)dst, n);
+        hipLaunchKernelGGL(pack_cast_f16_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream, (const f16_t*)src, (f16_t*)dst, n, sat);
     return check_launch("pack_cast_f16_kernel");
+}
+
+// Debug scan of an fp16 activation buffer for saturated epilogue outputs (tp_debug_count_saturated): every kernel of
+// the path clamps to +-65504 instead of producing inf, so an element AT the bound (or a NaN) marks a clamp.
+__global__ void __launch_bounds__(256)
+count_saturated_kernel(const f16x8* __restrict__ buf, long long nvec, int* __restrict__ count) {
+    int local = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        const f16x8 v = buf[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) local += !(fabsf((float)v[e]) < 65504.f);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) local += __shfl_xor(local, off);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, local);
+}
+
+int count_saturated_launch(const void* buf, long long n, int* count, hipStream_t stream) {
+    const long long nvec = n / 8;
+    long long blocks = (nvec + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(count_saturated_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const f16x8*)buf, nvec, count);
+    return check_launch("count_saturated_kernel");
 }
 
 // out_proj folded into mlp[0] (both are linear with nothing in between, builder.py:126-130 -> :136):
@@ -409,13 +443,13 @@ int pack_transpose_f16_launch(const void* src, void* dst, int n, hipStream_t str
     return check_launch("pack_transpose_f16_kernel");
 }
 
-__global__ void pack_round_f16_kernel(const float* __restrict__ src, f16_t* __restrict__ dst, long long n) {
+__global__ void pack_round_f16_kernel(const float* __restrict__ src, f16_t* __restrict__ dst, long long n, int* sat) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = (f16_t)fminf(fmaxf(src[i], -65504.f), 65504.f);
+    if (i < n) dst[i] = (f16_t)clamp_f16_range(src[i], sat);
 }
 
-int pack_round_f16_launch(const float* src, void* dst, long long n, hipStream_t stream) {
-    hipLaunchKernelGGL(pack_round_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, (f16_t*)dst, n);
+int pack_round_f16_launch(const float* src, void* dst, long long n, hipStream_t stream, int* sat) {
+    hipLaunchKernelGGL(pack_round_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, (f16_t*)dst, n, sat);
     return check_launch("pack_round_f16_kernel");
 }
 
@@ -448,12 +482,12 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 pack_ln_fold_kernel(const T* __restrict__ w, const T* __restrict__ bias, const T* __restrict__ gamma,
                     const T* __restrict__ beta, f16_t* __restrict__ w_out, float* __restrict__ colsum,
-                    float* __restrict__ bias_out, int n_in) {
+                    float* __restrict__ bias_out, int n_in, int* sat) {
     const int n = blockIdx.x;
     float cs = 0.f, bs = 0.f;
     for (int kk = threadIdx.x; kk < n_in; kk += blockDim.x) {
         const float wv = (float)w[(long long)n * n_in + kk];
-        const f16_t wp = (f16_t)fminf(fmaxf(wv * (float)gamma[kk], -65504.f), 65504.f);
+        const f16_t wp = (f16_t)clamp_f16_range(wv * (float)gamma[kk], sat);
         w_out[(long long)n * n_in + kk] = wp;
         cs += (float)wp;
         bs = fmaf((float)beta[kk], wv, bs);
@@ -471,15 +505,15 @@ pack_ln_fold_kernel(const T* __restrict__ w, const T* __restrict__ bias, const T
 
 int pack_ln_fold_launch(int dtype, const void* w, const void* bias, const void* gamma,
                         const void* beta, void* w_out, float* colsum, float* bias_out, int n_out,
-                        int n_in, hipStream_t stream) {
+                        int n_in, hipStream_t stream, int* sat) {
     if (dtype == TP_BF16)
         hipLaunchKernelGGL(pack_ln_fold_kernel<bf16_t>, dim3(n_out), dim3(256), 0, stream,
                            (const bf16_t*)w, (const bf16_t*)bias, (const bf16_t*)gamma, (const bf16_t*)beta,
-                           (f16_t*)w_out, colsum, bias_out, n_in);
+                           (f16_t*)w_out, colsum, bias_out, n_in, sat);
     else
         hipLaunchKernelGGL(pack_ln_fold_kernel<f16_t>, dim3(n_out), dim3(256), 0, stream,
                            (const f16_t*)w, (const f16_t*)bias, (const f16_t*)gamma, (const f16_t*)beta,
-                           (f16_t*)w_out, colsum, bias_out, n_in);
+                           (f16_t*)w_out, colsum, bias_out, n_in, sat);
     return check_launch("pack_ln_fold_kernel");
 }
 

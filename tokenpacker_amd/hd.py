@@ -12,7 +12,7 @@
 from __future__ import annotations
 
 import ctypes
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -101,10 +101,20 @@ def hd_crop_count(h_block: int, w_block: int) -> int:
 
 
 def assemble_hd_tokens(image_features: torch.Tensor, h_block: Sequence[int], w_block: Sequence[int],
-                       sep_embed: torch.Tensor, ret_embed: torch.Tensor) -> List[torch.Tensor]:
+                       sep_embed: torch.Tensor, ret_embed: torch.Tensor, out: Optional[torch.Tensor] = None,
+                       out_rows: Optional[Sequence[int]] = None, crop_map: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
     """``image_features [n_crops, M, D]`` (projector output for all crops of the batch, crops of image 0 first,
     row-major inside an image, global view last) -> list of per-image ``[rows_i, D]`` views of one buffer, equal
-    to the reference's ``cur_image_features`` for each image."""
+    to the reference's ``cur_image_features`` for each image.
+
+    With ``out [rows, D]`` and ``out_rows`` (first row of each image's block, increasing) the blocks are written
+    INTO a caller-owned buffer — e.g. the flattened ``inputs_embeds`` with the text embeddings already in place
+    (llava_arch.py:172-191) — and everything between the blocks is left untouched: the visual tokens land where
+    the LLM reads them, with no per-image ``torch.cat``.
+
+    ``crop_map`` (int32 device tensor, one entry per crop): crop c is row block ``crop_map[c]`` of ``image_features``
+    — the b_max-strided buffer of a ragged all-gather (``shard.GatheredTokens.buf`` / ``.crop_map()``) is read in
+    place instead of being compacted first."""
     if not image_features.is_cuda:
         raise RuntimeError("assemble_hd_tokens runs only on an AMD GPU (HIP kernel); there is no CPU fallback")
     if image_features.dim() != 3:
@@ -112,6 +122,11 @@ def assemble_hd_tokens(image_features: torch.Tensor, h_block: Sequence[int], w_b
     if len(h_block) != len(w_block):
         raise ValueError("h_block and w_block must have one entry per image")
     n_crops, M, D = image_features.shape
+    if crop_map is not None:
+        if crop_map.dtype != torch.int32 or crop_map.dim() != 1 or crop_map.device != image_features.device \
+                or not crop_map.is_contiguous():
+            raise ValueError("crop_map must be a contiguous int32 vector on the features' device")
+        n_crops = crop_map.numel()
     dt = {torch.bfloat16: _capi.TP_BF16, torch.float16: _capi.TP_F16}.get(image_features.dtype)
     if dt is None:
         raise TypeError("image_features must be bfloat16 or float16")
@@ -120,12 +135,20 @@ def assemble_hd_tokens(image_features: torch.Tensor, h_block: Sequence[int], w_b
     ret = ret_embed.reshape(-1).to(device=feats.device, dtype=feats.dtype).contiguous()
     if sep.numel() != D or ret.numel() != D:
         raise ValueError(f"separator embeddings must have {D} elements")
+    if (out is None) != (out_rows is None):
+        raise ValueError("pass `out` and `out_rows` together")
+    if out_rows is not None and len(out_rows) != len(h_block):
+        raise ValueError("out_rows must have one entry per image")
     plan = (_capi.tp_hd_image * len(h_block))()
     first, row, spans = 0, 0, []
     for i, (hb, wb) in enumerate(zip(h_block, w_block)):
         hb, wb = int(hb), int(wb)
         if hb < 1 or wb < 1:
             raise ValueError("h_block / w_block must be >= 1")
+        if out_rows is not None:
+            if int(out_rows[i]) < row:
+                raise ValueError(f"out_rows[{i}] = {int(out_rows[i])} overlaps the previous image's block (ends at {row})")
+            row = int(out_rows[i])
         plan[i] = _capi.tp_hd_image(first, hb, wb, 0, row)
         rows = hd_token_rows(hb, wb, M)
         spans.append((row, rows))
@@ -133,10 +156,19 @@ def assemble_hd_tokens(image_features: torch.Tensor, h_block: Sequence[int], w_b
         row += rows
     if first != n_crops:
         raise ValueError(f"h_block/w_block describe {first} crops, image_features holds {n_crops}")
-    out = torch.empty(row, D, dtype=feats.dtype, device=feats.device)
+    if out is None:
+        out = torch.empty(row, D, dtype=feats.dtype, device=feats.device)
+    else:
+        if out.dim() != 2 or out.shape[1] != D or out.dtype != feats.dtype or out.device != feats.device \
+                or not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous [rows, {D}] {feats.dtype} tensor on {feats.device}")
+        if row > out.shape[0]:
+            raise ValueError(f"the last image's block ends at row {row}, out has {out.shape[0]} rows")
     lib = _capi.load_library()
     with torch.cuda.device(feats.device):
-        _capi.check(lib.tp_hd_assemble(plan, len(h_block), feats.data_ptr(), sep.data_ptr(), ret.data_ptr(),
-                                       out.data_ptr(), M, D, dt, torch.cuda.current_stream(feats.device).cuda_stream),
+        _capi.check(lib.tp_hd_assemble(plan, len(h_block), feats.data_ptr(), n_crops,
+                                       crop_map.data_ptr() if crop_map is not None else None, sep.data_ptr(), ret.data_ptr(),
+                                       out.data_ptr(), out.shape[0], M, D, dt,
+                                       torch.cuda.current_stream(feats.device).cuda_stream),
                     "tp_hd_assemble")
     return [out[a:a + n] for a, n in spans]

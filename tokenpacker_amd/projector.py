@@ -41,16 +41,16 @@ class _ProjectFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x, n_parts, *rest):
         xm, params = rest[:n_parts], rest[n_parts:]          # x_multi: one tensor, or its four sources
-        out, train_ws, desc = module._launch_forward(x, xm[0] if n_parts == 1 else xm, train=True)
+        out, train_ws, desc, packed = module._launch_forward(x, xm[0] if n_parts == 1 else xm, train=True)
         ctx.module, ctx.desc, ctx.n_parts = module, desc, n_parts
-        ctx.save_for_backward(train_ws, *xm, *params)
+        ctx.save_for_backward(train_ws, packed, *xm, *params)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        train_ws, *rest = ctx.saved_tensors
+        train_ws, packed, *rest = ctx.saved_tensors
         xm, params = rest[:ctx.n_parts], rest[ctx.n_parts:]
-        grads = ctx.module._launch_backward(ctx.desc, xm[0] if ctx.n_parts == 1 else xm, train_ws, params, dy)
+        grads = ctx.module._launch_backward(ctx.desc, xm[0] if ctx.n_parts == 1 else xm, train_ws, packed, params, dy)
         return (None, None, None) + (None,) * ctx.n_parts + tuple(grads)
 
 
@@ -58,6 +58,7 @@ class TokenPacker(nn.Module):
     """Region-to-point visual projector (see module docstring)."""
 
     MULTI_LEVEL_DIM = 4096      # builder.py:61,67 hard-code nn.Linear(4096, 1024)
+    supports_out = True         # forward(..., _out=buffer): tokenpacker_amd.shard writes ragged shards into their gather slot
 
     def __init__(self, raw_grid: int = 24, embed_dim: int = 1024, num_heads: int = 1024 // 128,
                  kv_dim: int = 1024, hidden_size: int = 4096, scale_factor: int = 2,
@@ -93,9 +94,19 @@ class TokenPacker(nn.Module):
         #: set True to receive fp32 output straight from the last GEMM's accumulators
         #: (validation mode of SURVEY.md §8c; default = input dtype like the reference)
         self.output_fp32 = False
+        #: fp32 callers.  The reference module runs in any dtype; the HIP kernels compute in bf16 / fp16 MFMA.  Under
+        #: ``torch.autocast`` an fp32 module (fp32 master weights) is served in the autocast dtype like every
+        #: ``nn.Linear`` of the reference would be.  Outside autocast an fp32 module is refused unless this names the
+        #: dtype to compute in (torch.float16 / torch.bfloat16): operands are rounded to it, the result comes back
+        #: as fp32 from the last GEMM's accumulators (within 1e-3 of the fp32 reference, not bit-comparable to it).
+        self.fp32_compute_dtype: Optional[torch.dtype] = None
         self._packed: Optional[torch.Tensor] = None
         self._packed_key = None
+        self._packed_event = None
+        self._packed_stream = None
+        self._overflow_checked = False
         self._workspaces: Dict[tuple, torch.Tensor] = {}
+        self._last_launch = None             # (desc, workspace) of the last inference forward: saturation_report()
 
     # ------------------------------------------------------------------------------------------
     def _reset_parameters(self) -> None:
@@ -119,17 +130,35 @@ class TokenPacker(nn.Module):
     def _ln_eps(self) -> float:
         return float(self.ln_q_1.eps)
 
-    def _ensure_packed(self, dtype: torch.dtype, device: torch.device, stream_ptr: int) -> torch.Tensor:
-        """(Re)build the kernel-side weight image when any parameter storage or version changed
-        (optimizer step, load_state_dict, .to())."""
+    def invalidate_packed(self) -> None:
+        """Drop the kernel-side weight image; the next forward re-packs from the current parameters.
+
+        The inference (``no_grad``) path caches the image and re-validates it by ``(data_ptr, _version)`` of every
+        parameter, which sees ``optimizer.step()``, ``load_state_dict`` and ``.to()`` but NOT writes that bypass
+        autograd's version counter — ``p.data.copy_(...)``, DeepSpeed ZeRO's flat-buffer updates, fused multi-tensor
+        optimizers writing through raw pointers.  Every grad-enabled forward therefore re-packs unconditionally and
+        leaves the cache invalid behind it; code that rewrites weights out of band between two ``no_grad`` forwards
+        calls this."""
+        self._packed, self._packed_key = None, None
+
+    def _ensure_packed(self, dtype: torch.dtype, device: torch.device, stream_ptr: int, force: bool = False) -> torch.Tensor:
+        """(Re)build the kernel-side weight image: always when ``force`` (training forward), otherwise when any
+        parameter storage / version, the compute dtype or the pack-time tuning changed."""
         weights = self._named_weights()
-        key = (dtype, device, tuple((w.data_ptr(), w._version) for w in weights))
-        if self._packed is not None and self._packed_key == key:
+        fold = _capi.get_tuning(_capi.TP_TUNE_FOLD_OUT_PROJ)
+        key = (dtype, device, fold, tuple((w.data_ptr(), w._version) for w in weights))
+        stream = torch.cuda.current_stream(device)
+        if not force and self._packed is not None and self._packed_key == key:
+            if self._packed_stream != stream_ptr and self._packed_event is not None:
+                stream.wait_event(self._packed_event)         # packed on another stream: order this one behind it
             return self._packed
         for name, w in zip(_capi.WEIGHT_FIELDS, weights):
-            if w.dtype != dtype or w.device != device:
+            if w.device != device or not w.dtype.is_floating_point:
                 raise TypeError(f"parameter {name} is {w.dtype} on {w.device}; inputs are {dtype} on {device} "
-                                f"(cast the module with .to(...) like the reference does)")
+                                f"(move the module with .to(...) like the reference does)")
+            if w.dtype != dtype and not (torch.is_autocast_enabled("cuda") or self.fp32_compute_dtype is not None):
+                raise TypeError(f"parameter {name} is {w.dtype}, inputs are {dtype}: cast the module with .to({dtype}) like "
+                                f"the reference does, or run under torch.autocast")
         lib = _capi.load_library()
         desc = _capi.make_desc(1, self.raw_grid, self.scale_factor, self.hidden_size, _DTYPES[dtype],
                                ln_eps=self._ln_eps())
@@ -137,11 +166,28 @@ class TokenPacker(nn.Module):
         if nbytes == 0:
             raise RuntimeError(f"tp_packed_weight_bytes: {_capi.last_error()}")
         packed = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        contiguous = [w.detach().contiguous() for w in weights]      # keeps temporaries alive until enqueued
+        # fp32 master weights (autocast / fp32_compute_dtype) are rounded to the compute dtype here, like autocast does
+        contiguous = [w.detach().to(dtype).contiguous() for w in weights]      # keeps temporaries alive until enqueued
         raw = _capi.tp_weights(*[t.data_ptr() for t in contiguous])
         _capi.check(lib.tp_pack_weights(ctypes.byref(desc), ctypes.byref(raw), packed.data_ptr(), nbytes,
                                         stream_ptr), "tp_pack_weights")
-        self._packed, self._packed_key = packed, key
+        if not force or not self._overflow_checked:
+            # weights beyond the fp16 range (a bf16 model can hold them) were clamped by the pack kernels: refuse
+            # instead of silently differing from the reference.  One 4-byte read-back per (rare) inference re-pack
+            # and on the first training pack only — a training step must not synchronise.
+            off = lib.tp_packed_status_offset(ctypes.byref(desc))
+            clamped = int(packed[off:off + 4].view(torch.int32).item())
+            self._overflow_checked = True
+            if clamped:
+                raise OverflowError(f"{clamped} weight element(s) exceed the fp16 range (|w| > 65504) the HIP kernels keep "
+                                    f"post-first-layer weights in; the reference would compute with them in {dtype}")
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self._packed_event, self._packed_stream = ev, stream_ptr
+        if force:
+            self._packed, self._packed_key = None, None       # a training step's image is never reused (see invalidate_packed)
+        else:
+            self._packed, self._packed_key = packed, key
         return packed
 
     def _workspace(self, nbytes: int, device: torch.device, stream_ptr) -> torch.Tensor:
@@ -153,7 +199,13 @@ class TokenPacker(nn.Module):
         return ws
 
     # ------------------------------------------------------------------------------------------
-    def forward(self, x, attn_mask=None, _stage_events=None):
+    def out_like(self, x: torch.Tensor):
+        """``(tensor carrying the result's dtype / device, (M, D))`` for inputs like ``x`` — lets a caller allocate the
+        buffer it passes as ``_out``."""
+        dt = torch.float32 if self.output_fp32 else x.dtype
+        return torch.empty(0, dtype=dt, device=x.device), (self.num_queries, self.hidden_size)
+
+    def forward(self, x, attn_mask=None, _stage_events=None, _out=None):
         if attn_mask is not None:
             raise NotImplementedError("attn_mask is always None on the reference path (llava_arch.py:97)")
         x_multi = x[1]      # multi-level [B, N, 4096] — or its four [B, N, 1024] sources (tokenpacker_amd.tower)
@@ -167,8 +219,19 @@ class TokenPacker(nn.Module):
         if not (x.is_cuda and all(t.is_cuda for t in (parts or (x_multi,)))):
             raise RuntimeError("tokenpacker_amd.TokenPacker runs only on an AMD GPU (HIP kernels); "
                                "there is no CPU fallback")
-        if x.dtype not in _DTYPES or any(t.dtype != x.dtype for t in (parts or (x_multi,))):
-            raise TypeError(f"supported dtypes: bfloat16 / float16 for both inputs (got {x.dtype}, {x_multi.dtype})")
+        if any(t.dtype != x.dtype for t in (parts or (x_multi,))):
+            raise TypeError(f"x and x_multi must share a dtype (got {x.dtype}, {x_multi.dtype})")
+        compute_dtype, fp32_caller = x.dtype, False
+        if torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in _DTYPES \
+                and x.dtype in (torch.float32, torch.bfloat16, torch.float16):
+            compute_dtype = torch.get_autocast_dtype("cuda")          # what every nn.Linear of the reference would run in
+        elif x.dtype == torch.float32 and self.fp32_compute_dtype is not None:
+            if self.fp32_compute_dtype not in _DTYPES:
+                raise TypeError("fp32_compute_dtype must be torch.float16 or torch.bfloat16")
+            compute_dtype, fp32_caller = self.fp32_compute_dtype, True
+        if compute_dtype not in _DTYPES:
+            raise TypeError(f"supported dtypes: bfloat16 / float16 for both inputs (got {x.dtype}); an fp32 module runs "
+                            f"under torch.autocast, or with module.fp32_compute_dtype set (see its docstring)")
         N = self.raw_grid * self.raw_grid
         cm = self.MULTI_LEVEL_DIM // 4 if parts else self.MULTI_LEVEL_DIM
         if x.dim() != 3 or x.shape[1] != N or x.shape[2] != self.embed_dim \
@@ -182,10 +245,16 @@ class TokenPacker(nn.Module):
                 "frozen and runs under no_grad, clip_encoder.py:46); detach them")
         if x.shape[0] == 0:                  # empty batch: the reference returns an empty [0, M, D] tensor
             out_dtype = torch.float32 if self.output_fp32 else x.dtype
-            y = x.new_zeros((0, self.num_queries, self.hidden_size), dtype=out_dtype)
+            y = x.new_zeros((0, self.num_queries, self.hidden_size), dtype=out_dtype) if _out is None else _out
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
                 y = y + 0.0 * sum(p.sum() for p in self.parameters() if p.requires_grad).to(out_dtype)
             return y
+        if x.dtype != compute_dtype:                  # autocast / fp32 caller: operands rounded once, like autocast's casts
+            x = x.to(compute_dtype)
+            if parts:
+                parts = tuple(t.to(compute_dtype) for t in parts)
+            else:
+                x_multi = x_multi.to(compute_dtype)
         # the kernels take element strides (tower outputs are [:,1:] slices); only fix layouts they cannot address
         x = self._addressable(x)
         if parts:
@@ -196,17 +265,17 @@ class TokenPacker(nn.Module):
         else:
             x_multi = self._addressable(x_multi)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            if _stage_events is not None or self.output_fp32:
-                raise NotImplementedError("staged timing / fp32 output are inference-only")
+            if _stage_events is not None or self.output_fp32 or fp32_caller or _out is not None:
+                raise NotImplementedError("staged timing / fp32 output / fp32_compute_dtype / _out are inference-only")
             if not all(p.requires_grad for p in self.parameters()):
                 raise NotImplementedError("training needs requires_grad on ALL projector parameters "
                                           "(the reference trains the whole projector, train.py:952-958)")
             xm = x_multi if parts else (x_multi,)
             return _ProjectFn.apply(self, x, len(xm), *xm, *self._named_weights())
-        return self._launch_forward(x, x_multi, train=False, _stage_events=_stage_events)[0]
+        return self._launch_forward(x, x_multi, train=False, _stage_events=_stage_events, fp32_out=fp32_caller, out=_out)[0]
 
     # ------------------------------------------------------------------------------------------
-    def _launch_forward(self, x, x_multi, train: bool, _stage_events=None):
+    def _launch_forward(self, x, x_multi, train: bool, _stage_events=None, fp32_out: bool = False, out=None):
         B, device = x.shape[0], x.device
         parts = x_multi if isinstance(x_multi, tuple) else None
         if parts:
@@ -217,11 +286,17 @@ class TokenPacker(nn.Module):
         with torch.cuda.device(device):
             stream_ptr = torch.cuda.current_stream(device).cuda_stream
             lib = _capi.load_library()
-            packed = self._ensure_packed(x.dtype, device, stream_ptr)
-            out_dtype = torch.float32 if self.output_fp32 else x.dtype
+            packed = self._ensure_packed(x.dtype, device, stream_ptr, force=train)
+            fp32_out = fp32_out or self.output_fp32
+            out_dtype = torch.float32 if fp32_out else x.dtype
             desc = _capi.make_desc(B, self.raw_grid, self.scale_factor, self.hidden_size, _DTYPES[x.dtype],
-                                   _capi.TP_F32 if self.output_fp32 else _DTYPES[x.dtype], self._ln_eps())
-            out = torch.empty(B, self.num_queries, self.hidden_size, dtype=out_dtype, device=device)
+                                   _capi.TP_F32 if fp32_out else _DTYPES[x.dtype], self._ln_eps())
+            if out is None:
+                out = torch.empty(B, self.num_queries, self.hidden_size, dtype=out_dtype, device=device)
+            elif tuple(out.shape) != (B, self.num_queries, self.hidden_size) or out.dtype != out_dtype \
+                    or out.device != device or not out.is_contiguous() or out.data_ptr() % 16:
+                raise ValueError(f"_out must be a contiguous, 16-byte aligned [{B}, {self.num_queries}, {self.hidden_size}] "
+                                 f"{out_dtype} tensor on {device}")
             if train:
                 ws_bytes = lib.tp_train_workspace_bytes(ctypes.byref(desc))
                 if ws_bytes == 0:
@@ -237,7 +312,7 @@ class TokenPacker(nn.Module):
                                                      x_multi.data_ptr(), _capi.strides3(x_multi.stride()),
                                                      packed.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
                                                      stream_ptr), "tp_forward_train")
-                return out, ws, desc
+                return out, ws, desc, packed
             ws_bytes = lib.tp_workspace_bytes(ctypes.byref(desc))
             if ws_bytes == 0:
                 raise RuntimeError(f"tp_workspace_bytes: {_capi.last_error()}")
@@ -259,9 +334,26 @@ class TokenPacker(nn.Module):
                                                   x_multi.data_ptr(), _capi.strides3(x_multi.stride()),
                                                   packed.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
                                                   stream_ptr, handles, len(_stage_events)), "tp_forward_staged")
-        return out, ws, desc
+            self._last_launch = (desc, ws, stream_ptr)
+        return out, ws, desc, packed
 
-    def _launch_backward(self, desc, x_multi, train_ws, params, dy):
+    def saturation_report(self) -> Dict[str, int]:
+        """Debug aid: after an inference forward, how many elements of each fp16 intermediate (``q0, Hkv, H2, KV, Q1pre,
+        Q, O, A1, A2``) sit at the fp16 clamp bound (or are NaN).  Every epilogue clamps to +-65504 instead of
+        producing inf; all zeros means no activation of that forward left the fp16 range.
+        Scans the forward's own workspace (``tp_debug_count_saturated``) and synchronises — not for hot loops."""
+        if self._last_launch is None:
+            raise RuntimeError("saturation_report() needs a preceding inference forward")
+        desc, ws, stream_ptr = self._last_launch
+        lib = _capi.load_library()
+        with torch.cuda.device(ws.device):
+            counts = torch.zeros(_capi.TP_NUM_DEBUG_BUFFERS, dtype=torch.int32, device=ws.device)
+            _capi.check(lib.tp_debug_count_saturated(ctypes.byref(desc), ws.data_ptr(), ws.numel(), counts.data_ptr(),
+                                                     torch.cuda.current_stream(ws.device).cuda_stream),
+                        "tp_debug_count_saturated")
+            return dict(zip(_capi.DEBUG_BUFFER_NAMES, counts.tolist()))
+
+    def _launch_backward(self, desc, x_multi, train_ws, packed, params, dy):
         parts = tuple(x_multi) if isinstance(x_multi, (tuple, list)) else None
         if parts:
             x_multi = parts[0]
@@ -269,8 +361,9 @@ class TokenPacker(nn.Module):
         with torch.cuda.device(device):
             stream_ptr = torch.cuda.current_stream(device).cuda_stream
             lib = _capi.load_library()
-            packed = self._ensure_packed(x_multi.dtype, device, stream_ptr)
-            contiguous = [p.detach().contiguous() for p in params]
+            # `packed` is the image the forward of THIS step ran on; fp32 master weights (autocast) are rounded to the
+            # compute dtype for the dgrad operands exactly as they were for the forward
+            contiguous = [p.detach().to(x_multi.dtype).contiguous() for p in params]
             raw = _capi.tp_weights(*[t.data_ptr() for t in contiguous])
             grads = [torch.empty_like(t) for t in contiguous]
             gptr = _capi.tp_grads(*[t.data_ptr() for t in grads])
@@ -289,7 +382,7 @@ class TokenPacker(nn.Module):
                 _capi.check(lib.tp_backward(ctypes.byref(desc), x_multi.data_ptr(), _capi.strides3(x_multi.stride()),
                                             ctypes.byref(raw), packed.data_ptr(), train_ws.data_ptr(), dy.data_ptr(),
                                             ctypes.byref(gptr), bw.data_ptr(), bw.numel(), stream_ptr), "tp_backward")
-        return grads
+        return [g if g.dtype == p.dtype else g.to(p.dtype) for g, p in zip(grads, params)]
 
     def forward_staged(self, x):
         """Forward that also times every kernel of the schedule with HIP events recorded by the
