@@ -3,8 +3,10 @@
 Restates the ``mode == 'slice'`` branch of ``prepare_inputs_labels_for_multimodal``
 (reference ``llava/model/llava_arch.py:140-154``) for ONE image: crops in row-major order, the ``','`` embedding
 between crops of a row, the ``'\\n'`` embedding after every row, then — more than one crop — the global view
-and ``'\\n'``.  Parity pinned by construction: it is a concatenation, checked for length and content
-against the reference's own loop structure in ``tests/test_hd_cpu.py``.  The crop-grid choice
+and ``'\\n'``.  Parity PINNED: ``tests/golden/hd_splice.npz`` holds what the reference's unmodified
+``prepare_inputs_labels_for_multimodal`` returned for a seeded batch (``oracle/make_hd_golden.py:mint_splice``
+imports ``llava/model/llava_arch.py`` as it lies and calls it), and ``tests/test_hd_cpu.py`` checks
+:func:`splice_inputs_embeds` — which is built on :func:`assemble_one` — against it bit for bit.  The crop-grid choice
 (``Image_Patch.calculate``) is pinned by ``tests/golden/hd_grid.json``, minted from the real reference by
 ``oracle/make_hd_golden.py``."""
 from __future__ import annotations
@@ -41,6 +43,35 @@ def assemble_hd_tokens(image_features: torch.Tensor, h_block: Sequence[int], w_b
         out.append(t)
     assert idx == image_features.shape[0]
     return out
+
+
+def splice_inputs_embeds(input_ids: torch.Tensor, embed, image_features: torch.Tensor, h_block: Sequence[int],
+                         w_block: Sequence[int], sep_id: int, ret_id: int, image_token_index: int = -200) -> torch.Tensor:
+    """``new_input_embeds`` of ``prepare_inputs_labels_for_multimodal`` in ``mode == 'slice'`` (llava_arch.py:123-207,
+    default flags): per sample, text embeddings up to each image token, that image's assembled block (every image
+    token of sample b uses the grid ``h_block[b] x w_block[b]``), the remaining text; a sample without an image
+    token still consumes one crop index (:124-134); samples are zero-padded on the right to the longest (:193-200).
+    ``embed``: ids -> embeddings.  Returns ``[B, max_len, D]``."""
+    sep_e, ret_e = embed(torch.tensor([sep_id])), embed(torch.tensor([ret_id]))
+    outs, idx = [], 0
+    for b, ids in enumerate(input_ids):
+        if int((ids == image_token_index).sum()) == 0:
+            outs.append(embed(ids))
+            idx += 1
+            continue
+        pieces, cur = [], ids
+        while True:
+            pos = torch.where(cur == image_token_index)[0]
+            if pos.numel() == 0:
+                break
+            blk, idx = assemble_one(image_features, idx, int(h_block[b]), int(w_block[b]), sep_e, ret_e)
+            pieces += [embed(cur[:int(pos[0])]), blk]
+            cur = cur[int(pos[0]) + 1:]
+        if cur.numel() > 0:
+            pieces.append(embed(cur))
+        outs.append(torch.cat(pieces, dim=0))
+    L = max(o.shape[0] for o in outs)
+    return torch.stack([torch.cat([o, o.new_zeros(L - o.shape[0], o.shape[1])], dim=0) for o in outs], dim=0)
 
 
 def slice_image(image: torch.Tensor, h_block: int, w_block: int, block: int = 336) -> torch.Tensor:

@@ -93,5 +93,81 @@ def mint_slices():
     print("wrote", path, {k: tuple(v.shape) for k, v in out.items() if k.startswith("sub_")})
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# HD token assembly + splice: what the reference's UNMODIFIED prepare_inputs_labels_for_multimodal
+# (llava/model/llava_arch.py:100-233, mode == 'slice') returns for a seeded batch.  llava_arch is imported as it lies
+# (oracle/reference_loader.py); only its collaborators are stand-ins: encode_images returns the seeded "projector
+# output", the tokenizer maps ',' / '\\n' to two ids, the LM is an nn.Embedding.
+SPLICE = dict(D=32, M=4, vocab=40, sep_id=7, ret_id=11, seed=4242,
+              # (ids with -200 = image token, h_block, w_block) per sample; sample 2 has no image (consumes one crop)
+              samples=[([1, 2, -200, 3, 4, 5], 2, 3), ([6, -200, 8, -200, 17, 18], 1, 1), ([9, 10, 12, 13, 14, 15], 1, 1),
+                       ([-200, 16, 19, 20, 21, 22], 3, 1)])
+
+
+def splice_inputs():
+    import torch
+    g = torch.Generator().manual_seed(SPLICE["seed"])
+    D, M = SPLICE["D"], SPLICE["M"]
+    L = max(len(s[0]) for s in SPLICE["samples"])
+    assert all(len(s[0]) == L for s in SPLICE["samples"]), "the reference takes a rectangular input_ids"
+    ids = torch.tensor([s[0] for s in SPLICE["samples"]])
+    hb, wb = [s[1] for s in SPLICE["samples"]], [s[2] for s in SPLICE["samples"]]
+    n_crops = 0
+    for row, h, w in SPLICE["samples"]:
+        k = row.count(-200)
+        n_crops += max(k, 1) * (h * w + (1 if h * w > 1 else 0)) if k else 1
+    # values representable in bf16 / fp16, so that pure copies are exact in every dtype the kernel handles
+    feats = torch.randn(n_crops, M, D, generator=g).to(torch.bfloat16).half().float()
+    table = torch.randn(SPLICE["vocab"], D, generator=g).to(torch.bfloat16).half().float()
+    return ids, hb, wb, feats, table
+
+
+def mint_splice():
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    for name in ("torchvision", "torchvision.ops", "torchvision.ops.boxes"):      # load_reference()'s stubs confuse transformers
+        if name in sys.modules and getattr(sys.modules[name], "__spec__", None) is None:
+            del sys.modules[name]
+    from oracle import reference_loader as rl
+    arch = rl.import_llava_arch()
+    ids, hb, wb, feats, table = splice_inputs()
+
+    class LM(arch.LlavaMetaForCausalLM, torch.nn.Module):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            self.model = torch.nn.Module()
+            self.model.embed_tokens = torch.nn.Embedding.from_pretrained(table)
+            self.config = types.SimpleNamespace()
+            self.tokenizer = types.SimpleNamespace(
+                convert_tokens_to_ids=lambda toks: [{",": SPLICE["sep_id"], "\n": SPLICE["ret_id"]}[t] for t in toks])
+            self.device = torch.device("cpu")
+
+        def get_model(self):
+            return self.model
+
+        def get_vision_tower(self):
+            return object()                              # "there is a tower": llava_arch.py:103-104
+
+        def encode_images(self, images):                 # the projector output for all crops of the batch
+            return feats
+
+    with torch.no_grad():
+        _, _, _, embeds, _ = LM().prepare_inputs_labels_for_multimodal(ids, None, None, None, torch.zeros(1), "slice", hb, wb)
+    out = {"new_input_embeds": embeds.numpy(), "inputs_sha256": np.array(_digest(ids, feats, table))}
+    path = os.path.join(ROOT, "tests", "golden", "hd_splice.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, tuple(embeds.shape))
+
+
+def _digest(*ts):
+    import hashlib
+    h = hashlib.sha256()
+    for t in ts:
+        h.update(t.contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
 if __name__ == "__main__":
     mint_slices()
+    mint_splice()

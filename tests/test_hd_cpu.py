@@ -67,3 +67,18 @@ def test_slice_oracle_matches_reference_dataloader_code():
         assert float(crops.double().sum()) == s[0] and float(crops.double().abs().sum()) == s[1]
         # the resized extent implied by the plan is where the canvas stops being zero-padded
         assert plan[2] <= 336 * hb and plan[3] <= 336 * wb and (plan[2] == 336 * hb or plan[3] == 336 * wb)
+
+
+def test_splice_oracle_matches_the_unmodified_prepare_inputs_labels_for_multimodal():
+    """``hd_oracle.splice_inputs_embeds`` (and through it ``assemble_one``) against the output of the reference's own
+    function (llava_arch.py:100-233, mode 'slice'), called unmodified at mint time (oracle/make_hd_golden.py)."""
+    import numpy as np
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle"))
+    import make_hd_golden as mk
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "hd_splice.npz"))
+    ids, hb, wb, feats, table = mk.splice_inputs()
+    assert mk._digest(ids, feats, table) == str(z["inputs_sha256"])
+    got = hd_oracle.splice_inputs_embeds(ids, lambda t: table[t], feats, hb, wb, mk.SPLICE["sep_id"], mk.SPLICE["ret_id"])
+    want = torch.from_numpy(z["new_input_embeds"])
+    assert got.shape == want.shape and torch.equal(got, want)

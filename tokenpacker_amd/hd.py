@@ -172,3 +172,79 @@ def assemble_hd_tokens(image_features: torch.Tensor, h_block: Sequence[int], w_b
                                        torch.cuda.current_stream(feats.device).cuda_stream),
                     "tp_hd_assemble")
     return [out[a:a + n] for a, n in spans]
+
+
+def build_inputs_embeds(input_ids: torch.Tensor, embed_tokens, image_features: torch.Tensor, h_block: Sequence[int],
+                        w_block: Sequence[int], sep_id: int, ret_id: int, image_token_index: int = -200,
+                        crop_map: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``new_input_embeds [B, max_len, D]`` of the reference's ``prepare_inputs_labels_for_multimodal`` in
+    ``mode == 'slice'`` (``llava_arch.py:115-207``, default flags), with the visual tokens LANDING IN PLACE.
+
+    The reference walks every sample in Python, embeds text pieces one by one, builds each image's block with a
+    loop + ``torch.cat`` (:140-154), concatenates per sample (:190-191) and pads (:193-200).  Here the layout is
+    computed once on the host from ``input_ids`` (a tiny D2H copy — the reference synchronises per sample too),
+    ALL text tokens of the batch are embedded by one ``embed_tokens`` call and scattered into a zero-initialised
+    ``[B * max_len, D]`` buffer, and ONE ``tp_hd_assemble`` launch writes every image block into its rows of that
+    same buffer (gaps — the text rows — are left untouched).  ``image_features [n_crops, M, D]`` may be the
+    b_max-strided buffer of a ragged all-gather, read through ``crop_map`` (``shard.GatheredTokens``).
+    Every image token of sample b uses the grid ``h_block[b] x w_block[b]``; a sample without an image token still
+    consumes one crop index, as in the reference (:124-134).  Labels / attention masks stay host-side list logic
+    (out of scope)."""
+    if not image_features.is_cuda:
+        raise RuntimeError("build_inputs_embeds runs only on an AMD GPU (HIP kernel); there is no CPU fallback")
+    ids_cpu = input_ids.detach().cpu()
+    if ids_cpu.dim() != 2 or len(h_block) != ids_cpu.shape[0] or len(w_block) != ids_cpu.shape[0]:
+        raise ValueError("input_ids must be [B, L] with one h_block / w_block entry per sample")
+    M, D = image_features.shape[1], image_features.shape[2]
+    device, dtype = image_features.device, image_features.dtype
+    # ---- host-side layout: per sample a list of (text span | image block)
+    text_src, text_dst, img_plan, lengths, crop = [], [], [], [], 0
+    per_sample = []
+    for b, ids in enumerate(ids_cpu.tolist()):
+        hb, wb = int(h_block[b]), int(w_block[b])
+        segs, row, has_img = [], 0, False
+        for pos, tok in enumerate(ids):
+            if tok == image_token_index:
+                has_img = True
+                segs.append(("img", row, crop, hb, wb))
+                row += hd_token_rows(hb, wb, M)
+                crop += hd_crop_count(hb, wb)
+            else:
+                segs.append(("txt", row, pos))
+                row += 1
+        if not has_img:
+            crop += 1                                     # llava_arch.py:124-134: cur_image_idx += 1
+        per_sample.append(segs)
+        lengths.append(row)
+    n_logical = crop_map.numel() if crop_map is not None else image_features.shape[0]
+    if crop != n_logical:
+        raise ValueError(f"input_ids / h_block / w_block describe {crop} crops, image_features holds {n_logical}")
+    L = max(lengths)
+    for b, segs in enumerate(per_sample):
+        for seg in segs:
+            if seg[0] == "txt":
+                text_src.append(b * ids_cpu.shape[1] + seg[2])
+                text_dst.append(b * L + seg[1])
+            else:
+                img_plan.append((b * L + seg[1], seg[2], seg[3], seg[4]))
+    out = torch.zeros(ids_cpu.shape[0] * L, D, dtype=dtype, device=device)
+    ids_dev = input_ids.to(device).reshape(-1)
+    if text_src:
+        src = torch.tensor(text_src, dtype=torch.long, device=device)
+        dst = torch.tensor(text_dst, dtype=torch.long, device=device)
+        out.index_copy_(0, dst, embed_tokens(ids_dev.index_select(0, src)).to(dtype))
+    if img_plan:
+        seps = embed_tokens(torch.tensor([sep_id, ret_id], dtype=ids_dev.dtype, device=device)).to(dtype)
+        # the plan entries are in (sample, position) order = increasing rows and crops: what tp_hd_assemble requires
+        hbs, wbs, rows = [p[2] for p in img_plan], [p[3] for p in img_plan], [p[0] for p in img_plan]
+        if crop_map is None and all(p[1] == sum(hd_crop_count(a, c) for a, c in zip(hbs[:i], wbs[:i])) for i, p in enumerate(img_plan)):
+            assemble_hd_tokens(image_features, hbs, wbs, seps[0], seps[1], out=out, out_rows=rows)
+        else:
+            # crops skipped by image-less samples (or a ragged gather buffer): address every crop through a map
+            first = torch.tensor([p[1] for p in img_plan])
+            logical = torch.cat([torch.arange(int(f), int(f) + hd_crop_count(a, c)) for f, a, c in zip(first, hbs, wbs)])
+            cmap = logical.to(device=device, dtype=torch.int32)
+            if crop_map is not None:
+                cmap = crop_map.index_select(0, cmap.long()).contiguous()
+            assemble_hd_tokens(image_features, hbs, wbs, seps[0], seps[1], out=out, out_rows=rows, crop_map=cmap)
+    return out.view(ids_cpu.shape[0], L, D)
