@@ -180,13 +180,26 @@ int tp_point_queries(const tp_desc* desc, const void* x, const int64_t x_strides
 int tp_region_attention(const tp_desc* desc, const void* q, const void* k, const void* v, void* o,
                         void* stream);
 
+/* The same attention with the K/V in-projections ABSORBED into the query side — what tp_forward runs for
+ * scale_factor >= 3 (TP_TUNE_ABSORB_KV): with one query per region, Q_h·(W'k n_t + b'k)_h = (W'k_h^T Q_h)·n_t + const and
+ * sum_t p_t (W'v n_t + b'v)_h = W'v_h (sum_t p_t n_t) + b'v_h, so the two [B·576,1024]x[1024,1024] in-projection GEMMs
+ * shrink to query-sized work (1/s^2).  All fp16:
+ *   qt [B, M, 8, 1024] = per-head Q_h · W'k_h (W' = LayerNorm-folded in_proj rows of k),
+ *   h2k / h2v [B, g*g, 1024] = the PRE-LayerNorm second-layer outputs, normalised on load with
+ *   mr_k / mr_v [B*g*g][2] = their per-row (mean, rstd) from tp_ln_finalize;
+ *   u [B, M, 8, 1024] = per head sum_t softmax_t(qt_h·n^k_t / sqrt(128)) n^v_t   (then O_h = u_h·W'v_h^T + b'v_h).
+ * s*s <= 64. */
+int tp_region_attention_absorbed(const tp_desc* desc, const void* qt, const void* h2k, const void* h2v,
+                                 const float* mr_k, const float* mr_v, void* u, void* stream);
+
 /* Generic fused linear used for every dense contraction of the path (11 nn.Linear calls of
  * builder.py:112,113,120,126-130,136):  C[M,N] = epilogue(A[M,K] · W[N,K]^T).
  * flags: TP_LINEAR_* below.  `bias` fp32 [N] or NULL.  With TP_LINEAR_LN_FOLD the epilogue applies
  * a LayerNorm that precedes the linear: C = rstd_m·(acc − mu_m·colsum_n) + bias_n, with
  * `row_mean_rstd` = fp32 [M][2] (mean, rstd) per row of A, produced by tp_ln_finalize().
- * With TP_LINEAR_ROW_STATS the kernel writes partial (sum, sum of squares) of ITS rounded output to `row_stats_out`
- * ([N/128][M][2]: one slab per 128 output columns; tp_linear_stats_parts() returns N/128).
+ * With TP_LINEAR_ROW_STATS the kernel writes, per 128 output columns, the (mean, M2) of ITS rounded output — M2 = sum of
+ * squared deviations from that slab's own mean; merged by Chan's formula, accurate even when |mean| >> std — to
+ * `row_stats_out` ([N/128][M][2]: one slab per 128 output columns; tp_linear_stats_parts() returns N/128).
  * One call addresses at most 4 GiB of output, (M + 256) * ldc * sizeof(element) < 2^32 (the stores go through a
  * range-checked 32-bit buffer descriptor); larger problems are rejected with TP_ERR_INVALID_ARG.  tp_forward /
  * tp_forward_parts split a batch beyond that bound (about 1800 images at hidden_size 4096) into consecutive chunks
@@ -220,8 +233,8 @@ typedef struct tp_linear_args {
     float*  row_stats_out;     /* ROW_STATS                                                        */
 } tp_linear_args;
 int tp_linear(const tp_linear_args* args, void* stream);
-/* (sum, sumsq) slabs [parts][M][2] written by a TP_LINEAR_ROW_STATS call -> per-row (mean, rstd)
- * [M][2] of nn.LayerNorm(ln_dim, eps) (biased variance), for a TP_LINEAR_LN_FOLD call. */
+/* (mean, M2) slabs [parts][M][2] written by a TP_LINEAR_ROW_STATS call -> per-row (mean, rstd)
+ * [M][2] of nn.LayerNorm(ln_dim, eps) (biased variance), for a TP_LINEAR_LN_FOLD call.  ln_dim == parts * 128. */
 int tp_ln_finalize(const float* row_stats, int parts, int64_t M, int ln_dim, float eps,
                    float* row_mean_rstd, void* stream);
 /* Number of row-stat slabs a TP_LINEAR_ROW_STATS call with these M,N (and args->tile) writes. */
@@ -325,7 +338,11 @@ int tp_debug_count_saturated(const tp_desc* desc, const void* workspace, size_t 
  * device int).  Stands in for another stream's kernels when the GEMM tile queue is measured (tools/hog_bench.py). */
 int tp_test_occupy_cus(int workgroups, int microseconds, void* scratch_int, void* stream);
 
-/* ---- tuning knobs (benchmarks only; defaults are what tp_forward ships with) ------------------ */
+/* ---- tuning knobs (benchmarks / deployment policy; defaults are what tp_forward ships with) --------------------
+ * The table is ONE process-wide array of atomics: tp_set_tuning is NOT scoped to a stream, a call or a thread — two
+ * host threads that want different values must serialise their forwards around it.  Everything else in this header
+ * is reentrant (state is per call, per thread (error string) or per caller stream (the forked query-side stream; at
+ * most 64 distinct caller streams per device get one, later ones run the query side on the caller's stream)). */
 enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all half tiles by CU rounds) | 128 | 256 */
        TP_TUNE_XCD_SWIZZLE = 1, /* 1 (default) | 0                                                 */
        TP_TUNE_GEMM_KERNEL = 2, /* 256-tile main loop: 0 persistent ping-pong (default; tile shape by round count)
@@ -333,7 +350,12 @@ enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all hal
                                    | 3 persistent ping-pong, every tile a 128x256 half tile            */
        TP_TUNE_Q_SIDE_STREAM = 5, /* 1 (default): the query side runs on a forked side stream | 0: one stream */
        TP_TUNE_DYNAMIC_TILES = 4, /* 1 (default): persistent GEMMs draw tiles from per-XCD queues | 0: static striding */
-       TP_TUNE_FOLD_OUT_PROJ = 3, /* 0 (default): out_proj and mlp[0] as two GEMMs | 1: folded (W = Wm0·Wout) */
+       TP_TUNE_FOLD_OUT_PROJ = 3, /* 0 (default): out_proj and mlp[0] as two GEMMs | 1: folded (W = Wm0·Wout); read at
+                                     PACK time (tp_pack_weights builds the folded weight only then) and at forward time */
+       TP_TUNE_RESERVE_CUS = 6,   /* r in 0..7 (default 0): persistent GEMMs launch (CUs/8 - r) workgroups per XCD, leaving
+                                     r CUs per XCD to kernels of other streams (RCCL's all-gather overlapping the next forward) */
+       TP_TUNE_ABSORB_KV = 7,     /* K/V in-projection absorbed into the query side (see tp_forward): 0 auto (scale_factor >= 3),
+                                     1 never, 2 always */
        TP_TUNE_COUNT_ = 8 };
 int tp_set_tuning(int key, int value);
 

@@ -242,3 +242,35 @@ def test_empty_batch_returns_empty_like_the_reference():
     assert y.shape == (0, 144, 256) and y.requires_grad
     y.sum().backward()
     assert all(p.grad is not None and not p.grad.any() for p in m.parameters())
+
+
+@pytest.mark.parametrize("s", [2, 3, 4])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_absorbed_kv_schedule_is_the_same_function(s, dtype):
+    """TP_TUNE_ABSORB_KV: the K/V in-projections absorbed into the query side (default for scale_factor >= 3) against
+    the plain schedule (in-projection GEMMs over all B*576 tokens): both within the gate against the fp64 oracle, and
+    within rounding of each other."""
+    from tokenpacker_amd import _capi
+    D, B = 256, 2
+    params = synth.make_params(90 + s, D)
+    x, xm = synth.make_inputs(91 + s, B, dtype)
+    p_lp = {k: v.to(dtype) for k, v in params.items()}
+    y_exact = orc.forward(p_lp, x, xm, scale_factor=s, compute_dtype=torch.float64, io_dtype=dtype)
+    ys = {}
+    try:
+        for mode in (1, 2):                                # 1 = never absorb, 2 = always
+            _capi.set_tuning(_capi.TP_TUNE_ABSORB_KV, mode)
+            m = _module(params, s, D, dtype)
+            m.output_fp32 = True
+            with torch.no_grad():
+                ys[mode] = m((x.cuda(), xm.cuda()))
+            torch.cuda.synchronize()
+    finally:
+        _capi.set_tuning(_capi.TP_TUNE_ABSORB_KV, 0)
+    e1, e2 = orc.rel_err(ys[1], y_exact), orc.rel_err(ys[2], y_exact)
+    l1, l2 = orc.rel_l2(ys[1], y_exact), orc.rel_l2(ys[2], y_exact)
+    print(f"\n[parity] absorb s={s} {dtype}: plain rel_err {e1:.3e} (l2 {l1:.3e}), absorbed {e2:.3e} (l2 {l2:.3e}), "
+          f"between them {orc.rel_err(ys[2], ys[1]):.3e}")
+    assert not torch.equal(ys[1], ys[2])                   # the knob really switches the schedule
+    assert e1 <= 1e-3 and e2 <= 1e-3, (e1, e2)
+    assert l2 <= 1.25 * l1 + 1e-5

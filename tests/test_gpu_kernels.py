@@ -87,7 +87,7 @@ def test_linear_strided_batch_rows(dtype, tile):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("tile", TILES)
 def test_linear_row_stats_and_ln_fold(dtype, tile):
-    """GEMM#1 emits per-row (sum, sumsq) partials of its ROUNDED output; GEMM#2 consumes them to apply
+    """GEMM#1 emits per-row, per-128-column (mean, M2) partials of its ROUNDED output; GEMM#2 consumes them to apply
     LayerNorm folded into its epilogue.  Reference: LN then linear in fp64 (builder.py:112,120 + in-proj)."""
     M, E = 700, 1024
     A = _rand((M, 256), dtype, 8)
@@ -97,9 +97,11 @@ def test_linear_row_stats_and_ln_fold(dtype, tile):
     parts = stats.shape[0]
     assert parts == E // 128          # one slab per 128 columns, whatever the tile
     Hd = H.double().cpu()
-    s = stats.double().cpu().sum(0)
-    assert torch.allclose(s[:, 0], Hd.sum(1), rtol=1e-5, atol=1e-3), "row sums"
-    assert torch.allclose(s[:, 1], (Hd * Hd).sum(1), rtol=1e-5, atol=1e-3), "row sums of squares"
+    slabs = Hd.reshape(M, parts, 128)
+    st = stats.double().cpu()                                    # [parts][M][2]
+    assert torch.allclose(st[:, :, 0].t(), slabs.mean(2), rtol=0, atol=2e-6), "slab means"
+    m2 = ((slabs - slabs.mean(2, keepdim=True)) ** 2).sum(2)
+    assert torch.allclose(st[:, :, 1].t(), m2, rtol=2e-5, atol=1e-5), "slab sums of squared deviations"
 
     # LN-fold operands prepared exactly like tp_pack_weights does
     g = torch.Generator().manual_seed(11)
@@ -249,3 +251,36 @@ def test_region_attention_peaked_softmax():
     assert P.max() > 0.99          # the case really is peaked
     ref = torch.einsum("bijhk,bijkhd->bijhd", P, V).reshape(B, M, E)
     gu.assert_close(o, ref, "region_attention peaked", 2.0 ** -11 * 1.05 + 1e-5)
+
+
+@pytest.mark.parametrize("s", [2, 3, 4, 6, 8])
+def test_region_attention_absorbed(s):
+    """The attention of the absorbed schedule on its own (tp_region_attention_absorbed): rows of H2 normalised on load
+    with their (mean, rstd), per-head logits against qt, softmax over the region, u_h = sum_t p_t n^v_t — against the
+    same sums in fp64.  Rows carry a large common offset so that normalise-on-load is really exercised."""
+    B, g, E, H = 2, 24, 1024, 8
+    G = g // s
+    M, N = G * G, g * g
+    gen = torch.Generator().manual_seed(50 + s)
+    qt = (0.4 * torch.randn(B, M, H, E, generator=gen)).half().cuda()
+    h2 = [(1.7 * torch.randn(B, N, E, generator=gen) + 3.0 * torch.randn(B, N, 1, generator=gen)).half().cuda() for _ in range(2)]
+    mr = []
+    for h in h2:
+        hd = h.double()
+        mu, var = hd.mean(-1), hd.var(-1, unbiased=False)
+        mr.append(torch.stack([mu, 1.0 / torch.sqrt(var + 1e-6)], dim=-1).float().reshape(B * N, 2).contiguous())
+    u = torch.empty(B, M, H, E, dtype=torch.float16, device="cuda")
+    lib = _capi.load_library()
+    desc = _capi.make_desc(B, g, s, 4096, _capi.TP_F16)
+    _capi.check(lib.tp_region_attention_absorbed(ctypes.byref(desc), qt.data_ptr(), h2[0].data_ptr(), h2[1].data_ptr(),
+                                                 mr[0].data_ptr(), mr[1].data_ptr(), u.data_ptr(), gu.stream_ptr()),
+                "tp_region_attention_absorbed")
+    torch.cuda.synchronize()
+    n = [((h.double().cpu() - m_[:, 0].double().cpu().reshape(B, N, 1)) * m_[:, 1].double().cpu().reshape(B, N, 1))
+         for h, m_ in zip(h2, mr)]
+    nk = orc.region_gather(n[0], g, s)                      # [B, G, G, s*s, E]
+    nv = orc.region_gather(n[1], g, s)
+    q = qt.double().cpu().reshape(B, G, G, H, E)
+    P = torch.softmax(torch.einsum("bijhe,bijke->bijhk", q, nk) / math.sqrt(128), dim=-1)
+    ref = torch.einsum("bijhk,bijke->bijhe", P, nv).reshape(B, M, H, E)
+    gu.assert_close(u.reshape(B * M * H, E), ref.reshape(B * M * H, E), f"region_attention_absorbed s={s}", 2.0 ** -11 * 1.05 + 1e-5)

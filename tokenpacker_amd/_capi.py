@@ -17,6 +17,7 @@ TP_OK, TP_ERR_INVALID_ARG, TP_ERR_BAD_SCALE, TP_ERR_WORKSPACE, TP_ERR_LAUNCH = 0
 TP_LINEAR_GELU, TP_LINEAR_LN_FOLD, TP_LINEAR_ROW_STATS = 1, 2, 4
 TP_TUNE_GEMM_TILE, TP_TUNE_XCD_SWIZZLE, TP_TUNE_GEMM_KERNEL, TP_TUNE_FOLD_OUT_PROJ, TP_TUNE_DYNAMIC_TILES = 0, 1, 2, 3, 4
 TP_TUNE_Q_SIDE_STREAM = 5
+TP_TUNE_RESERVE_CUS, TP_TUNE_ABSORB_KV = 6, 7
 TP_WGRAD_X_TRANSPOSED = 1
 TP_NUM_STAGES = 10
 TP_NUM_DEBUG_BUFFERS = 9
@@ -35,6 +36,7 @@ EXPORTED_SYMBOLS = (
     "tp_train_workspace_bytes", "tp_backward_workspace_bytes", "tp_forward_train", "tp_backward",
     "tp_forward_parts", "tp_forward_train_parts", "tp_backward_parts", "tp_test_occupy_cus", "tp_hd_slice",
     "tp_wgrad", "tp_wgrad_workspace_bytes", "tp_packed_status_offset", "tp_debug_count_saturated",
+    "tp_region_attention_absorbed",
 )
 
 # state-dict name -> tp_weights field order (include/tokenpacker.h)
@@ -128,6 +130,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.tp_point_queries.argtypes = [POINTER(tp_desc), c_void_p, POINTER(c_int64), c_void_p, c_void_p]
     lib.tp_region_attention.restype = c_int
     lib.tp_region_attention.argtypes = [POINTER(tp_desc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.tp_region_attention_absorbed.restype = c_int
+    lib.tp_region_attention_absorbed.argtypes = [POINTER(tp_desc)] + [c_void_p] * 7
     lib.tp_linear.restype = c_int
     lib.tp_linear.argtypes = [POINTER(tp_linear_args), c_void_p]
     lib.tp_ln_finalize.restype = c_int
@@ -201,7 +205,7 @@ def strides3(st) -> "ctypes.Array":
 
 
 _TUNING_DEFAULTS = {TP_TUNE_GEMM_TILE: 0, TP_TUNE_XCD_SWIZZLE: 1, TP_TUNE_GEMM_KERNEL: 0, TP_TUNE_FOLD_OUT_PROJ: 0,
-                    TP_TUNE_DYNAMIC_TILES: 1, TP_TUNE_Q_SIDE_STREAM: 1}
+                    TP_TUNE_DYNAMIC_TILES: 1, TP_TUNE_Q_SIDE_STREAM: 1, TP_TUNE_RESERVE_CUS: 0, TP_TUNE_ABSORB_KV: 0}
 _tuning_values = dict(_TUNING_DEFAULTS)
 
 

@@ -40,7 +40,7 @@ int check_launch(const char* what) {
     return TP_OK;
 }
 
-static std::atomic<int> g_tuning[TP_TUNE_COUNT_] = {{0}, {1}, {0}, {0}, {1}, {1}, {0}, {0}};
+static std::atomic<int> g_tuning[TP_TUNE_COUNT_] = {{0}, {1}, {0}, {0}, {1}, {1}, {0}, {0}};   // [6] RESERVE_CUS, [7] ABSORB_KV
 int tuning(int key) { return (key >= 0 && key < TP_TUNE_COUNT_) ? g_tuning[key].load() : 0; }
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
@@ -55,6 +55,7 @@ PackedLayout packed_layout(int D) {
     L.w_q1 = take(E * E * 2);
     L.w_in_kv = take(2 * E * E * 2);     L.c_in_kv = take(2 * E * 4);  L.b_in_kv = take(2 * E * 4);
     L.w_in_q = take(E * E * 2);          L.c_in_q = take(E * 4);       L.b_in_q = take(E * 4);
+    L.w_qt = take(E * E * 2);
     L.w_out = take(E * E * 2);           L.b_out = take(E * 4);
     L.w_m0 = take((size_t)D * E * 2);    L.b_m0 = take((size_t)D * 4);
     L.w_m2 = take((size_t)D * D * 2);    L.b_m2 = take((size_t)D * 4);
@@ -78,7 +79,8 @@ WorkspaceLayout workspace_layout(int B, int grid, int s, int D, bool train) {
     L.h2 = take(2 * rows_kv * E * 2);
     L.stats_kv = take(2 * (size_t)8 * rows_kv * 2 * 4);     // up to 8 slabs (tile 128) per group
     L.mr_kv = take(2 * rows_kv * 2 * 4);                    // per-row (mean, rstd), 2 groups
-    L.kv = take(2 * rows_kv * E * 2);
+    // K | V [2][rows_kv, E]; the absorbed schedule keeps qt | u [2][rows_q, 8, E] there instead
+    L.kv = take(2 * (rows_kv > 8 * rows_q ? rows_kv : 8 * rows_q) * E * 2);
     L.q1pre = take(rows_q * E * 2);
     L.stats_q = take((size_t)8 * rows_q * 2 * 4);
     L.mr_q = take(rows_q * 2 * 4);
@@ -122,6 +124,16 @@ int validate_desc(const tp_desc* d) {
     }
     if (!(d->ln_eps > 0.f)) { set_error("tp_desc: ln_eps must be > 0"); return TP_ERR_INVALID_ARG; }
     return TP_OK;
+}
+
+// The absorbed schedule (region_attention_absorbed_kernel's header): auto = scale_factor >= 3, where the two in-projection
+// GEMMs over the B*576 fine tokens cost far more than the 1/s^2-sized query-side work that replaces them (at s = 2 the
+// [B M, 8, 1024] intermediates cost what the GEMMs save).  Inference only: the backward needs K and V.
+bool absorb_kv(const tp_desc* d, bool train) {
+    if (train) return false;
+    const int s2 = d->scale_factor * d->scale_factor, mode = tuning(TP_TUNE_ABSORB_KV);
+    if (s2 > 64 || mode == 1) return false;
+    return mode == 2 || d->scale_factor >= 3;
 }
 
 GemmArgs plain_gemm(const void* A, long long lda_elems, const void* W, void* C, long long ldc,
@@ -234,6 +246,7 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
     TP_TRY(pack_ln_fold_launch(dt, inw + 2 * E * E * 2, inb + 2 * E * 2, raw->ln_v_1_weight, raw->ln_v_1_bias,
                                P + L.w_in_kv + E * E * 2, (float*)(P + L.c_in_kv) + E, (float*)(P + L.b_in_kv) + E,
                                (int)E, (int)E, stream, sat));
+    TP_TRY(pack_head_transpose_launch(P + L.w_in_kv, P + L.w_qt, stream));      // of the ROUNDED W'k: the absorbed schedule
     TP_TRY(pack_cast_f16_launch(dt, raw->clip_attn_out_proj_weight, P + L.w_out, (long long)(E * E), stream, sat));
     TP_TRY(pack_cast_f32_launch(dt, raw->clip_attn_out_proj_bias, (float*)(P + L.b_out), (int)E, stream));
     TP_TRY(pack_cast_f16_launch(dt, raw->mlp_0_weight, P + L.w_m0, (long long)D * E, stream, sat));
@@ -281,6 +294,14 @@ int tp_region_attention(const tp_desc* desc, const void* q, const void* k, const
     TP_TRY(validate_desc(desc));
     if (!q || !k || !v || !o) { set_error("tp_region_attention: NULL pointer"); return TP_ERR_INVALID_ARG; }
     return region_attention_launch(q, k, v, o, desc->batch, desc->raw_grid, desc->scale_factor, (hipStream_t)stream);
+}
+
+int tp_region_attention_absorbed(const tp_desc* desc, const void* qt, const void* h2k, const void* h2v, const float* mr_k,
+                                 const float* mr_v, void* u, void* stream) {
+    TP_TRY(validate_desc(desc));
+    if (!qt || !h2k || !h2v || !mr_k || !mr_v || !u) { set_error("tp_region_attention_absorbed: NULL pointer"); return TP_ERR_INVALID_ARG; }
+    return region_attention_absorbed_launch(qt, h2k, h2v, mr_k, mr_v, u, desc->batch, desc->raw_grid, desc->scale_factor,
+                                            (hipStream_t)stream);
 }
 
 int tp_hd_slice(const float* image, int H, int W, int h_block, int w_block, int h_res, int w_res, int hg, int wg,
@@ -358,6 +379,10 @@ int tp_hd_assemble(const tp_hd_image* plan, int n_images, const void* tokens, in
 int tp_ln_finalize(const float* row_stats, int parts, int64_t M, int ln_dim, float eps, float* row_mean_rstd, void* stream) {
     if (!row_stats || !row_mean_rstd || parts <= 0 || M <= 0 || ln_dim <= 0 || !(eps > 0.f)) {
         set_error("tp_ln_finalize: invalid argument");
+        return TP_ERR_INVALID_ARG;
+    }
+    if (ln_dim != parts * 128) {
+        set_error("tp_ln_finalize: ln_dim %d != %d slabs of 128 columns", ln_dim, parts);
         return TP_ERR_INVALID_ARG;
     }
     return ln_finalize_launch(row_stats, row_mean_rstd, M, parts, 1, ln_dim, eps, (hipStream_t)stream);
@@ -479,7 +504,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     char* ws = (char*)workspace;
     const long long kvE = (long long)rows_kv * E;      // elements per K/V group slab
 
-    // tile-queue heads of the persistent GEMM launches: 32 ints per launch, zeroed once per forward
+    // tile-queue heads of the persistent GEMM launches: 64 ints per launch (<= 16 launches), zeroed once per forward
     int* counters = tuning(TP_TUNE_DYNAMIC_TILES) ? (int*)(ws + W.counters) : nullptr;
     if (counters) {
         hipError_t e = hipMemsetAsync(counters, 0, 4096, stream);
@@ -487,7 +512,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     }
     int launch_no = 0;
     auto launch = [&](int in_dt, int out_dt, GemmArgs& a, hipStream_t st) -> int {
-        a.tile_counters = counters ? counters + 32 * launch_no++ : nullptr;
+        a.tile_counters = counters ? counters + 64 * launch_no++ : nullptr;      // [groups <= 8][8 XCDs] heads per launch
         return gemm_launch(in_dt, out_dt, a, st);
     };
     // query side on a side stream (not when the caller wants per-stage events: those need one stream)
@@ -507,6 +532,14 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         a.colsum = (const float*)(pw + P.c_in_q);
         return launch(TP_F16, TP_F16, a, st);
     };
+    const bool absorb = absorb_kv(desc, train);
+    char* const qt = ws + W.kv;                                        // [rows_q, 8, E] fp16 (absorbed schedule)
+    char* const uu = ws + W.kv + (size_t)rows_q * 8 * E * 2;           // [rows_q, 8, E] fp16
+    auto qt_gemm = [&](hipStream_t st) -> int {         // qt[m, h, :] = Q[m, h*128:(h+1)*128] · W'k[h*128:(h+1)*128, :]
+        GemmArgs a = plain_gemm(ws + W.q, E, pw + P.w_qt, qt, 8 * E, rows_q, E, kHeadDim, nullptr, 0);
+        a.groups = kHeads; a.a_gs = kHeadDim * 2; a.w_gs = (long long)E * kHeadDim * 2; a.c_gs = E * 2;
+        return launch(TP_F16, TP_F16, a, st);
+    };
     if (side) {
         hipError_t e = hipEventRecord(side->fork, stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(side->s, side->fork, 0);
@@ -514,6 +547,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         TP_TRY(point_queries_launch(dt, x, x_strides, ws + W.q0, B, g, s, side->s));
         TP_TRY(q_proj(side->s));
         TP_TRY(q_inproj(side->s));
+        if (absorb) TP_TRY(qt_gemm(side->s));
         e = hipEventRecord(side->join, side->s);
         if (e != hipSuccess) { set_error("tp_forward: side stream join: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
     }
@@ -556,8 +590,8 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     TP_TRY(mark());
     TP_TRY(ln_finalize_launch((const float*)(ws + W.stats_kv), (float*)(ws + W.mr_kv), rows_kv, parts_kv, 2, E,
                               desc->ln_eps, stream));
-    // 4. {K,V} = LN(H2[g]) · Win{k,v}^T + b   (LayerNorm folded into the epilogue)
-    {
+    // 4. {K,V} = LN(H2[g]) · Win{k,v}^T + b   (LayerNorm folded into the epilogue) — not in the absorbed schedule
+    if (!absorb) {
         GemmArgs a = plain_gemm(ws + W.h2, E, pw + P.w_in_kv, ws + W.kv, E, rows_kv, E, E,
                                 (const float*)(pw + P.b_in_kv), TP_LINEAR_LN_FOLD);
         a.groups = 2; a.a_gs = kvE * 2; a.w_gs = (long long)E * E * 2; a.c_gs = kvE * 2; a.bias_gs = E;
@@ -568,13 +602,22 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     TP_TRY(mark());
     if (!side) TP_TRY(q_proj(stream));
     TP_TRY(mark());
-    if (!side) TP_TRY(q_inproj(stream));
+    if (!side) { TP_TRY(q_inproj(stream)); if (absorb) TP_TRY(qt_gemm(stream)); }
     TP_TRY(mark());
     if (side) {
         hipError_t e = hipStreamWaitEvent(stream, side->join, 0);
         if (e != hipSuccess) { set_error("tp_forward: side stream join wait: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
     }
     // 7. region-to-point attention
+    if (absorb) {
+        TP_TRY(region_attention_absorbed_launch(qt, ws + W.h2, ws + W.h2 + kvE * 2, (const float*)(ws + W.mr_kv),
+                                                (const float*)(ws + W.mr_kv) + (size_t)rows_kv * 2, uu, B, g, s, stream));
+        // O[:, h*128:(h+1)*128] = u[:, h, :] · W'v[h*128:(h+1)*128, :]^T + b'v   (eight N = 128 groups)
+        GemmArgs a = plain_gemm(uu, 8 * E, pw + P.w_in_kv + (size_t)E * E * 2, ws + W.o, E, rows_q, kHeadDim, E,
+                                (const float*)(pw + P.b_in_kv) + E, 0);
+        a.groups = kHeads; a.a_gs = E * 2; a.w_gs = (long long)kHeadDim * E * 2; a.c_gs = kHeadDim * 2; a.bias_gs = kHeadDim;
+        TP_TRY(launch(TP_F16, TP_F16, a, stream));
+    } else
     TP_TRY(region_attention_launch(ws + W.q, ws + W.kv, ws + W.kv + kvE * 2, ws + W.o, B, g, s, stream));
     TP_TRY(mark());
     // 8. out_proj — optionally folded into mlp[0] at pack time (TP_TUNE_FOLD_OUT_PROJ, default OFF): -2 % time, same

@@ -538,7 +538,15 @@ static int g8_num_cus() {
     return cus;
 }
 
-int gemm8_persistent_cus() { return g8_num_cus() / 8 * 8; }
+// Workgroups of a persistent launch: one per CU, a multiple of the 8 XCDs, minus the CUs the caller reserves for
+// kernels of OTHER streams (TP_TUNE_RESERVE_CUS = r: r CUs per XCD stay free — the all-gather that overlaps the next
+// forward needs somewhere to run; a persistent workgroup holds its CU's LDS and registers for the whole launch).
+int gemm8_persistent_cus() {
+    int r = tuning(TP_TUNE_RESERVE_CUS);
+    r = r < 0 ? 0 : (r > 7 ? 7 : r);
+    const int per_xcd = g8_num_cus() / 8 - r;
+    return (per_xcd < 1 ? 1 : per_xcd) * 8;
+}
 
 template <typename TI, typename TO, int AMODE, bool PERSIST, bool TRAIN_EPI, bool HALF = false>
 static int launch8_cfg(const GemmArgs& a, hipStream_t stream) {
@@ -560,7 +568,7 @@ static int launch8_cfg(const GemmArgs& a, hipStream_t stream) {
     const int ntiles = tiles_m * tiles_n;
     int nwg = ntiles;
     if (PERSIST) {                                     // one workgroup per CU (140 KiB of LDS each, 156 KiB with half tiles), a multiple of the 8 XCDs
-        const int cap = g8_num_cus() / 8 * 8;
+        const int cap = gemm8_persistent_cus();
         if (nwg > cap && cap > 0) nwg = cap;
     }
     dim3 grid((unsigned)nwg, (unsigned)a.groups, 1);

@@ -141,7 +141,12 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
     }
 
     // Row statistics are accumulated per 64-column slice (VW slices per wave) and combined below in a fixed
-    // tree, so a wave that owns 128 columns produces bit-identical sums to two waves that own 64 each.
+    // tree, so a wave that owns 128 columns produces bit-identical results to two waves that own 64 each.
+    // What travels is (mean, M2 = sum of squared deviations from that mean) of a group of values, merged pairwise by
+    // Chan's formula — NOT (sum, sum of squares): var = E[x^2] - mean^2 in fp32 loses every digit once |mean| >> std
+    // (rows with a large common offset, e.g. behind massive-activation channels of a trained CLIP), whereas the
+    // merged M2 stays accurate to fp32 round-off of the spread itself.  A lane's own 4·FNV values are accumulated
+    // as shifted sums around its first value (the shift makes the one-pass form safe).
     constexpr int VW = WN / 64;                    // 64-column slices per wave
     constexpr int FNV = FN / VW;                   // fragments per slice (= 4)
     static_assert(WN % 64 == 0, "wave tile must be a multiple of 64 columns");
@@ -153,7 +158,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
         const float mu = mean_rstd[i].x, rstd = mean_rstd[i].y;
 #pragma unroll
         for (int vs = 0; vs < VW; ++vs) {
-            float s1 = 0.f, s2 = 0.f;
+            float s1 = 0.f, s2 = 0.f, pivot = 0.f;
             // fragments are finished in PAIRS (j, j+1): a lane owns 4 consecutive columns of each; one
             // v_permlane16_swap per dword trades the odd 16-lane rows' fragment-j half against the even rows'
             // fragment-(j+1) half, after which every lane holds 8 consecutive columns -> 16-byte stores, 64
@@ -214,10 +219,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
                     if (flags & TP_LINEAR_ROW_STATS) {                  // stats of the ROUNDED values, fragment order
                         v0 = __builtin_convertvector(o0, f32x4);
                         v1 = __builtin_convertvector(o1, f32x4);
+                        if (jj == 0) pivot = v0[0];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { s1 += v0[r]; s2 += v0[r] * v0[r]; }
+                        for (int r = 0; r < 4; ++r) { const float d = v0[r] - pivot; s1 += d; s2 = fmaf(d, d, s2); }
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { s1 += v1[r]; s2 += v1[r] * v1[r]; }
+                        for (int r = 0; r < 4; ++r) { const float d = v1[r] - pivot; s1 += d; s2 = fmaf(d, d, s2); }
                     }
                     u32x2 a = __builtin_bit_cast(u32x2, o0), b = __builtin_bit_cast(u32x2, o1);
                     const auto sx = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
@@ -231,14 +237,17 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
                 }
                 if constexpr (OUT_F32) {
                     if (flags & TP_LINEAR_ROW_STATS) {                  // (rejected by gemm_launch; kept for completeness)
+                        if (jj == 0) pivot = v0[0];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { s1 += v0[r]; s2 += v0[r] * v0[r]; }
+                        for (int r = 0; r < 4; ++r) { const float d = v0[r] - pivot; s1 += d; s2 = fmaf(d, d, s2); }
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { s1 += v1[r]; s2 += v1[r] * v1[r]; }
+                        for (int r = 0; r < 4; ++r) { const float d = v1[r] - pivot; s1 += d; s2 = fmaf(d, d, s2); }
                     }
                 }
             }
-            rs1[i][vs] = s1; rs2[i][vs] = s2;
+            // the lane's 4·FNV values as (mean, M2)
+            constexpr float inv_nl = 1.0f / (4 * FNV);
+            rs1[i][vs] = fmaf(s1, inv_nl, pivot); rs2[i][vs] = fmaf(-s1 * inv_nl, s1, s2);
         }
     }
 
@@ -250,9 +259,17 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int vs = 0; vs < VW; ++vs) {
+                // (mean, M2) of equal-sized groups a, b of n values each:  mean = (ma + mb) / 2,
+                // M2 = M2a + M2b + (ma - mb)^2 n / 2 — written symmetrically, so both lanes of a pair get the same bits
                 float s1 = rs1[i][vs], s2 = rs2[i][vs];
-                s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                {
+                    const float mb = __shfl_xor(s1, 16), qb = __shfl_xor(s2, 16), d = s1 - mb;
+                    s1 = 0.5f * (s1 + mb); s2 = fmaf(d * d, 0.5f * (4 * FNV), s2 + qb);
+                }
+                {
+                    const float mb = __shfl_xor(s1, 32), qb = __shfl_xor(s2, 32), d = s1 - mb;
+                    s1 = 0.5f * (s1 + mb); s2 = fmaf(d * d, 0.5f * (8 * FNV), s2 + qb);
+                }
                 if (lane < 16) {
                     const int rr = wm * WM + i * 16 + lane;
                     red[((wn * VW + vs) * BM + rr) * 2 + 0] = s1;
@@ -266,12 +283,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
         constexpr int SLABS = BN / 128, WPS = 2;
         for (int idx = tid; idx < BM * SLABS; idx += NW * 64) {
             const int rr = idx % BM, sl = idx / BM;
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < WPS; ++w) {
-                s1 += red[((sl * WPS + w) * BM + rr) * 2];
-                s2 += red[((sl * WPS + w) * BM + rr) * 2 + 1];
-            }
+            static_assert(WPS == 2 && 16 * FNV == 64, "a slab is two 64-column slices");
+            const float ma = red[((sl * WPS + 0) * BM + rr) * 2], qa = red[((sl * WPS + 0) * BM + rr) * 2 + 1];
+            const float mb = red[((sl * WPS + 1) * BM + rr) * 2], qb = red[((sl * WPS + 1) * BM + rr) * 2 + 1];
+            const float dm = ma - mb;
+            const float s1 = 0.5f * (ma + mb), s2 = fmaf(dm * dm, 32.0f, qa + qb);        // (mean, M2) of the 128 columns
             const int m = m0 + rr;
             if (m < p.M) {
                 float* so = p.stats_out + g * p.stats_out_gs + ((long long)(tile_n * SLABS + sl) * p.M + m) * 2;

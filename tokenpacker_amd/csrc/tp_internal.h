@@ -86,6 +86,12 @@ int point_queries_launch(int dtype, const void* x, const int64_t st[3], void* q0
                          int s, hipStream_t stream);
 int region_attention_launch(const void* q, const void* k, const void* v, void* o, int B,
                             int grid, int s, hipStream_t stream);      // fp16 in / fp16 out
+// K/V in-projections absorbed into the query side (tp_kernels.hip): qt [B*M, 8, 1024], H2 k / v [B*N, 1024] fp16 with
+// their per-row (mean, rstd) -> u [B*M, 8, 1024] fp16
+int region_attention_absorbed_launch(const void* qt, const void* h2k, const void* h2v, const float* mr_k, const float* mr_v,
+                                     void* u, int B, int grid, int s, hipStream_t stream);
+int pack_head_transpose_launch(const void* w_f16, void* dst_f16, hipStream_t stream);    // [8*128, 1024] -> [8][1024][128]
+bool absorb_kv(const tp_desc* desc, bool train);          // whether tp_forward runs the absorbed schedule for desc
 int hd_slice_launch(const float* img, int H, int W, int h_block, int w_block, int h_res, int w_res, int hg, int wg,
                     float* crops, int block, hipStream_t stream);
 int occupy_cus_launch(int blocks, int usec, int* sink, hipStream_t stream);
@@ -113,6 +119,7 @@ struct PackedLayout {
     size_t w_q1;                  // [1024,1024] f16
     size_t w_in_kv, c_in_kv, b_in_kv;   // LN-folded in-proj for k, v: [2][1024,1024] f16, [2][1024] f32 x2
     size_t w_in_q, c_in_q, b_in_q;      // LN-folded in-proj for q
+    size_t w_qt;                  // [8][1024][128] f16: per-head transposes of the LN-folded K in-proj (absorbed schedule)
     size_t w_out, b_out;          // [1024,1024] f16, [1024] f32
     size_t w_m0, b_m0;            // [D,1024] f16, [D] f32
     size_t w_m2, b_m2;            // [D,D] f16, [D] f32

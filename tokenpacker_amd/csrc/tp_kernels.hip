@@ -181,6 +181,157 @@ int region_attention_launch(const void* q, const void* k, const void* v, void* o
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Region-to-point attention with the K/V in-projections ABSORBED into the query side (scale_factor >= 3).
+//
+// With ONE query per region the in-projections of nn.MultiheadAttention (torch/nn/functional.py:5854-5860; three
+// separate linears because q, k, v are different tensors) need not be applied to the s*s keys and values of every
+// region.  With n_t = LayerNorm-normalised row t of H2 (mean / rstd applied, the affine folded into W' = W·diag(gamma),
+// b' = W·beta + b as everywhere else in this library):
+//     K_t = W'k n_t + b'k        =>   Q_h · K_t,h = (W'k_h^T Q_h) · n_t + Q_h · b'k_h  = qt_h · n_t + const(t)
+//     V_t = W'v n_t + b'v        =>   sum_t p_t V_t,h = W'v_h (sum_t p_t n_t) + b'v_h  = W'v_h u_h + b'v_h
+// (const(t) is the same for every key of the region: softmax ignores it; sum_t p_t = 1.)  So the 2 x [B 576, 1024] x
+// [1024, 1024] in-projection GEMMs (2.4 GFLOP / image, 604 MB of K/V written and read again at B = 256) become
+//   qt = per-head Q_h · W'k_h   [B M, 8, 1024]   (a K = 128 GEMM over the B·M queries, 1/s^2 of the FLOPs)
+//   this kernel: logits from qt and the rows of H2k normalised ON LOAD, softmax, u_h = sum_t p_t n^v_t
+//   O_h = u_h · W'v_h^T + b'v_h                  (a per-head GEMM over the B·M queries)
+// Same function, same parity gates; the roofline is still priced on the un-absorbed FLOP count.
+//
+// One wavefront per query, four per workgroup; lane l owns elements [8l, 8l+8) and [512+8l, 512+8l+8) of every
+// 1024-vector (two coalesced 1-KiB wave transactions per row).  Phase A: the 8 per-head dot products of every key
+// are reduced over the wave with a halving exchange (10 shuffles per key instead of 48) and parked in 2 KiB of LDS;
+// softmax runs there; phase B re-walks the region's tokens on the V side, accumulating u in 128 fp32 registers.
+// HBM-bound: reads 2 s^2 rows of H2 + 16 KiB of qt, writes 16 KiB of u per query.
+constexpr int kAbsorbMaxKeys = 64;          // s*s <= 64 (s <= 8): logits of a region live in LDS
+
+__global__ void __launch_bounds__(256)
+region_attention_absorbed_kernel(const f16_t* __restrict__ qt, const f16_t* __restrict__ h2k, const f16_t* __restrict__ h2v,
+                                 const float* __restrict__ mr_k, const float* __restrict__ mr_v, f16_t* __restrict__ u,
+                                 int B, int g, int s, float scale) {
+    constexpr int E = kEmbed, H = kHeads;
+    __shared__ float logit_lds[4][kAbsorbMaxKeys * H];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int G = g / s, M = G * G, N = g * g, S2 = s * s;
+    const long long qi = (long long)blockIdx.x * 4 + wv;
+    if (qi >= (long long)B * M) return;                       // (no workgroup barrier below: waves are independent)
+    const int b = (int)(qi / M), m = (int)(qi % M);
+    const int i = m / G, j = m % G;
+    const int ea = lane * 8, eb = 512 + lane * 8;
+    float* lg = logit_lds[wv];
+    auto token_row = [&](int kk) -> long long {
+        const int a = kk / s, c = kk - a * s;
+        return (long long)b * N + (long long)((i * s + a) * g + j * s + c);
+    };
+    auto load_normalised = [&](const f16_t* __restrict__ base, const float* __restrict__ mr, long long row, float (&na)[8], float (&nb)[8]) {
+        const float2 st = *(const float2*)(mr + row * 2);       // (mean, rstd): the same address for all lanes
+        load8(base + row * E + ea, na);
+        load8(base + row * E + eb, nb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { na[e] = (na[e] - st.x) * st.y; nb[e] = (nb[e] - st.x) * st.y; }
+    };
+
+    {   // ---- phase A: logits ---------------------------------------------------------------------------------
+        f16x8 qa[H], qb[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            qa[h] = *(const f16x8*)(qt + (qi * H + h) * E + ea);
+            qb[h] = *(const f16x8*)(qt + (qi * H + h) * E + eb);
+        }
+        for (int t = 0; t < S2; ++t) {
+            float na[8], nb[8], v[H];
+            load_normalised(h2k, mr_k, token_row(t), na, nb);
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                float acc = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { acc = fmaf(na[e], (float)qa[h][e], acc); acc = fmaf(nb[e], (float)qb[h][e], acc); }
+                v[h] = acc;
+            }
+            // halving exchange: after the three steps lane l holds the sum over its 8-lane group's partners of head
+            // hsel(l) = 4 bit5 + 2 bit4 + bit3; three plain butterflies finish the 64-lane sum
+            float w4[4], w2[2], y;
+            {
+                const bool hi = lane & 32;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const float send = hi ? v[q] : v[q + 4], keep = hi ? v[q + 4] : v[q]; w4[q] = keep + __shfl_xor(send, 32); }
+            }
+            {
+                const bool hi = lane & 16;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { const float send = hi ? w4[q] : w4[q + 2], keep = hi ? w4[q + 2] : w4[q]; w2[q] = keep + __shfl_xor(send, 16); }
+            }
+            {
+                const bool hi = lane & 8;
+                const float send = hi ? w2[0] : w2[1], keep = hi ? w2[1] : w2[0];
+                y = keep + __shfl_xor(send, 8);
+            }
+            y += __shfl_xor(y, 4); y += __shfl_xor(y, 2); y += __shfl_xor(y, 1);
+            if ((lane & 7) == 0) lg[t * H + ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1)] = y * scale;
+        }
+    }
+    // ---- softmax over the region's keys, one lane per head (LDS traffic of ONE wave is ordered; the asm keeps hipcc
+    // from moving the accesses across) ---------------------------------------------------------------------------
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane < H) {
+        float mx = -INFINITY;
+        for (int t = 0; t < S2; ++t) mx = fmaxf(mx, lg[t * H + lane]);
+        float den = 0.f;
+        for (int t = 0; t < S2; ++t) { const float p = __expf(lg[t * H + lane] - mx); den += p; lg[t * H + lane] = p; }
+        const float inv = 1.0f / den;
+        for (int t = 0; t < S2; ++t) lg[t * H + lane] *= inv;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ---- phase B: u_h = sum_t p_t,h n^v_t ---------------------------------------------------------------------------
+    float ua[H][8], ub[H][8];
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ua[h][e] = 0.f; ub[h][e] = 0.f; }
+    for (int t = 0; t < S2; ++t) {
+        float na[8], nb[8];
+        load_normalised(h2v, mr_v, token_row(t), na, nb);
+        const f32x4 p0 = *(const f32x4*)(lg + t * H), p1 = *(const f32x4*)(lg + t * H + 4);     // broadcast reads
+        const float p[H] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ua[h][e] = fmaf(p[h], na[e], ua[h][e]); ub[h][e] = fmaf(p[h], nb[e], ub[h][e]); }
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        store8(u + (qi * H + h) * E + ea, ua[h]);
+        store8(u + (qi * H + h) * E + eb, ub[h]);
+    }
+}
+
+int region_attention_absorbed_launch(const void* qt, const void* h2k, const void* h2v, const float* mr_k, const float* mr_v,
+                                     void* u, int B, int grid, int s, hipStream_t stream) {
+    if (s * s > kAbsorbMaxKeys) { set_error("absorbed region attention: s*s = %d keys > %d", s * s, kAbsorbMaxKeys); return TP_ERR_INVALID_ARG; }
+    const int G = grid / s, M = G * G;
+    const long long nq = (long long)B * M;
+    const unsigned blocks = (unsigned)((nq + 3) / 4);
+    hipLaunchKernelGGL(region_attention_absorbed_kernel, dim3(blocks), dim3(256), 0, stream, (const f16_t*)qt, (const f16_t*)h2k,
+                       (const f16_t*)h2v, mr_k, mr_v, (f16_t*)u, B, grid, s, 0.08838834764831845f);
+    return check_launch("region_attention_absorbed_kernel");
+}
+
+// w_qt[h][j][d] = W'k[h*128 + d][j]: the per-head transposes the qt GEMM reads as its [N = 1024, K = 128] operand
+__global__ void __launch_bounds__(256)
+pack_head_transpose_kernel(const f16_t* __restrict__ src, f16_t* __restrict__ dst) {
+    __shared__ f16_t tile[32][33];
+    const int h = blockIdx.z, j0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = src[(long long)(h * kHeadDim + d0 + r) * kEmbed + j0 + tx];   // [d][j]
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) dst[((long long)h * kEmbed + j0 + r) * kHeadDim + d0 + tx] = tile[tx][r];    // [j][d]
+}
+
+int pack_head_transpose_launch(const void* w_f16, void* dst_f16, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_head_transpose_kernel, dim3(kEmbed / 32, kHeadDim / 32, kHeads), dim3(256), 0, stream,
+                       (const f16_t*)w_f16, (f16_t*)dst_f16);
+    return check_launch("pack_head_transpose_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Test hook: keep `blocks` CUs busy for about `usec` microseconds (100 KiB of LDS per workgroup, so none of the
 // path's 140-KiB workgroups fits beside it) — stands in for a collective's kernels on another stream when the
 // tile queue of the persistent GEMM is exercised (tools/hog_bench.py).
@@ -334,9 +485,10 @@ int hd_slice_launch(const float* img, int H, int W, int h_block, int w_block, in
 }
 
 // ---------------------------------------------------------------------------------------------------
-// LayerNorm statistics: the producing GEMM leaves one (sum, sumsq) slab per 128 output columns
-// ([parts][M][2]); this turns them into per-row (mean, rstd) for the consuming GEMM's epilogue.
-// The slabs are summed in slab order -> deterministic.  ~10 MB of traffic at B=256: noise.
+// LayerNorm statistics: the producing GEMM leaves one (mean, M2) slab per 128 output columns ([parts][M][2]; M2 = sum
+// of squared deviations from the slab's own mean); this merges them (Chan's formula, slab order -> deterministic)
+// into per-row (mean, rstd) for the consuming GEMM's epilogue.  Unlike E[x^2] - mean^2 this keeps its accuracy when
+// |mean| >> std (nn.LayerNorm itself uses a two-pass / Welford reduction).  ~10 MB of traffic at B=256: noise.
 __global__ void __launch_bounds__(256)
 ln_finalize_kernel(const float* __restrict__ parts, float* __restrict__ mean_rstd, long long M, int nparts,
                    float inv_dim, float eps) {
@@ -344,13 +496,18 @@ ln_finalize_kernel(const float* __restrict__ parts, float* __restrict__ mean_rst
     const int g = blockIdx.y;
     if (m >= M) return;
     const float* pg = parts + (long long)g * nparts * M * 2;
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, q = 0.f;
     for (int pp = 0; pp < nparts; ++pp) {
         const float2 st = *(const float2*)(pg + ((long long)pp * M + m) * 2);
-        s1 += st.x; s2 += st.y;
+        s1 += st.x; q += st.y;
     }
-    const float mu = s1 * inv_dim;
-    const float var = fmaxf(s2 * inv_dim - mu * mu, 0.f);      // biased variance (nn.LayerNorm)
+    const float mu = s1 / (float)nparts;                        // slabs are equally sized (128 columns each)
+    float between = 0.f;
+    for (int pp = 0; pp < nparts; ++pp) {
+        const float d = pg[((long long)pp * M + m) * 2] - mu;
+        between = fmaf(d, d, between);
+    }
+    const float var = (q + 128.0f * between) * inv_dim;        // biased variance (nn.LayerNorm); >= 0 by construction
     *(float2*)(mean_rstd + ((long long)g * M + m) * 2) = make_float2(mu, 1.0f / sqrtf(var + eps));
 }
 
