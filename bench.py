@@ -5,25 +5,38 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path (``TokenPacker.forward``) over one synthetic batch of CLIP
-features already resident in HBM: per GPU ``[256, 576, 1024]`` + ``[256, 576, 4096]`` bf16 ->
-``[256, 144, 4096]`` (BASELINE.json configs[1]: scale_factor=2, B=256, CLIP-L 336 px, bf16).  With
-N > 1 the batch is sharded (weak scaling: 256 images per GPU, weights replicated) and every step
-ends with the ONE all-gather of projected tokens the north_star prescribes, so each rank holds
-``[256*N, 144, 4096]``; ``--no-gather`` drops it (DDP-style, the LLM consumes the local shard).
+One "step" = one pass of the hot path (``TokenPacker.forward``) over one synthetic batch of CLIP features already
+resident in HBM — BASELINE.json's metric, "projector images/sec, B=256 576->144 tokens, 1/2/4/8 x MI355X": a GLOBAL
+batch of 256 images ``[256, 576, 1024]`` + ``[256, 576, 4096]`` bf16 -> ``[256, 144, 4096]`` (configs[1]:
+scale_factor=2, CLIP-L 336 px, bf16).  With N > 1 the batch is SHARDED (``--scaling strong``, the default: 256/N
+images per GPU, weights replicated — SURVEY.md §8e) and every step ends with the ONE all-gather of projected tokens
+the north_star prescribes, so each rank holds ``[256, 144, 4096]``; the gather of step i overlaps the forward of
+step i+1 (two rotating output buffers, all gathers drained inside the timed region).  ``--scaling weak`` keeps 256
+images per GPU instead; ``--no-gather`` drops the collective (DDP-style: the LLM consumes the local shard).
+
+Other workloads (each prints the same one-line JSON):
+  --hd    BASELINE configs[3], TokenPacker-HD: 32 images x 9 crops = 288 crops sharded over the ranks (ragged when
+          288 % N != 0), ONE all-gather of b_max-row slots, then the HD token assembly (tp_hd_assemble) reading the
+          gathered buffer in place.
+  --e2e   BASELINE configs[4], encode_images() end to end: random-init CLIP-ViT-L/14-336 forward (HF transformers on
+          PyTorch-ROCm — the producer, not our code) -> HIP projector on the four hidden-state slices (no torch.cat)
+          -> Vicuna-7B-shaped prefill (32 Llama layers of GEMMs + SDPA on PyTorch-ROCm — the consumer, not our code),
+          B=64 split over the ranks DDP-style; tokens/s plus the split into tower / projector / prefill time.
 
 Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
-  roofline     — dominant kernel = the first K/V layer GEMM (x_multi·[Wk0;Wv0]^T + GELU, 45 % of the
-                 path's FLOPs): algorithmic FLOPs per launch / its average duration measured with HIP
-                 events recorded by the library on the launch stream inside the timed forward
-                 (tp_forward_staged), against the dense bf16 MFMA peak.
-  cpu_baseline — the CPU oracle (a torch-CPU port of the reference's arithmetic, fp32, all host
-                 cores) timed on a bounded sample (BASELINE config 1: B=4) on rank 0 at N=1.
+  roofline     — dominant kernel = the first K/V layer GEMM (x_multi·[Wk0;Wv0]^T + GELU, 45 % of the path's FLOPs):
+                 algorithmic FLOPs per launch / its average duration measured with HIP events recorded by the library
+                 on the launch stream inside a real forward (tp_forward_staged), against the dense bf16 MFMA peak;
+                 ``traffic`` = HBM bytes per launch from the rocprofv3 PMC passes condensed in profiles/traffic.json
+                 (stamped with the git tree of the kernel sources they were measured on; a stale file is refused).
+  cpu_baseline — the reference's op sequence (nn.Linear / F.interpolate / nn.MultiheadAttention ..., fp32) on the host
+                 cores, BASELINE config 1 (B=4), a bounded ~12 s sample, rank 0 at N=1 only.
   stages_ms    — per-kernel breakdown of one forward.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -33,6 +46,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
 
 # algorithmic work per image, D = hidden size, s = scale factor
 def flops_per_image(s: int, D: int, g: int = 24) -> float:
@@ -55,7 +69,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--batch", type=int, default=256,
+                    help="images: the GLOBAL batch under --scaling strong (default), per GPU under --scaling weak")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     ap.add_argument("--scale-factor", type=int, default=2)
     ap.add_argument("--hidden-size", type=int, default=4096)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
@@ -66,9 +82,18 @@ def parse_args():
     ap.add_argument("--sync-gather", action="store_true",
                     help="N>1: finish each step's all-gather before the next forward (default: the gather of step i "
                          "overlaps the forward of step i+1, two rotating output buffers)")
+    ap.add_argument("--hd", action="store_true", help="TokenPacker-HD workload (BASELINE configs[3]); see module docstring")
+    ap.add_argument("--hd-images", type=int, default=32)
+    ap.add_argument("--e2e", action="store_true", help="encode_images() + 7B-shaped prefill (BASELINE configs[4])")
+    ap.add_argument("--e2e-batch", type=int, default=64, help="global batch of the --e2e workload")
+    ap.add_argument("--e2e-text-tokens", type=int, default=64)
+    ap.add_argument("--e2e-layers", type=int, default=32, help="Llama layers of the prefill (32 = 7B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0: min(cores, 32))")
     ap.add_argument("--tile", type=int, default=0, help="force GEMM tile (0 auto, 128, 256)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="tp_set_tuning, e.g. --tune ABSORB_KV=2 --tune RESERVE_CUS=1 (keys: _capi.TP_TUNE_*)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1 (nccl = RCCL; gloo only to exercise the N>1 flow on one GPU)")
     ap.add_argument("--single-device", action="store_true",
@@ -87,31 +112,179 @@ def make_device_inputs(B, dtype, layout, device, seed):
     return xb, xmb
 
 
-def cpu_baseline(seconds: float, s: int, D: int):
-    """Timed CPU leg: the oracle (torch-CPU port of the reference arithmetic) in fp32 on all host
-    cores, BASELINE config 1 (B=4).  This is the ONLY place bench.py touches oracle/."""
-    from oracle import tokenpacker_oracle as orc          # noqa: the cpu_baseline leg
-    from tokenpacker_amd import synth
+def cpu_baseline(seconds: float, s: int, D: int, threads: int):
+    """Timed CPU leg: the reference's own op sequence — nn.Linear x9, nn.GELU, nn.LayerNorm, F.interpolate and
+    nn.MultiheadAttention (L=1, S=s*s) in the reference's token-major layout (oracle/reference_ops.py, a restatement of
+    builder.py:107-137 checked against the reference module) — in fp32 on the host cores, BASELINE config 1 (B=4).
+    This is the ONLY place bench.py touches oracle/."""
+    from oracle.reference_ops import eager_forward        # noqa: the cpu_baseline leg
+    from tokenpacker_amd import TokenPacker, synth
     B = 4
-    params = synth.make_params(0, D)
+    cores = threads if threads > 0 else min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    m = TokenPacker(hidden_size=D, scale_factor=s)
+    m.load_state_dict(synth.make_params(0, D))
+    m = m.eval().requires_grad_(False)
     x, xm = synth.make_inputs(1234, B)
-    cores = torch.get_num_threads()
     with torch.no_grad():
         for _ in range(2):
-            orc.forward(params, x, xm, scale_factor=s, compute_dtype=torch.float32)
+            eager_forward(m, x, xm)
         n, t0 = 0, time.perf_counter()
         while True:
-            orc.forward(params, x, xm, scale_factor=s, compute_dtype=torch.float32)
+            eager_forward(m, x, xm)
             n += 1
             el = time.perf_counter() - t0
-            if el >= seconds or n >= 200:
+            if el >= seconds or n >= 400:
                 break
-    return {"value": round(B * n / el, 2), "unit": "images/s", "cores": cores, "kind": "port",
+    return {"value": round(B * n / el, 2), "unit": "images/s", "cores": cores, "kind": "reference-op-sequence",
             "ms_per_image": round(1e3 * el / (B * n), 3),
-            "sample": f"{n} forwards of B={B}, s={s}, D={D}, fp32 torch-CPU oracle, {el:.1f} s "
+            "sample": f"{n} forwards of B={B}, s={s}, D={D}, fp32, the reference's torch op sequence incl. "
+                      f"nn.MultiheadAttention on {cores} host threads of {os.cpu_count()} logical cores, {el:.1f} s "
                       f"(BASELINE config 1 shape)"}
 
 
+def kernel_source_digest() -> str:
+    """sha256 over the kernel sources: what profiles/traffic.json must have been measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "tokenpacker_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic(B: int, dtype: str, layout: str):
+    """PMC-derived HBM bytes per kv_layer0 launch — only if the file was stamped on THIS kernel source."""
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tfile) or layout != "tower":
+        return None, None
+    try:
+        doc = json.load(open(tfile))
+        entry = doc.get(f"kv_layer0_B{B}_{dtype}")
+        stamp = doc.get("_stamp", {})
+        if not entry:
+            return None, None
+        if stamp.get("kernel_source_sha16") != kernel_source_digest():
+            return None, f"profiles/traffic.json is stale (measured on kernel sources {stamp.get('kernel_source_sha16')}, tag {stamp.get('tag')})"
+        return entry["total"], f"{stamp.get('tag')} @ {stamp.get('head')}"
+    except Exception as exc:        # noqa: a broken file must not break the bench line
+        return None, f"profiles/traffic.json unreadable: {exc}"
+
+
+def build_model(D, s, dtype, device):
+    from tokenpacker_amd import TokenPacker
+    torch.manual_seed(0)
+    model = TokenPacker(hidden_size=D, scale_factor=s)
+    # default init has zero biases / unit LN affine; randomise them so those code paths do real work
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("bias"):
+                p.copy_(0.02 * torch.randn(p.shape, generator=g))
+            elif name.startswith("ln_"):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+    return model.to(device=device, dtype=dtype).eval().requires_grad_(False)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def run_e2e(args, world, rank, device, dtype, dist):
+    """BASELINE configs[4]: tower -> HIP projector -> 7B-shaped prefill, DDP-style (no collective: each rank's LLM
+    consumes its own shard)."""
+    import torch.nn.functional as F
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    from tokenpacker_amd import shard, tower
+    s, D = args.scale_factor, args.hidden_size
+    M = (24 // s) ** 2
+    lo, hi = shard.shard_bounds(args.e2e_batch, world, rank)
+    b = hi - lo
+    torch.manual_seed(7)
+    clip = CLIPVisionModel(CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24,
+                                            num_attention_heads=16, image_size=336, patch_size=14))
+    clip = clip.to(device=device, dtype=dtype).eval().requires_grad_(False)
+    model = build_model(D, s, dtype, device)
+    L, H, Dh, F_ = args.e2e_layers, 32, D // 32, 11008 if D == 4096 else int(D * 2.6875)
+    g = torch.Generator(device=device).manual_seed(11 + rank)
+
+    def w(*shape):
+        return (torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * shape[-1] ** -0.5).to(dtype)
+    layers = [dict(qkv=w(3 * D, D), o=w(D, D), gate_up=w(2 * F_, D), down=w(D, F_),
+                   n1=torch.ones(D, device=device, dtype=dtype), n2=torch.ones(D, device=device, dtype=dtype)) for _ in range(L)]
+    images = torch.randn(b, 3, 336, 336, generator=g, device=device, dtype=torch.float32).to(dtype)
+    text = (0.02 * torch.randn(b, args.e2e_text_tokens, D, generator=g, device=device, dtype=torch.float32)).to(dtype)
+    T = M + args.e2e_text_tokens
+
+    def rms(t, wgt):
+        return (t.float() * torch.rsqrt(t.float().square().mean(-1, keepdim=True) + 1e-6)).to(t.dtype) * wgt
+
+    def prefill(h):
+        for ly in layers:
+            q, k, v = F.linear(rms(h, ly["n1"]), ly["qkv"]).view(b, T, 3, H, Dh).permute(2, 0, 3, 1, 4)
+            a = F.scaled_dot_product_attention(q, k, v, is_causal=True).transpose(1, 2).reshape(b, T, D)
+            h = h + F.linear(a, ly["o"])
+            gu = F.linear(rms(h, ly["n2"]), ly["gate_up"])
+            h = h + F.linear(F.silu(gu[..., :F_]) * gu[..., F_:], ly["down"])
+        return h
+
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+    def step(timed=False):
+        if timed:
+            ev[0].record()
+        hs = clip(images, output_hidden_states=True).hidden_states          # the tower (clip_encoder.py:46-62)
+        if timed:
+            ev[1].record()
+        x, parts = tower.select_features(hs)                                 # [:, 1:] views, no torch.cat
+        tok = model((x, parts))                                              # the hot path (llava_arch.py:97)
+        if timed:
+            ev[2].record()
+        out = prefill(torch.cat([tok, text], dim=1))                         # visual tokens ahead of the text
+        if timed:
+            ev[3].record()
+        return out
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1)):
+            y = step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        step(timed=True)
+        torch.cuda.synchronize(device)
+    assert y.shape == (b, T, D) and torch.isfinite(y[:1].float()).all()
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t[0].item())
+    if rank != 0:
+        return
+    tokens = args.e2e_batch * T
+    out = {"metric": "encode_images + prefill tokens/sec", "value": round(tokens * args.steps / elapsed, 1), "unit": "tokens/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": f"BASELINE configs[4]: CLIP-ViT-L/14-336 forward (random init, HF transformers on PyTorch-ROCm) -> "
+                                  f"HIP TokenPacker (scale_factor={s}, four hidden-state slices, no torch.cat) -> Llama-7B-shaped "
+                                  f"prefill ({L} layers, D={D}, PyTorch-ROCm GEMMs + SDPA), {M} visual + {args.e2e_text_tokens} text "
+                                  f"tokens per sample",
+                      "global_batch": args.e2e_batch, "per_gpu_batch": b, "parallelism": f"DDP-style batch shard x{world}, no collective",
+                      "tokens_per_step": tokens},
+           "split_ms": {"tower": round(ev[0].elapsed_time(ev[1]), 3), "projector_hip": round(ev[1].elapsed_time(ev[2]), 3),
+                        "prefill": round(ev[2].elapsed_time(ev[3]), 3)},
+           "note": "tower and prefill are PyTorch-ROCm library code around the path (producer / consumer), timed to place the "
+                   "projector inside encode_images(); only projector_hip is this repository's kernels"}
+    print(json.dumps(out), flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -136,33 +309,58 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    from tokenpacker_amd import TokenPacker, _capi, shard
+    from tokenpacker_amd import _capi, hd, shard
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
-    B, s, D = args.batch, args.scale_factor, args.hidden_size
+    s, D = args.scale_factor, args.hidden_size
     M = (24 // s) ** 2
     if args.tile:
         _capi.set_tuning(_capi.TP_TUNE_GEMM_TILE, args.tile)
+    for kv in args.tune:
+        key, val = kv.split("=")
+        _capi.set_tuning(getattr(_capi, "TP_TUNE_" + key.upper()), int(val))
 
-    torch.manual_seed(0)
-    model = TokenPacker(hidden_size=D, scale_factor=s)
-    # default init has zero biases / unit LN affine; randomise them so those code paths do real work
-    g = torch.Generator().manual_seed(1)
-    with torch.no_grad():
-        for name, p in model.named_parameters():
-            if name.endswith("bias"):
-                p.copy_(0.02 * torch.randn(p.shape, generator=g))
-            elif name.startswith("ln_"):
-                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
-    model = model.to(device=device, dtype=dtype).eval().requires_grad_(False)
+    if args.e2e:
+        run_e2e(args, world, rank, device, dtype, dist)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
-    x, xm = make_device_inputs(B, dtype, args.layout, device, seed=1234 + rank)
-    total = B * world
+    # ---- the workload: what each rank projects, and how many units the whole job processes per step -------------
+    if args.hd:
+        # 32 images x (2 x 4 grid + global view) = 288 crops (BASELINE configs[3]); crops are the projector's batch
+        hb, wb = [2] * args.hd_images, [4] * args.hd_images
+        total = sum(hd.hd_crop_count(a, c) for a, c in zip(hb, wb))
+        lo, hi = shard.shard_bounds(total, world, rank)
+        B, scaling = hi - lo, "strong"
+    elif args.scaling == "strong":
+        total = args.batch
+        lo, hi = shard.shard_bounds(total, world, rank)
+        B, scaling = hi - lo, "strong"
+    else:
+        B, total, scaling = args.batch, args.batch * world, "weak"
+    ragged = len(set(shard.shard_sizes(total, world))) > 1 if scaling == "strong" else False
+
+    model = build_model(D, s, dtype, device)
+    x, xm = make_device_inputs(max(B, 1), dtype, args.layout, device, seed=1234 + rank)
+    x, xm = x[:B], xm[:B]
     gather = world > 1 and not args.no_gather
-
-    pipe = shard.TokenGatherPipeline(total, depth=2) if (gather and not args.sync_gather) else None
+    pipe = shard.TokenGatherPipeline(total, depth=2) if (gather and not args.sync_gather and not ragged and not args.hd) else None
+    if args.hd:
+        gsep = torch.Generator(device=device).manual_seed(5)
+        sep = torch.randn(D, generator=gsep, device=device, dtype=torch.float32).to(dtype)
+        ret = torch.randn(D, generator=gsep, device=device, dtype=torch.float32).to(dtype)
 
     def step():
+        if args.hd:
+            # project the local crops -> ONE all-gather (b_max-row slots, read in place) -> HD token assembly of all images
+            if gather:
+                g_tok = shard.project_sharded(model, x, xm, total, dense=False)
+                if isinstance(g_tok, shard.GatheredTokens):
+                    return hd.assemble_hd_tokens(g_tok.buf, hb, wb, sep, ret, crop_map=g_tok.crop_map())
+                return hd.assemble_hd_tokens(g_tok, hb, wb, sep, ret)
+            y_loc = model((x, xm))
+            return hd.assemble_hd_tokens(y_loc, hb, wb, sep, ret) if world == 1 else y_loc
         if pipe is not None:                 # forward of this step overlaps the gather of the previous one
             slot = pipe.submit(model((x, xm)))
             return pipe._bufs[slot]
@@ -192,7 +390,7 @@ def main():
         # launch stream (tp_forward_staged).  A few extra forwards after the timed region.
         n_prof = min(max(args.steps, 3), 10)
         stage_ms = [0.0] * _capi.TP_NUM_STAGES
-        for _ in range(n_prof):
+        for _ in range(n_prof if B > 0 else 0):
             _, evs = model.forward_staged((x, xm))
             torch.cuda.synchronize(device)
             for i in range(_capi.TP_NUM_STAGES):
@@ -210,17 +408,30 @@ def main():
                 y_loc = model((x, xm))
             fence()
             extra["forward_only_ms"] = 1e3 * (time.perf_counter() - t1) / n_x
-            gp = pipe if pipe is not None else shard.TokenGatherPipeline(total, depth=2)
-            gp.submit(y_loc)
-            fence()
-            t1 = time.perf_counter()
-            for _ in range(n_x):
+            if not ragged:
+                gp = pipe if pipe is not None else shard.TokenGatherPipeline(total, depth=2)
                 gp.submit(y_loc)
-            gp.drain()
-            fence()
-            extra["gather_only_ms"] = 1e3 * (time.perf_counter() - t1) / n_x
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(n_x):
+                    gp.submit(y_loc)
+                gp.drain()
+                fence()
+                extra["gather_only_ms"] = 1e3 * (time.perf_counter() - t1) / n_x
+            else:
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(n_x):
+                    shard.all_gather_tokens(y_loc, total, dense=False)
+                fence()
+                extra["gather_only_ms"] = 1e3 * (time.perf_counter() - t1) / n_x
 
-    assert y.shape == ((total if gather else B), M, D) and torch.isfinite(y[:2].float()).all()
+    if args.hd:
+        rows_img = hd.hd_token_rows(2, 4, M)
+        if gather or world == 1:
+            assert len(y) == args.hd_images and y[0].shape == (rows_img, D) and torch.isfinite(y[0].float()).all()
+    else:
+        assert y.shape == ((total if gather else B), M, D) and torch.isfinite(y[:2].float()).all(), y.shape
 
     t = torch.tensor([elapsed, extra.get("forward_only_ms", 0.0), extra.get("gather_only_ms", 0.0)],
                      dtype=torch.float64, device=device)
@@ -232,17 +443,11 @@ def main():
 
     if rank == 0:
         fl_img = flops_per_image(s, D)
-        kv0_flops = 2.0 * B * 576 * 4096 * 2048                 # algorithmic FLOPs of the dominant launch
+        kv0_flops = 2.0 * B * 576 * 4096 * 2048                 # algorithmic FLOPs of the dominant launch ON THIS RANK
         kv0_ms = stage_ms[1]
-        achieved = kv0_flops / (kv0_ms * 1e-3) / 1e12
-        traffic, traffic_detail = None, None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, if collected
-        if os.path.exists(tfile):
-            try:
-                traffic_detail = json.load(open(tfile)).get(f"kv_layer0_B{B}_{args.dtype}")
-                traffic = traffic_detail["total"] if (traffic_detail and args.layout == "tower") else None
-            except Exception:
-                traffic = None
+        achieved = kv0_flops / (kv0_ms * 1e-3) / 1e12 if kv0_ms > 0 else 0.0
+        traffic, traffic_src = load_traffic(B, args.dtype, args.layout)
+        unit_name = "HD crops (projector batch elements)" if args.hd else "images"
         out = {
             "metric": "projector images/sec",
             "value": round(images_per_s, 1),
@@ -251,27 +456,32 @@ def main():
             "ms_per_step": round(ms_per_step, 4),
             "ms_per_image": round(ms_per_step / total, 6),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"TokenPacker projector forward, scale_factor={s} (576->{M} tokens), "
-                                   f"B={B} images/GPU, CLIP-L/14 336px grid 24x24, C=1024, Cmulti=4096, D={D}",
+            "config": {"workload": (f"TokenPacker-HD: {args.hd_images} images x 9 crops (2x4 grid + global view) = {total} crops "
+                                    f"sharded over {world} rank(s), projector + all-gather + HD token assembly, " if args.hd else
+                                    "TokenPacker projector forward, ") +
+                                   f"scale_factor={s} (576->{M} tokens), global batch {total} {unit_name}, {B} on rank 0, "
+                                   f"CLIP-L/14 336px grid 24x24, C=1024, Cmulti=4096, D={D}",
                        "global_batch": total, "per_gpu_batch": B, "scale_factor": s, "hidden_size": D,
                        "input_layout": args.layout,
                        "parallelism": f"batch-shard x{world}" + ((" + all_gather(tokens)" + (
                            ", gather of step i overlapped with forward of step i+1" if pipe is not None else "")) if gather else ""),
-                       "weights": "random init (reference distribution), synthetic unit-normal CLIP features"},
-            "whole_path": {"achieved_tflops": round(fl_img * B / (ms_per_step * 1e-3) / 1e12, 1),
-                           "frac_of_mfma_peak": round(fl_img * B / (ms_per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                       "weights": "random init (reference distribution), synthetic unit-normal CLIP features",
+                       "tuning": {k: _capi.get_tuning(getattr(_capi, k)) for k in dir(_capi) if k.startswith("TP_TUNE_")}},
+            "whole_path": {"achieved_tflops": round(fl_img * total / (ms_per_step * 1e-3) / 1e12, 1),
+                           "frac_of_mfma_peak": round(fl_img * total / (ms_per_step * 1e-3) / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),
                            "algorithmic_gflop_per_image": round(fl_img / 1e9, 3),
                            "algorithmic_io_mb_per_image": round(bytes_per_image(s, D) / 1e6, 3),
-                           "io_gbps": round(bytes_per_image(s, D) * B / (ms_per_step * 1e-3) / 1e9, 1)},
+                           "io_gbps": round(bytes_per_image(s, D) * total / (ms_per_step * 1e-3) / 1e9, 1)},
             "roofline": {"kernel": "tp::gemm8_kernel<T, f16, STRIDED_A> 256x256x64 ping-pong (kv_layer0: x_multi·[Wk0;Wv0]^T + bias + GELU)",
                          "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                          "flops_per_launch": kv0_flops, "avg_launch_ms": round(kv0_ms, 4),
-                         "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/traffic.json)",
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/traffic.json)",
                          "algorithmic_bytes": float(B * 576 * 4096 * 2 + 2048 * 4096 * 2 + B * 576 * 2048 * 2)},
             "stages_ms": {n: round(v, 4) for n, v in zip(_capi.STAGE_NAMES, stage_ms)},
         }
@@ -280,9 +490,10 @@ def main():
             out["multi_gpu"] = {"forward_only_ms": round(float(t[1].item()), 4),
                                 "forward_only_images_per_s": round(total / (float(t[1].item()) * 1e-3), 1),
                                 "gather_only_ms": round(float(t[2].item()), 4),
-                                "gather_bytes_received_per_rank": int((world - 1) * B * M * D * y.element_size())}
+                                "collective": f"{args.backend} all_gather_into_tensor over {world} ranks" + (" (ragged: b_max-row slots)" if ragged else ""),
+                                "gather_bytes_received_per_rank": int((total - B) * M * D * 2)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, s, D)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, s, D, args.cpu_threads)
         print(json.dumps(out), flush=True)
 
     if world > 1:

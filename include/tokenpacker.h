@@ -328,7 +328,7 @@ int tp_hd_slice(const float* image, int H, int W, int h_block, int w_block, int 
 /* ---- debug: fp16 saturation scan ---------------------------------------------------------------------------------
  * Every activation between the kernels of tp_forward is fp16 and every epilogue CLAMPS to +-65504 instead of producing
  * inf.  After a tp_forward on `stream` with the same desc / workspace, this scans the nine intermediate
- * buffers — q0, Hkv, H2, KV, Q1pre, Q, O, A1, A2 in this order — and writes into counts[i] (device int32[9]) the
+ * buffers — q0, Hkv, H2, KV (qt | u under the absorbed schedule), Q1pre, Q, O, A1, A2 in this order — and writes into counts[i] (device int32[9]) the
  * number of elements at the clamp bound (or NaN).  All zeros = no activation of that forward left the fp16 range. */
 #define TP_NUM_DEBUG_BUFFERS 9
 int tp_debug_count_saturated(const tp_desc* desc, const void* workspace, size_t workspace_bytes, int32_t* counts,

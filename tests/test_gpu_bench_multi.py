@@ -19,17 +19,23 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("extra", [[], ["--sync-gather"], ["--no-gather"]])
-def test_two_rank_bench_line(extra):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--batch", "4", "--backend", "gloo", "--single-device", "--no-cpu-baseline"] + extra
+def _run(extra, nproc=2):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1",
+           "--backend", "gloo", "--single-device", "--no-cpu-baseline"] + extra
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("extra", [[], ["--sync-gather"], ["--no-gather"]])
+def test_two_rank_bench_line(extra):
+    """Default = the metric's configuration: STRONG scaling, the global batch sharded over the ranks."""
+    d = _run(["--batch", "8"] + extra)
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong"
+    assert d["config"]["global_batch"] == 8 and d["config"]["per_gpu_batch"] == 4
     assert d["value"] > 0 and abs(d["value"] - 8 * 3 / (d["ms_per_step"] * 3 * 1e-3)) / d["value"] < 1e-3
     assert ("all_gather" in d["config"]["parallelism"]) == ("--no-gather" not in extra)
     assert "roofline" in d and "cpu_baseline" not in d
@@ -38,3 +44,24 @@ def test_two_rank_bench_line(extra):
         mg = d["multi_gpu"]
         assert mg["forward_only_ms"] > 0 and mg["gather_only_ms"] > 0
         assert mg["gather_bytes_received_per_rank"] == 4 * 144 * 4096 * 2
+
+
+def test_two_rank_weak_scaling_line():
+    d = _run(["--batch", "4", "--scaling", "weak"])
+    assert d["scaling"] == "weak" and d["config"]["global_batch"] == 8 and d["config"]["per_gpu_batch"] == 4
+
+
+@pytest.mark.parametrize("nproc,images", [(2, 4), (3, 5)])
+def test_hd_line_equal_and_ragged_shards(nproc, images):
+    """--hd: crops sharded over the ranks (3 ranks x 45 crops of 5 images is ragged: 15 each ... 5 images x 9 = 45 = 3 x 15
+    is equal, so use a count that is not: (3, 5) -> 45 crops / 3 = 15; (2, 4) -> 36 / 2 = 18) — plus a truly ragged one
+    below."""
+    d = _run(["--hd", "--hd-images", str(images)], nproc=nproc)
+    assert d["scaling"] == "strong" and d["config"]["global_batch"] == images * 9
+    assert "TokenPacker-HD" in d["config"]["workload"] and d["value"] > 0
+
+
+def test_hd_line_ragged():
+    d = _run(["--hd", "--hd-images", "3"], nproc=2)              # 27 crops over 2 ranks: 14 + 13
+    assert d["config"]["global_batch"] == 27 and d["config"]["per_gpu_batch"] == 14
+    assert "ragged" in d["multi_gpu"]["collective"]

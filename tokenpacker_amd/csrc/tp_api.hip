@@ -325,7 +325,9 @@ int tp_debug_count_saturated(const tp_desc* desc, const void* workspace, size_t 
     const long long rows_kv = (long long)B * g * g, rows_q = (long long)B * (g / s) * (g / s), E = kEmbed;
     const char* ws = (const char*)workspace;
     const struct { size_t off; long long n; } bufs[TP_NUM_DEBUG_BUFFERS] = {
-        {W.q0, rows_q * E}, {W.hkv, rows_kv * 2 * E}, {W.h2, 2 * rows_kv * E}, {W.kv, 2 * rows_kv * E}, {W.q1pre, rows_q * E},
+        // (the absorbed schedule keeps qt | u [2][rows_q, 8, E] where K | V would be)
+        {W.q0, rows_q * E}, {W.hkv, rows_kv * 2 * E}, {W.h2, 2 * rows_kv * E},
+        {W.kv, absorb_kv(desc, false) ? 2 * rows_q * 8 * E : 2 * rows_kv * E}, {W.q1pre, rows_q * E},
         {W.q, rows_q * E}, {W.o, rows_q * E}, {W.a1, rows_q * E}, {W.a2, rows_q * (long long)D}};
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * TP_NUM_DEBUG_BUFFERS, stream);
     if (e != hipSuccess) { set_error("tp_debug_count_saturated: hipMemsetAsync: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }

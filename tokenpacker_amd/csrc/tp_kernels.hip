@@ -221,12 +221,20 @@ region_attention_absorbed_kernel(const f16_t* __restrict__ qt, const f16_t* __re
         const int a = kk / s, c = kk - a * s;
         return (long long)b * N + (long long)((i * s + a) * g + j * s + c);
     };
-    auto load_normalised = [&](const f16_t* __restrict__ base, const float* __restrict__ mr, long long row, float (&na)[8], float (&nb)[8]) {
-        const float2 st = *(const float2*)(mr + row * 2);       // (mean, rstd): the same address for all lanes
-        load8(base + row * E + ea, na);
-        load8(base + row * E + eb, nb);
+    // Rows are fetched ONE KEY AHEAD (packed, 8 VGPRs + the row's statistics) so that two rows per wave are in flight:
+    // at 2 waves / SIMD (the 128 fp32 accumulators of phase B) a CU would otherwise keep 16 KiB outstanding.
+    struct Row { f16x8 a, b; float2 st; };
+    auto fetch = [&](const f16_t* __restrict__ base, const float* __restrict__ mr, int t) -> Row {
+        const long long row = token_row(t < S2 ? t : S2 - 1);
+        Row r;
+        r.st = *(const float2*)(mr + row * 2);                  // (mean, rstd): the same address for all lanes
+        r.a = *(const f16x8*)(base + row * E + ea);
+        r.b = *(const f16x8*)(base + row * E + eb);
+        return r;
+    };
+    auto normalise = [&](const Row& r, float (&na)[8], float (&nb)[8]) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { na[e] = (na[e] - st.x) * st.y; nb[e] = (nb[e] - st.x) * st.y; }
+        for (int e = 0; e < 8; ++e) { na[e] = ((float)r.a[e] - r.st.x) * r.st.y; nb[e] = ((float)r.b[e] - r.st.x) * r.st.y; }
     };
 
     {   // ---- phase A: logits ---------------------------------------------------------------------------------
@@ -236,9 +244,12 @@ region_attention_absorbed_kernel(const f16_t* __restrict__ qt, const f16_t* __re
             qa[h] = *(const f16x8*)(qt + (qi * H + h) * E + ea);
             qb[h] = *(const f16x8*)(qt + (qi * H + h) * E + eb);
         }
+        Row cur = fetch(h2k, mr_k, 0);
         for (int t = 0; t < S2; ++t) {
+            const Row nxt = fetch(h2k, mr_k, t + 1);
             float na[8], nb[8], v[H];
-            load_normalised(h2k, mr_k, token_row(t), na, nb);
+            normalise(cur, na, nb);
+            cur = nxt;
 #pragma unroll
             for (int h = 0; h < H; ++h) {
                 float acc = 0.f;
@@ -286,9 +297,12 @@ region_attention_absorbed_kernel(const f16_t* __restrict__ qt, const f16_t* __re
     for (int h = 0; h < H; ++h)
 #pragma unroll
         for (int e = 0; e < 8; ++e) { ua[h][e] = 0.f; ub[h][e] = 0.f; }
+    Row cur = fetch(h2v, mr_v, 0);
     for (int t = 0; t < S2; ++t) {
+        const Row nxt = fetch(h2v, mr_v, t + 1);
         float na[8], nb[8];
-        load_normalised(h2v, mr_v, token_row(t), na, nb);
+        normalise(cur, na, nb);
+        cur = nxt;
         const f32x4 p0 = *(const f32x4*)(lg + t * H), p1 = *(const f32x4*)(lg + t * H + 4);     // broadcast reads
         const float p[H] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
 #pragma unroll

@@ -22,7 +22,7 @@ fi
 if has tests; then
   echo "== pytest gpu =="
   timeout 1500 python -m pytest tests -m gpu -q -s -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1
-  echo "pytest exit $?"; grep -E "passed|failed|error" $OUT/pytest_gpu.log | tail -5; grep -E "^\[parity\]|^\[eager" $OUT/pytest_gpu.log | tail -40
+  echo "pytest exit $?"; grep -E "passed|failed|error" $OUT/pytest_gpu.log | tail -5; grep -E "^\[parity\]|^\[eager|^\[e2e\]|^\[adv\]|^\[grad\].*worst" $OUT/pytest_gpu.log | tail -120; grep -E "^(FAILED|ERROR)" $OUT/pytest_gpu.log | head -40
   cp gpurun_out/eager_rocm_s*.json $OUT/ 2>/dev/null
 fi
 if has gemm; then
@@ -53,6 +53,24 @@ if has sweep; then
   for sf in 3 4; do timeout 300 python bench.py --scale-factor $sf --no-cpu-baseline > $OUT/bench_s$sf.json 2>> $OUT/bench.err; cat $OUT/bench_s$sf.json; done
   timeout 300 python bench.py --batch 36 --no-cpu-baseline > $OUT/bench_hd36.json 2>> $OUT/bench.err; cat $OUT/bench_hd36.json
   timeout 300 python bench.py --dtype fp16 --no-cpu-baseline > $OUT/bench_fp16.json 2>> $OUT/bench.err; cat $OUT/bench_fp16.json
+fi
+if has small; then
+  echo "== small batches (strong-scaling shards: 256/8 = 32 images, B = 1, 8, 64, 128) and the HD workload on one GPU =="
+  for b in 1 8 32 64 128; do timeout 300 python bench.py --batch $b --no-cpu-baseline > $OUT/bench_b$b.json 2>> $OUT/bench.err; python - "$OUT/bench_b$b.json" <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1])); print("B=%d: %.1f img/s  %.4f ms/step  whole-path %.0f TFLOP/s" % (d["config"]["global_batch"], d["value"], d["ms_per_step"], d["whole_path"]["achieved_tflops"]))
+PY
+  done
+  timeout 300 python bench.py --hd --no-cpu-baseline > $OUT/bench_hd288.json 2>> $OUT/bench.err; cat $OUT/bench_hd288.json
+fi
+if has absorb; then
+  echo "== absorbed K/V schedule A/B (s = 2 forced on; s = 3, 4 forced off) =="
+  timeout 300 python bench.py --tune ABSORB_KV=2 --no-cpu-baseline > $OUT/bench_s2_absorb.json 2>> $OUT/bench.err; cat $OUT/bench_s2_absorb.json
+  for sf in 3 4; do timeout 300 python bench.py --scale-factor $sf --tune ABSORB_KV=1 --no-cpu-baseline > $OUT/bench_s${sf}_plain.json 2>> $OUT/bench.err; cat $OUT/bench_s${sf}_plain.json; done
+fi
+if has e2e; then
+  echo "== encode_images + 7B-shaped prefill (BASELINE configs[4], B=64 on one GPU) =="
+  timeout 600 python bench.py --e2e --steps 5 --warmup 2 > $OUT/bench_e2e.json 2>> $OUT/bench.err; cat $OUT/bench_e2e.json; tail -3 $OUT/bench.err
 fi
 if has prof; then
   echo "== rocprof kernel trace =="
