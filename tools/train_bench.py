@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Training-step timing of the projector on one MI355X: HIP forward+backward (tp_forward_train / tp_backward
 through the autograd node) next to the reference's op sequence under PyTorch-ROCm eager autograd
-(tests/eager_port.py).  Batch 32 is the reference's per-GPU pretraining batch (scripts/v1_5/pretrain.sh:19).
+(oracle/reference_ops.py).  Batch 32 is the reference's per-GPU pretraining batch (scripts/v1_5/pretrain.sh:19).
+A step is forward + backward + OPTIMIZER STEP (plain SGD on the 23 parameters, `--optimizer none` to leave it out):
+the weight update is what makes the next forward re-pack the kernel-side weight image (casts, LayerNorm folds) and
+the backward re-transpose the weights, so it belongs inside the timed step.  FLOPs are priced on the work the
+backward actually has to do: no input gradient for k/v_proj_1[0] (the CLIP features come from a frozen tower).
 
     python tools/train_bench.py [--batches 32 256] [--scale-factor 2] [--out gpurun_out/train_bench.json]
 """
@@ -15,13 +19,20 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tests.eager_port import eager_forward  # noqa: E402  (baseline only)
+from oracle.reference_ops import eager_forward  # noqa: E402  (baseline only)
 from tokenpacker_amd import TokenPacker  # noqa: E402
 
 
 def flops_fwd(B, s, D):
     N, M, E = 576, (24 // s) ** 2, 1024
     return 2.0 * B * (N * 4096 * E * 2 + N * E * E * 4 + M * E * E * 3 + M * E * D + M * D * D)
+
+
+def flops_train(B, s, D):
+    """forward + weight gradients of every linear + input gradients of every linear EXCEPT the two first K/V layers
+    (their input is x_multi, which gets no gradient: 2 x 4.83 GF / image of dgrad that nobody has to compute)."""
+    N, E = 576, 1024
+    return 3.0 * flops_fwd(B, s, D) - 2.0 * B * (N * 4096 * E * 2)
 
 
 def timed(fn, iters, warm=3):
@@ -42,6 +53,7 @@ def main():
     ap.add_argument("--hidden-size", type=int, default=4096)
     ap.add_argument("--out", default="gpurun_out/train_bench.json")
     ap.add_argument("--hip-only", action="store_true", help="skip the eager baseline (profiling runs)")
+    ap.add_argument("--optimizer", default="sgd", choices=["sgd", "none"])
     args = ap.parse_args()
     s, D, dtype = args.scale_factor, args.hidden_size, torch.bfloat16
     results = []
@@ -53,13 +65,19 @@ def main():
         xm = torch.randn(B, 576, 4096, generator=g, device="cuda").to(dtype)
         w = torch.randn(B, (24 // s) ** 2, D, generator=g, device="cuda").to(dtype)
 
+        opt = torch.optim.SGD(m.parameters(), lr=1e-6) if args.optimizer == "sgd" else None
+
         def step_hip():
             m.zero_grad(set_to_none=True)
             (m((x, xm)) * w).sum().backward()
+            if opt is not None:
+                opt.step()
 
         def step_eager():
             m.zero_grad(set_to_none=True)
             (eager_forward(m, x, xm) * w).sum().backward()
+            if opt is not None:
+                opt.step()
 
         def fwd_hip():
             with torch.no_grad():
@@ -84,7 +102,9 @@ def main():
         rec = {"B": B, "scale_factor": s, "D": D, "dtype": "bf16", "hip_fwd_bwd_ms": round(ms_hip, 3),
                "hip_fwd_only_ms": round(ms_fwd, 3), "eager_rocm_fwd_bwd_ms": round(ms_eager, 3),
                "speedup": round(ms_eager / ms_hip, 3), "images_per_s_train": round(B / ms_hip * 1e3, 1),
-               "train_tflops_algorithmic": round(3 * flops_fwd(B, s, D) / ms_hip / 1e9, 1),
+               "optimizer_in_step": args.optimizer,
+               "train_tflops_algorithmic": round(flops_train(B, s, D) / ms_hip / 1e9, 1),
+               "train_gflop_per_image": round(flops_train(1, s, D) / 1e9, 2),
                "max_param_grad_rel_l2_vs_eager": agree}
         print(json.dumps(rec), flush=True)
         results.append(rec)
