@@ -100,7 +100,9 @@ size_t tp_packed_weight_bytes(const tp_desc* desc);
  * [0] = number of weight elements that did not fit the fp16 range the kernels keep every post-first-layer weight in
  *       and were clamped to +-65504 (a bf16 model can hold such values; results would silently differ from the
  *       reference, so the Python wrapper raises OverflowError when it is non-zero),
- * [1] = 1 when the out_proj∘mlp[0] fold was built (TP_TUNE_FOLD_OUT_PROJ set at pack time).  0 on invalid args. */
+ * [1] = 1 when the out_proj∘mlp[0] fold was built (TP_TUNE_FOLD_OUT_PROJ set at pack time),
+ * [2] = 1 when the fused LayerNorm chain's Wc = W'·W2 / d = W'·b2 were built (TP_TUNE_FUSE_KV_LN at pack time).
+ * 0 on invalid args. */
 size_t tp_packed_status_offset(const tp_desc* desc);
 /* Bytes of scratch tp_forward() needs for this descriptor (depends on batch); 0 on invalid args. */
 size_t tp_workspace_bytes(const tp_desc* desc);
@@ -210,7 +212,9 @@ enum {
     TP_LINEAR_ROW_STATS = 4,
     TP_LINEAR_OUT_F32 = 8,     /* retired: use tp_linear_args.out_dtype = TP_F32                    */
     TP_LINEAR_SAVE_PRE = 16,   /* with GELU: also store the pre-activation (training forward)       */
-    TP_LINEAR_GELU_BWD = 32    /* multiply the result by gelu'(z), z = fp16 pre-activations (backward) */
+    TP_LINEAR_GELU_BWD = 32,   /* multiply the result by gelu'(z), z = fp16 pre-activations (backward) */
+    TP_LINEAR_NO_STORE = 64    /* with ROW_STATS: compute the row statistics of the (unrounded) result and store NOTHING else
+                                  — C may be NULL (the LayerNorm statistics of a tensor nobody needs to materialise)     */
 };
 typedef struct tp_linear_args {
     int32_t M, N, K;           /* N % 128 == 0, K % 64 == 0                                        */
@@ -356,7 +360,10 @@ enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all hal
                                      r CUs per XCD to kernels of other streams (RCCL's all-gather overlapping the next forward) */
        TP_TUNE_ABSORB_KV = 7,     /* K/V in-projection absorbed into the query side (see tp_forward): 0 auto (scale_factor >= 3),
                                      1 never, 2 always */
-       TP_TUNE_COUNT_ = 8 };
+       TP_TUNE_FUSE_KV_LN = 8,    /* 1 (default): inference, plain schedule: the K/V second layer is computed for its LayerNorm
+                                     statistics only (no H2 written) and the in-projection reads Hkv through the pre-multiplied
+                                     weight Wc = W'·W2 (tp_forward's header) | 0: H2 written and read back */
+       TP_TUNE_COUNT_ = 12 };
 int tp_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -274,3 +274,40 @@ def test_absorbed_kv_schedule_is_the_same_function(s, dtype):
     assert not torch.equal(ys[1], ys[2])                   # the knob really switches the schedule
     assert e1 <= 1e-3 and e2 <= 1e-3, (e1, e2)
     assert l2 <= 1.25 * l1 + 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B", [2, 9])
+def test_fused_layernorm_chain_is_the_same_function(dtype, B):
+    """TP_TUNE_FUSE_KV_LN (default on; inference, plain schedule): the K/V second layer computed for its LayerNorm
+    statistics only + the in-projection through Wc = W'·W2, against the two-GEMM form that writes H2: both within
+    the gate against the fp64 oracle.  B = 9 puts the GEMMs on the 256-tile persistent kernel (> 200 tiles), B = 2 on
+    the 128-tile kernel: both implement the accumulator pre-load (GemmArgs::acc_init)."""
+    from tokenpacker_amd import _capi
+    D, s = 256, 2
+    params = synth.make_params(95, D)
+    x, xm = synth.make_inputs(96, B, dtype)
+    p_lp = {k: v.to(dtype) for k, v in params.items()}
+    y_exact = orc.forward(p_lp, x, xm, scale_factor=s, compute_dtype=torch.float64, io_dtype=dtype)
+    ys = {}
+    try:
+        for mode in (0, 1):
+            _capi.set_tuning(_capi.TP_TUNE_FUSE_KV_LN, mode)
+            m = _module(params, s, D, dtype)
+            m.output_fp32 = True
+            with torch.no_grad():
+                ys[mode] = m((x.cuda(), xm.cuda()))
+            torch.cuda.synchronize()
+            assert sum(m.saturation_report().values()) == 0
+    finally:
+        _capi.set_tuning(_capi.TP_TUNE_FUSE_KV_LN, 1)
+    e0, e1 = orc.rel_err(ys[0], y_exact), orc.rel_err(ys[1], y_exact)
+    l0, l1 = orc.rel_l2(ys[0], y_exact), orc.rel_l2(ys[1], y_exact)
+    print(f"\n[parity] fused LN chain B={B} {dtype}: two-GEMM rel_err {e0:.3e} (l2 {l0:.3e}), fused {e1:.3e} (l2 {l1:.3e})")
+    assert not torch.equal(ys[0], ys[1])
+    assert e0 <= 1e-3 and e1 <= 1e-3, (e0, e1)
+    assert l1 <= 1.1 * l0 + 1e-5
+    # batch invariance across the two GEMM kernels: image 0 of the B-batch == the same image alone
+    m = _module(params, s, D, dtype)
+    with torch.no_grad():
+        assert torch.equal(m((x.cuda(), xm.cuda()))[:1], m((x[:1].cuda(), xm[:1].cuda())))

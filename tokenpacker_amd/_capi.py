@@ -15,9 +15,10 @@ TP_ABI_VERSION = 2
 TP_BF16, TP_F16, TP_F32 = 0, 1, 2
 TP_OK, TP_ERR_INVALID_ARG, TP_ERR_BAD_SCALE, TP_ERR_WORKSPACE, TP_ERR_LAUNCH = 0, -1, -2, -3, -4
 TP_LINEAR_GELU, TP_LINEAR_LN_FOLD, TP_LINEAR_ROW_STATS = 1, 2, 4
+TP_LINEAR_NO_STORE = 64
 TP_TUNE_GEMM_TILE, TP_TUNE_XCD_SWIZZLE, TP_TUNE_GEMM_KERNEL, TP_TUNE_FOLD_OUT_PROJ, TP_TUNE_DYNAMIC_TILES = 0, 1, 2, 3, 4
 TP_TUNE_Q_SIDE_STREAM = 5
-TP_TUNE_RESERVE_CUS, TP_TUNE_ABSORB_KV = 6, 7
+TP_TUNE_RESERVE_CUS, TP_TUNE_ABSORB_KV, TP_TUNE_FUSE_KV_LN = 6, 7, 8
 TP_WGRAD_X_TRANSPOSED = 1
 TP_NUM_STAGES = 10
 TP_NUM_DEBUG_BUFFERS = 9
@@ -205,7 +206,7 @@ def strides3(st) -> "ctypes.Array":
 
 
 _TUNING_DEFAULTS = {TP_TUNE_GEMM_TILE: 0, TP_TUNE_XCD_SWIZZLE: 1, TP_TUNE_GEMM_KERNEL: 0, TP_TUNE_FOLD_OUT_PROJ: 0,
-                    TP_TUNE_DYNAMIC_TILES: 1, TP_TUNE_Q_SIDE_STREAM: 1, TP_TUNE_RESERVE_CUS: 0, TP_TUNE_ABSORB_KV: 0}
+                    TP_TUNE_DYNAMIC_TILES: 1, TP_TUNE_Q_SIDE_STREAM: 1, TP_TUNE_RESERVE_CUS: 0, TP_TUNE_ABSORB_KV: 0, TP_TUNE_FUSE_KV_LN: 1}
 _tuning_values = dict(_TUNING_DEFAULTS)
 
 

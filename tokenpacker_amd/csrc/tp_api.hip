@@ -40,7 +40,7 @@ int check_launch(const char* what) {
     return TP_OK;
 }
 
-static std::atomic<int> g_tuning[TP_TUNE_COUNT_] = {{0}, {1}, {0}, {0}, {1}, {1}, {0}, {0}};   // [6] RESERVE_CUS, [7] ABSORB_KV
+static std::atomic<int> g_tuning[TP_TUNE_COUNT_] = {{0}, {1}, {0}, {0}, {1}, {1}, {0}, {0}, {1}, {0}, {0}, {0}};   // [6] RESERVE_CUS, [7] ABSORB_KV, [8] FUSE_KV_LN
 int tuning(int key) { return (key >= 0 && key < TP_TUNE_COUNT_) ? g_tuning[key].load() : 0; }
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
@@ -56,6 +56,7 @@ PackedLayout packed_layout(int D) {
     L.w_in_kv = take(2 * E * E * 2);     L.c_in_kv = take(2 * E * 4);  L.b_in_kv = take(2 * E * 4);
     L.w_in_q = take(E * E * 2);          L.c_in_q = take(E * 4);       L.b_in_q = take(E * 4);
     L.w_qt = take(E * E * 2);
+    L.w_c_kv = take(2 * E * E * 2);      L.d_in_kv = take(2 * E * 4);
     L.w_out = take(E * E * 2);           L.b_out = take(E * 4);
     L.w_m0 = take((size_t)D * E * 2);    L.b_m0 = take((size_t)D * 4);
     L.w_m2 = take((size_t)D * D * 2);    L.b_m2 = take((size_t)D * 4);
@@ -253,6 +254,26 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
     TP_TRY(pack_cast_f32_launch(dt, raw->mlp_0_bias, (float*)(P + L.b_m0), D, stream));
     TP_TRY(pack_cast_f16_launch(dt, raw->mlp_2_weight, P + L.w_m2, (long long)D * D, stream, sat));
     TP_TRY(pack_cast_f32_launch(dt, raw->mlp_2_bias, (float*)(P + L.b_m2), D, stream));
+    // Fused LayerNorm chain of the K/V side (inference, plain schedule; TP_TUNE_FUSE_KV_LN):
+    //   K = LN(H2)·Win^T + b,  H2 = Hkv·W2^T + b2   =>   K = rstd·(Hkv·Wc^T + d − mu·c) + b',
+    //   Wc = W'·W2 (fp32 accumulate on the MFMA kernel, rounded once to fp16),  d = W'·b2,  (mu, rstd) = row statistics
+    //   of H2 — which is then computed for those statistics only and never written (604 MB less written and read per
+    //   B = 256 forward, 16 fewer output stores per tile of that GEMM).  W' is the ROUNDED folded weight, so the mean
+    //   term still cancels against c = rowsum(W') exactly as in the unfused form.
+    if (tuning(TP_TUNE_FUSE_KV_LN) != 0) {
+        for (int g = 0; g < 2; ++g) {
+            TP_TRY(pack_transpose_f16_launch(P + L.w_kv2 + (size_t)g * E * E * 2, P + L.scratch_t, (int)E, stream));   // W2^T [k][j]
+            GemmArgs a = plain_gemm(P + L.w_in_kv + (size_t)g * E * E * 2, E, P + L.scratch_t, P + L.scratch_p, E, (int)E, (int)E,
+                                    (int)E, nullptr, 0);
+            a.tile = 128;
+            TP_TRY(gemm_launch(TP_F16, TP_F32, a, stream));                      // Wc[n][k] = sum_j W'[n][j] W2[j][k]
+            TP_TRY(pack_round_f16_launch((const float*)(P + L.scratch_p), P + L.w_c_kv + (size_t)g * E * E * 2, (long long)E * E, stream, sat));
+            TP_TRY(pack_bias_fold_launch(P + L.w_in_kv + (size_t)g * E * E * 2, (const float*)(P + L.b_kv2) + g * E, nullptr,
+                                         (float*)(P + L.d_in_kv) + g * E, (int)E, (int)E, stream));
+        }
+        hipError_t e = hipMemsetD32Async((hipDeviceptr_t)(status + 2), 1, 1, stream);
+        if (e != hipSuccess) { set_error("tp_pack_weights: hipMemsetD32Async(status): %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
+    }
     // out_proj folded into mlp[0]:  W_om = Wm0·Wout (fp32 accumulate on the MFMA kernel, rounded once to fp16),
     // b_om = Wm0·bout + bm0 — built only when the fold is switched on AT PACK TIME (TP_TUNE_FOLD_OUT_PROJ, default off:
     // a training step re-packs every step and must not pay for a product it never uses); status[1] records it.
@@ -326,7 +347,8 @@ int tp_debug_count_saturated(const tp_desc* desc, const void* workspace, size_t 
     const char* ws = (const char*)workspace;
     const struct { size_t off; long long n; } bufs[TP_NUM_DEBUG_BUFFERS] = {
         // (the absorbed schedule keeps qt | u [2][rows_q, 8, E] where K | V would be)
-        {W.q0, rows_q * E}, {W.hkv, rows_kv * 2 * E}, {W.h2, 2 * rows_kv * E},
+        {W.q0, rows_q * E}, {W.hkv, rows_kv * 2 * E},
+        {W.h2, (!absorb_kv(desc, false) && tuning(TP_TUNE_FUSE_KV_LN) != 0) ? 0 : 2 * rows_kv * E},   // (fused chain: H2 is never written)
         {W.kv, absorb_kv(desc, false) ? 2 * rows_q * 8 * E : 2 * rows_kv * E}, {W.q1pre, rows_q * E},
         {W.q, rows_q * E}, {W.o, rows_q * E}, {W.a1, rows_q * E}, {W.a2, rows_q * (long long)D}};
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * TP_NUM_DEBUG_BUFFERS, stream);
@@ -396,7 +418,11 @@ int tp_linear_stats_parts(const tp_linear_args* a) {
 }
 
 int tp_linear(const tp_linear_args* a, void* stream) {
-    if (!a || !a->A || !a->W || !a->C) { set_error("tp_linear: NULL argument"); return TP_ERR_INVALID_ARG; }
+    if (!a || !a->A || !a->W || (!a->C && !(a->flags & TP_LINEAR_NO_STORE))) { set_error("tp_linear: NULL argument"); return TP_ERR_INVALID_ARG; }
+    if ((a->flags & TP_LINEAR_NO_STORE) && !(a->flags & TP_LINEAR_ROW_STATS)) {
+        set_error("tp_linear: TP_LINEAR_NO_STORE only makes sense with TP_LINEAR_ROW_STATS");
+        return TP_ERR_INVALID_ARG;
+    }
     if ((a->flags & TP_LINEAR_LN_FOLD) && (!a->row_mean_rstd || !a->colsum)) {
         set_error("tp_linear: LN_FOLD needs row_mean_rstd and colsum");
         return TP_ERR_INVALID_ARG;
@@ -582,9 +608,11 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     // 3. H2[g] = Hkv[:, g*1024:(g+1)*1024] · W{k,v}2^T + b, and LayerNorm partials of H2
     TP_TRY(mark());
     const int parts_kv = gemm_stats_parts(E);
+    // (fused LayerNorm chain — inference, plain schedule: H2 is needed for its row statistics only and is not written)
+    const bool fuse_ln = !train && !absorb && tuning(TP_TUNE_FUSE_KV_LN) != 0;
     {
-        GemmArgs a = plain_gemm(ws + W.hkv, 2 * E, pw + P.w_kv2, ws + W.h2, E, rows_kv, E, E,
-                                (const float*)(pw + P.b_kv2), TP_LINEAR_ROW_STATS);
+        GemmArgs a = plain_gemm(ws + W.hkv, 2 * E, pw + P.w_kv2, fuse_ln ? nullptr : ws + W.h2, E, rows_kv, E, E,
+                                (const float*)(pw + P.b_kv2), TP_LINEAR_ROW_STATS | (fuse_ln ? TP_LINEAR_NO_STORE : 0));
         a.groups = 2; a.a_gs = E * 2; a.w_gs = (long long)E * E * 2; a.c_gs = kvE * 2; a.bias_gs = E;
         a.stats_out = (float*)(ws + W.stats_kv); a.stats_out_gs = (long long)parts_kv * rows_kv * 2;
         TP_TRY(launch(TP_F16, TP_F16, a, stream));
@@ -597,6 +625,11 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         GemmArgs a = plain_gemm(ws + W.h2, E, pw + P.w_in_kv, ws + W.kv, E, rows_kv, E, E,
                                 (const float*)(pw + P.b_in_kv), TP_LINEAR_LN_FOLD);
         a.groups = 2; a.a_gs = kvE * 2; a.w_gs = (long long)E * E * 2; a.c_gs = kvE * 2; a.bias_gs = E;
+        if (fuse_ln) {                                  // {K,V} = rstd·(Hkv[:, g]·Wc^T + d − mu·c) + b'
+            a.A = (const char*)(ws + W.hkv); a.lda_bytes = 2 * E * 2; a.a_gs = E * 2;
+            a.W = pw + P.w_c_kv;
+            a.acc_init = (const float*)(pw + P.d_in_kv); a.acc_init_gs = E;
+        }
         a.stats_in = (const float*)(ws + W.mr_kv); a.stats_in_gs = (long long)rows_kv * 2;
         a.colsum = (const float*)(pw + P.c_in_kv); a.colsum_gs = E;
         TP_TRY(launch(TP_F16, TP_F16, a, stream));

@@ -33,7 +33,7 @@ constexpr int gemm_lds_bytes() { return 2 * (BM + BN) * ROW_BYTES; }
 // [:,1:] slices) — only the first K/V layer needs it, which also gives that launch (45 % of the path's
 // FLOPs) its own kernel symbol in profiles.
 // TI: operand element type (bf16 / fp16) — selects the MFMA;  TO: output element type (bf16 / fp16 / float).
-template <typename TI, typename TO, int BM, int BN, int WM, int WN, int AMODE, bool TRAIN_EPI>
+template <typename TI, typename TO, int BM, int BN, int WM, int WN, int AMODE, bool TRAIN_EPI, int XMODE = 0>   // XMODE: tp_gemm8.hip
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
     using T = TI;
@@ -112,6 +112,15 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (XMODE == 2) {                         // accumulators start from a per-column constant (GemmArgs::acc_init)
+        const float* __restrict__ ai = p.acc_init + g * p.acc_init_gs + n0 + wn * WN + (lane >> 4) * 4;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const f32x4 dv = *(const f32x4*)(ai + j * 16);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) acc[i][j] = dv;
+        }
+    }
 
     // LayerNorm-fold operands (per-row mean, rstd) do not depend on the contraction: fetch them now so
     // their latency hides under the whole K loop instead of serialising the epilogue.
@@ -152,7 +161,7 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
         }
     }
 
-    gemm_epilogue<TO, BM, BN, WM, WN, false, TRAIN_EPI>(acc, p, g, m0, n0, tile_n, wm, wn, lane, tid, mean_rstd, smem);
+    gemm_epilogue<TO, BM, BN, WM, WN, false, TRAIN_EPI, XMODE == 1>(acc, p, g, m0, n0, tile_n, wm, wn, lane, tid, mean_rstd, smem);
 }
 
 // ---- host side ------------------------------------------------------------------------------------
@@ -165,11 +174,11 @@ int gemm_pick_tile(int M, int N, int forced, int groups) {
     return tiles256 >= 200 ? 256 : 128;     // the persistent 256-tile kernel from ~0.8 of a CU round up, else finer tiles
 }
 
-template <typename TI, typename TO, int BM, int BN, int WM, int WN, int AMODE, bool TRAIN_EPI = false>
+template <typename TI, typename TO, int BM, int BN, int WM, int WN, int AMODE, bool TRAIN_EPI = false, int XMODE = 0>
 static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     constexpr int lds = gemm_lds_bytes<BM, BN>();
     constexpr int threads = (BM / WM) * (BN / WN) * 64;
-    auto kern = gemm_kernel<TI, TO, BM, BN, WM, WN, AMODE, TRAIN_EPI>;
+    auto kern = gemm_kernel<TI, TO, BM, BN, WM, WN, AMODE, TRAIN_EPI, XMODE>;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [&] {
@@ -192,6 +201,18 @@ static int launch_types(const GemmArgs& a, hipStream_t stream) {
     const bool strided = a.rows_per_batch < a.M;
     constexpr bool HALF_OUT = !std::is_same<TO, float>::value;
     const bool train_epi = (a.flags & (TP_LINEAR_SAVE_PRE | TP_LINEAR_GELU_BWD)) != 0;
+    if ((a.flags & TP_LINEAR_NO_STORE) || a.acc_init) {     // the two GEMMs of the fused LayerNorm chain (128-tile form)
+        if constexpr (std::is_same<TI, f16_t>::value && std::is_same<TO, f16_t>::value) {
+            if (strided || train_epi || a.A_parts[0] || ((a.flags & TP_LINEAR_NO_STORE) && a.acc_init)) {
+                set_error("tp gemm: NO_STORE / acc_init take a contiguous A, no training epilogue, and not both at once");
+                return TP_ERR_INVALID_ARG;
+            }
+            return (a.flags & TP_LINEAR_NO_STORE) ? launch_cfg<TI, TO, 128, 128, 64, 64, 0, false, 1>(a, stream)
+                                                  : launch_cfg<TI, TO, 128, 128, 64, 64, 0, false, 2>(a, stream);
+        }
+        set_error("tp gemm: NO_STORE / acc_init are built for fp16 operands and output");
+        return TP_ERR_INVALID_ARG;
+    }
     if (a.A_parts[0] || train_epi) {                   // training epilogues / four-source A: 128-tile kernel only
         if constexpr (HALF_OUT) {
             if (a.A_parts[0]) {

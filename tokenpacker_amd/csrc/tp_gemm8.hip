@@ -60,9 +60,10 @@ constexpr int G8_BM = 256, G8_BN = 256, G8_WN = 64;
 constexpr int G8_GROUP = 128 * ROW_BYTES;          // 16 KiB: one DMA group (128 rows x 128 B)
 constexpr int G8_BUF = 4 * G8_GROUP;               // 64 KiB: one K-tile (G0 | G1 | G2 | G3)
 constexpr int G8_RING = 2 * G8_BUF;                // 128 KiB of K-tile buffers
-// persistent kernel, behind the ring: bias[256] | colsum[256] | (mean, rstd)[256] (4 KiB), 8 KiB row-statistics scratch,
-// the next tile index drawn from the queue
-constexpr int G8_LDS = G8_RING + 4096 + 8192 + 256;
+// persistent kernel, behind the ring: bias[256] | colsum[256] | (mean, rstd)[256] | acc_init[256] (5 KiB), 8 KiB
+// row-statistics scratch, the next tile index drawn from the queue
+constexpr int G8_PAR = 5120;
+constexpr int G8_LDS = G8_RING + G8_PAR + 8192 + 256;
 constexpr int G8_DEPTH = 3;                        // DMA groups left in flight by the in-loop wait (3 or 4 are legal;
                                                    // 4 = the latest legal wait placement measured no faster: r01u)
 
@@ -84,7 +85,10 @@ constexpr int G8_DEPTH = 3;                        // DMA groups left in flight 
 // so a K-tile is three DMA groups (G0 = the 128 A rows, G1 / G2 = W halves b0 / b1) consumed in TWO phases (a0,b0) (a0,b1)
 // of 16 MFMAs; the ring holds three K-tiles of 48 KiB.  Schedule: phase 0 of tile t issues G2(t+1), phase 1 issues G0(t+2)
 // and G1(t+2) — re-target distance 3 phases, flight time 2..3 phases — and both wait vmcnt(6).
-template <typename TI, typename TO, int AMODE, bool PERSIST, bool TRAIN_EPI, bool HALF = false>
+// XMODE: 0 plain | 1 statistics only (TP_LINEAR_NO_STORE: no output) | 2 accumulators pre-loaded from GemmArgs::acc_init —
+// the two GEMMs of the fused LayerNorm chain; separate instantiations so that the common kernels' register budget is
+// not taxed (one more live value in the persistent loop tipped them into scratch).
+template <typename TI, typename TO, int AMODE, bool PERSIST, bool TRAIN_EPI, bool HALF = false, int XMODE = 0>
 __global__ void __launch_bounds__(512, 2)
 gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int xcd_swizzle) {
     using X8 = typename Vec<TI>::x8;
@@ -94,7 +98,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
     constexpr int FM = WM / 16, FN = WN / 16;          // 8 x 4 (HALF: 4 x 4) accumulator fragments per wave
     constexpr int KBUF = HALF ? 3 * G8_GROUP : G8_BUF;  // one K-tile in the ring
     constexpr int RING = HALF ? 3 * KBUF : G8_RING;     // HALF: 144 KiB (three K-tiles), else 128 KiB (two)
-    constexpr int L_PAR = RING, L_RED = RING + 4096, L_NEXT = RING + 4096 + 8192;
+    constexpr int L_PAR = RING, L_RED = RING + G8_PAR, L_NEXT = RING + G8_PAR + 8192;
     auto ring_of = [](const int kt) __attribute__((always_inline)) -> int { if constexpr (HALF) return kt % 3; else return kt & 1; };
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -404,6 +408,18 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (XMODE == 2) {                         // accumulators start from a per-column constant (GemmArgs::acc_init)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                f32x4 dv;
+                if constexpr (PERSIST)                      // staged in LDS with the tile's other epilogue parameters
+                    dv = *(const f32x4*)(smem + L_PAR + 4096 + (wn * WN + (lane >> 4) * 4 + j * 16) * 4);
+                else
+                    dv = *(const f32x4*)(p.acc_init + g * p.acc_init_gs + n0 + wn * WN + (lane >> 4) * 4 + j * 16);
+#pragma unroll
+                for (int i = 0; i < FM; ++i) acc[i][j] = dv;
+            }
+        }
         if (wm == 1) __builtin_amdgcn_s_barrier();         // the late half runs one barrier behind
         __builtin_amdgcn_sched_barrier(0);
         int t = 0;
@@ -455,7 +471,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
                 mean_rstd[i] = *(const float2*)(p.stats_in + g * p.stats_in_gs + (long long)m * 2);
             }
         }
-        gemm_epilogue<TO, BM, BN, WM, WN, false, TRAIN_EPI>(acc, p, g, m0, n0, tile_n, wm, wn, lane, tid, mean_rstd, smem);
+        gemm_epilogue<TO, BM, BN, WM, WN, false, TRAIN_EPI, XMODE == 1>(acc, p, g, m0, n0, tile_n, wm, wn, lane, tid, mean_rstd, smem);
     } else {
         // ---- persistent: walk the tile list ----------------------------------------------------------------
         // Epilogue parameters of a tile, one element per thread: threads 0..255 the tile's bias / colsum column,
@@ -465,12 +481,14 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         const float* __restrict__ stats_in = (p.flags & TP_LINEAR_LN_FOLD) ? p.stats_in + g * p.stats_in_gs : nullptr;
         // every thread fetches column / row (tid & 255): no divergent control flow around the loads, nothing
         // consumes them before publish_params() — they ride out the epilogue in 4 VGPRs
-        float pf_bias = 0.f, pf_csum = 0.f;
+        const float* __restrict__ acc_init = (XMODE == 2) ? p.acc_init + g * p.acc_init_gs : nullptr;
+        float pf_bias = 0.f, pf_csum = 0.f, pf_init = 0.f;
         float2 pf_mr = make_float2(0.f, 1.f);
         auto prefetch_params = [&]() __attribute__((always_inline)) {
             const int e = tid & 255;
             if (bias) pf_bias = bias[n0 + e];
             if (colsum) pf_csum = colsum[n0 + e];
+            if constexpr (XMODE == 2) pf_init = acc_init[n0 + e];
             if (stats_in) {
                 int m = m0 + e;
                 m = m < p.M ? m : p.M - 1;
@@ -479,7 +497,10 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         };
         auto publish_params = [&]() __attribute__((always_inline)) {
             float* par = (float*)(smem + L_PAR);
-            if (tid < 256) { par[tid] = pf_bias; par[BN + tid] = pf_csum; }
+            if (tid < 256) {
+                par[tid] = pf_bias; par[BN + tid] = pf_csum;
+                if constexpr (XMODE == 2) par[4 * BN + tid] = pf_init;
+            }
             else *(float2*)(par + 2 * BN + 2 * (tid - 256)) = pf_mr;
         };
 
@@ -518,8 +539,8 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
                 const f32x2_t v = *(const f32x2_t*)(smem + L_PAR + 2 * BN * 4 + (wm * WM + i * 16 + (lane & 15)) * 8);
                 mean_rstd[i] = make_float2(v[0], v[1]);
             }
-            gemm_epilogue<TO, BM, BN, WM, WN, true, TRAIN_EPI>(acc, p, g, m0c, n0c, tile_nc, wm, wn, lane, tid, mean_rstd,
-                                                               smem + L_RED, smem + L_PAR);
+            gemm_epilogue<TO, BM, BN, WM, WN, true, TRAIN_EPI, XMODE == 1>(acc, p, g, m0c, n0c, tile_nc, wm, wn, lane, tid,
+                                                                           mean_rstd, smem + L_RED, smem + L_PAR);
             if (!has_next) break;
             L = Ln;
             block_sync_lds();                               // everyone is done with this tile's parameters
@@ -548,10 +569,10 @@ int gemm8_persistent_cus() {
     return (per_xcd < 1 ? 1 : per_xcd) * 8;
 }
 
-template <typename TI, typename TO, int AMODE, bool PERSIST, bool TRAIN_EPI, bool HALF = false>
+template <typename TI, typename TO, int AMODE, bool PERSIST, bool TRAIN_EPI, bool HALF = false, int XMODE = 0>
 static int launch8_cfg(const GemmArgs& a, hipStream_t stream) {
-    auto kern = gemm8_kernel<TI, TO, AMODE, PERSIST, TRAIN_EPI, HALF>;
-    constexpr int lds = HALF ? 9 * G8_GROUP + 4096 + 8192 + 256 : (PERSIST ? G8_LDS : G8_RING);
+    auto kern = gemm8_kernel<TI, TO, AMODE, PERSIST, TRAIN_EPI, HALF, XMODE>;
+    constexpr int lds = HALF ? 9 * G8_GROUP + G8_PAR + 8192 + 256 : (PERSIST ? G8_LDS : G8_RING);
     constexpr int TBM = HALF ? G8_BM / 2 : G8_BM;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
@@ -594,6 +615,19 @@ static int launch8_var(const GemmArgs& a, hipStream_t stream) {
         return TP_ERR_INVALID_ARG;
     }
     const bool half = a.half_tiles != 0;
+    if ((a.flags & TP_LINEAR_NO_STORE) || a.acc_init) {       // the two GEMMs of the fused LayerNorm chain
+        if constexpr (std::is_same<TI, f16_t>::value && std::is_same<TO, f16_t>::value && PERSIST) {
+            if (a.rows_per_batch < a.M || train_epi || ((a.flags & TP_LINEAR_NO_STORE) && a.acc_init) || (half && a.K < 2 * BK)) {
+                set_error("tp gemm8: NO_STORE / acc_init take a contiguous A, no training epilogue, and not both at once");
+                return TP_ERR_INVALID_ARG;
+            }
+            if (a.flags & TP_LINEAR_NO_STORE)
+                return half ? launch8_cfg<TI, TO, 0, PERSIST, false, true, 1>(a, stream) : launch8_cfg<TI, TO, 0, PERSIST, false, false, 1>(a, stream);
+            return half ? launch8_cfg<TI, TO, 0, PERSIST, false, true, 2>(a, stream) : launch8_cfg<TI, TO, 0, PERSIST, false, false, 2>(a, stream);
+        }
+        set_error("tp gemm8: NO_STORE / acc_init are built for fp16 operands and output on the persistent kernel");
+        return TP_ERR_INVALID_ARG;
+    }
     if (half && (!PERSIST || a.K < 2 * BK)) {
         set_error("tp gemm8: half tiles need the persistent kernel and K >= 128");
         return TP_ERR_INVALID_ARG;

@@ -103,7 +103,8 @@ __device__ __forceinline__ void block_sync_lds() {
 
 // TRAIN_EPI compiles in the two training-only epilogue features (TP_LINEAR_SAVE_PRE, TP_LINEAR_GELU_BWD); the
 // inference kernels are instantiated without them so that their register budget is not taxed.
-template <typename TO, int BM, int BN, int WM, int WN, bool LDS_PARAMS = false, bool TRAIN_EPI = false>
+// STATS_ONLY (TP_LINEAR_NO_STORE): the row statistics of the unrounded result are the only output — no conversion, no store.
+template <typename TO, int BM, int BN, int WM, int WN, bool LDS_PARAMS = false, bool TRAIN_EPI = false, bool STATS_ONLY = false>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], const GemmArgs& p, const int g,
                                               const int m0, const int n0, const int tile_n, const int wm,
                                               const int wn, const int lane, const int tid,
@@ -199,6 +200,16 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
                     }
                 }
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                if constexpr (STATS_ONLY) {                             // statistics only: nothing is rounded, nothing stored
+                    if (flags & TP_LINEAR_ROW_STATS) {
+                        if (jj == 0) pivot = v0[0];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float d = v0[r] - pivot; s1 += d; s2 = fmaf(d, d, s2); }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float d = v1[r] - pivot; s1 += d; s2 = fmaf(d, d, s2); }
+                    }
+                    continue;
+                }
                 if constexpr (OUT_F32) {
                     const unsigned coff = (unsigned)(((long long)m * p.ldc + col_base) * 4);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), rsrc_c, (int)(coff + j0 * 64), 0, 0);

@@ -39,6 +39,8 @@ struct GemmArgs {
     const float* bias;
     const float* stats_in;            // LN_FOLD: per-row (mean, rstd) [M][2]
     const float* colsum; float* stats_out;
+    const float* acc_init;            // optional fp32 [N]: initial value of the accumulators per output column (a constant row
+                                      // vector added BEFORE the LayerNorm fold: rstd·(A·W^T + acc_init − mu·colsum) + bias)
     char* C2;                         // SAVE_PRE: pre-activation copy of C (same dtype / ldc), NULL otherwise
     const char* Z;                    // GELU_BWD: fp16 pre-activations [M, ldz] the result is multiplied by gelu'(.)
     long long ldz;                    // elements
@@ -62,7 +64,7 @@ struct GemmArgs {
     const char* W_parts[4];
     int n_part;
     // per-group strides (bytes for A/W/C, floats for the fp32 side arrays)
-    long long a_gs, w_gs, c_gs, bias_gs, stats_in_gs, colsum_gs, stats_out_gs;
+    long long a_gs, w_gs, c_gs, bias_gs, stats_in_gs, colsum_gs, stats_out_gs, acc_init_gs;
     int M, N, K;
     int m_begin, m_end;               // ping-pong kernel: tiles cover rows [m_begin, m_end) (m_end 0: M); row indices, the
                                       // bound M and every per-row array stay those of the whole problem
@@ -105,7 +107,7 @@ int pack_cast_f16_launch(int dtype, const void* src, void* dst_f16, long long n,
 int pack_transpose_f16_launch(const void* src_f16, void* dst_f16, int n, hipStream_t stream);          // [n,n]
 int pack_round_f16_launch(const float* src, void* dst_f16, long long n, hipStream_t stream, int* sat = nullptr);   // saturating
 int pack_bias_fold_launch(const void* w_f16, const float* v, const float* b, float* out, int n_out, int n_in,
-                          hipStream_t stream);                                                          // out = w·v + b
+                          hipStream_t stream);                                             // out = w·v + b  (b may be NULL)
 int pack_ln_fold_launch(int dtype, const void* w, const void* bias, const void* gamma,
                         const void* beta, void* w_out, float* colsum, float* bias_out, int n_out,
                         int n_in, hipStream_t stream, int* sat = nullptr);
@@ -119,6 +121,7 @@ struct PackedLayout {
     size_t w_q1;                  // [1024,1024] f16
     size_t w_in_kv, c_in_kv, b_in_kv;   // LN-folded in-proj for k, v: [2][1024,1024] f16, [2][1024] f32 x2
     size_t w_in_q, c_in_q, b_in_q;      // LN-folded in-proj for q
+    size_t w_c_kv, d_in_kv;       // fused LayerNorm chain: Wc = W'·W2 [2][1024,1024] f16, d = W'·b2 [2][1024] f32
     size_t w_qt;                  // [8][1024][128] f16: per-head transposes of the LN-folded K in-proj (absorbed schedule)
     size_t w_out, b_out;          // [1024,1024] f16, [1024] f32
     size_t w_m0, b_m0;            // [D,1024] f16, [D] f32

@@ -635,7 +635,7 @@ pack_bias_fold_kernel(const f16_t* __restrict__ w, const float* __restrict__ v, 
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) out[n] = red[0] + red[1] + red[2] + red[3] + b[n];
+    if (threadIdx.x == 0) out[n] = red[0] + red[1] + red[2] + red[3] + (b ? b[n] : 0.f);
 }
 
 int pack_bias_fold_launch(const void* w, const float* v, const float* b, float* out, int n_out, int n_in,

@@ -145,7 +145,8 @@ class TokenPacker(nn.Module):
         """(Re)build the kernel-side weight image: always when ``force`` (training forward), otherwise when any
         parameter storage / version, the compute dtype or the pack-time tuning changed."""
         weights = self._named_weights()
-        fold = _capi.get_tuning(_capi.TP_TUNE_FOLD_OUT_PROJ)
+        # pack-time tuning: the folded / pre-multiplied weights exist only if their knob was on when packing
+        fold = (_capi.get_tuning(_capi.TP_TUNE_FOLD_OUT_PROJ), _capi.get_tuning(_capi.TP_TUNE_FUSE_KV_LN))
         key = (dtype, device, fold, tuple((w.data_ptr(), w._version) for w in weights))
         stream = torch.cuda.current_stream(device)
         if not force and self._packed is not None and self._packed_key == key:
