@@ -107,3 +107,21 @@ def assert_close(got, want, name, tol):
     ok = err <= tol and not torch.isnan(got_f).any()
     assert ok, describe_mismatch(got, want, name, tol)
     return err
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def training_schedule_for_inference():
+    """Inference normally runs schedules the training forward cannot (the backward needs H2, K and V): the fused
+    LayerNorm chain (TP_TUNE_FUSE_KV_LN) and, for scale_factor >= 3, the absorbed K/V in-projection
+    (TP_TUNE_ABSORB_KV).  Inside this context inference is told to run the training forward's schedule, which makes the
+    two bit-identical."""
+    _capi.set_tuning(_capi.TP_TUNE_ABSORB_KV, 1)
+    _capi.set_tuning(_capi.TP_TUNE_FUSE_KV_LN, 0)
+    try:
+        yield
+    finally:
+        _capi.set_tuning(_capi.TP_TUNE_ABSORB_KV, 0)
+        _capi.set_tuning(_capi.TP_TUNE_FUSE_KV_LN, 1)

@@ -37,19 +37,14 @@ def test_parts_equal_concatenated(dtype, B, s):
         y.float().square().sum().backward()
         grads.append((y.detach(), [p.grad.clone() for p in m.parameters()]))
     assert torch.equal(grads[0][0], grads[1][0])
-    if s == 2:
-        assert torch.equal(grads[0][0], y_cat)                    # training forward == inference forward, bit for bit
-    else:
-        # scale_factor >= 3: inference runs the absorbed K/V schedule, training the plain one (the backward needs K, V):
-        # the same function up to rounding — and bit-identical once inference is told not to absorb
-        from tokenpacker_amd import _capi
-        assert float((grads[0][0].float() - y_cat.float()).abs().max()) <= 2.0 ** -6 * float(y_cat.float().abs().max())
-        _capi.set_tuning(_capi.TP_TUNE_ABSORB_KV, 1)
-        try:
-            with torch.no_grad():
-                assert torch.equal(m((x, parts)), grads[0][0])
-        finally:
-            _capi.set_tuning(_capi.TP_TUNE_ABSORB_KV, 0)
+    # inference runs the fused LayerNorm chain (and, for scale_factor >= 3, the absorbed K/V schedule); the training forward
+    # cannot (the backward needs H2, K, V): the same function up to rounding — and bit-identical once inference is told to
+    # run the training forward's schedule
+    from tests import gpu_util as gu
+    assert float((grads[0][0].float() - y_cat.float()).abs().max()) <= 2.0 ** -6 * float(y_cat.float().abs().max())
+    with gu.training_schedule_for_inference():
+        with torch.no_grad():
+            assert torch.equal(m((x, parts)), grads[0][0])
     assert all(torch.equal(a, b) for a, b in zip(grads[0][1], grads[1][1]))
 
 

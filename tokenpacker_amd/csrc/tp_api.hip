@@ -61,7 +61,7 @@ PackedLayout packed_layout(int D) {
     L.w_m0 = take((size_t)D * E * 2);    L.b_m0 = take((size_t)D * 4);
     L.w_m2 = take((size_t)D * D * 2);    L.b_m2 = take((size_t)D * 4);
     L.w_om = take((size_t)D * E * 2);    L.b_om = take((size_t)D * 4);
-    L.scratch_t = take(E * E * 2);       L.scratch_p = take((size_t)D * E * 4);
+    L.scratch_t = take(E * E * 2);       L.scratch_p = take((size_t)(D > (int)E ? D : (int)E) * E * 4);   // fp32 [max(D, E), E]
     L.status = take(256);
     L.total = off;
     return L;

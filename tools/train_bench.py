@@ -65,7 +65,10 @@ def main():
         xm = torch.randn(B, 576, 4096, generator=g, device="cuda").to(dtype)
         w = torch.randn(B, (24 // s) ** 2, D, generator=g, device="cuda").to(dtype)
 
-        opt = torch.optim.SGD(m.parameters(), lr=1e-6) if args.optimizer == "sgd" else None
+        import copy
+        m_eager = copy.deepcopy(m)                       # each pipeline trains its own copy of the weights
+        opt = torch.optim.SGD(m.parameters(), lr=1e-7) if args.optimizer == "sgd" else None
+        opt_e = torch.optim.SGD(m_eager.parameters(), lr=1e-7) if args.optimizer == "sgd" else None
 
         def step_hip():
             m.zero_grad(set_to_none=True)
@@ -74,10 +77,10 @@ def main():
                 opt.step()
 
         def step_eager():
-            m.zero_grad(set_to_none=True)
-            (eager_forward(m, x, xm) * w).sum().backward()
-            if opt is not None:
-                opt.step()
+            m_eager.zero_grad(set_to_none=True)
+            (eager_forward(m_eager, x, xm) * w).sum().backward()
+            if opt_e is not None:
+                opt_e.step()
 
         def fwd_hip():
             with torch.no_grad():
@@ -93,8 +96,13 @@ def main():
         if args.hip_only:
             print(json.dumps({"B": B, "hip_fwd_bwd_ms": round(ms_hip, 3), "hip_fwd_only_ms": round(ms_fwd, 3)}), flush=True)
             continue
-        step_eager(); ge = {k: p.grad.float().clone() for k, p in m.named_parameters()}
-        step_hip(); gh = {k: p.grad.float().clone() for k, p in m.named_parameters()}
+        finite = {"hip": all(bool(torch.isfinite(p.float()).all()) for p in m.parameters()),
+                  "eager": all(bool(torch.isfinite(p.float()).all()) for p in m_eager.parameters())}
+        m_eager.load_state_dict(m.state_dict())          # gradient agreement on identical weights
+        step_eager(); ge = {k: p.grad.float().clone() for k, p in m_eager.named_parameters()}
+        m.load_state_dict(m_eager.state_dict()) if False else None
+        m.zero_grad(set_to_none=True); (m((x, xm)) * w).sum().backward()
+        gh = {k: p.grad.float().clone() for k, p in m.named_parameters()}
         for d in (ge, gh):
             d.pop("ln_k_1.bias")
             d["clip_attn.in_proj_bias"] = torch.cat([d["clip_attn.in_proj_bias"][:E], d["clip_attn.in_proj_bias"][2 * E:]])
@@ -105,10 +113,10 @@ def main():
                "optimizer_in_step": args.optimizer,
                "train_tflops_algorithmic": round(flops_train(B, s, D) / ms_hip / 1e9, 1),
                "train_gflop_per_image": round(flops_train(1, s, D) / 1e9, 2),
-               "max_param_grad_rel_l2_vs_eager": agree}
+               "weights_finite_after_training": finite, "max_param_grad_rel_l2_vs_eager": agree}
         print(json.dumps(rec), flush=True)
         results.append(rec)
-        del m, x, xm, w
+        del m, m_eager, x, xm, w
         torch.cuda.empty_cache()
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     json.dump(results, open(args.out, "w"), indent=1)
