@@ -124,8 +124,15 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
  *              buffers (clip_encoder.py:37-38,62); base pointers must be 16-byte aligned and row
  *              strides multiples of 8 elements.
  *   out      [B, M, D] contiguous, element type desc.out_dtype.
- * `attn_mask` of the reference signature is always None on the real path (llava_arch.py:97) and is
- * not part of this ABI. */
+ * `attn_mask` of the reference signature is always None on the real path (llava_arch.py:97): tp_forward is the
+ * mask-less call, tp_forward_masked below honours one.
+ *
+ * Schedules (same function, same parity gates; what differs is which intermediates exist):
+ *   training (tp_forward_train)     : every layer as its own GEMM — the backward needs H2, K and V;
+ *   inference, scale_factor 2       : fused LayerNorm chain (TP_TUNE_FUSE_KV_LN): the K/V second layer is computed for its
+ *                                     LayerNorm statistics only, the in-projection reads Hkv through Wc = W'·W2;
+ *   inference, scale_factor >= 3    : K/V in-projections absorbed into the query side (TP_TUNE_ABSORB_KV, see
+ *                                     tp_region_attention_absorbed). */
 int tp_forward(const tp_desc* desc,
                const void* x, const int64_t x_strides[3],
                const void* x_multi, const int64_t xm_strides[3],
@@ -133,6 +140,18 @@ int tp_forward(const tp_desc* desc,
                void* out,
                void* workspace, size_t workspace_bytes,
                void* stream);
+
+/* tp_forward with the `attn_mask` argument of `TokenPacker.forward(x, attn_mask)` (builder.py:107,130), as
+ * nn.MultiheadAttention applies it: an ADDITIVE fp32 mask on the scaled logits (a boolean mask is the caller's
+ * 0 / -inf).  mask_mode 1: attn_mask [s*s] — the reference's 2-D (L=1, S=s*s) form, shared by every image, region
+ * and head; mask_mode 2: attn_mask [(M*B)*8, s*s] — its 3-D (N*num_heads, L=1, S) form with the reference's batch
+ * index N = region * B + image (divide_feature's order, builder.py:96-105); mask_mode 0: none.  Key index inside a
+ * region: a*s + b for fine token (i*s + a, j*s + b).  Inference only. */
+int tp_forward_masked(const tp_desc* desc,
+                      const void* x, const int64_t x_strides[3],
+                      const void* x_multi, const int64_t xm_strides[3],
+                      const void* packed_weights, void* out, void* workspace, size_t workspace_bytes,
+                      const float* attn_mask, int mask_mode, void* stream);
 
 /* tp_forward with x_multi given as its FOUR [B, g*g, 1024] sources — the CLIP hidden states 12, 16, 22, 23 that
  * `CLIPVisionTower.feature_select` concatenates (clip_encoder.py:28-32) — each with the element strides

@@ -190,13 +190,32 @@ def run_grad_yardstick(ref, name, s, pseed, iseed, D=256, B=1):
     np.savez_compressed(path, **out)
 
 
+def run_mask_case(ref, name="mask_s2_D256_B2", s=2, D=256, B=2, pseed=71, iseed=171):
+    """The reference module called WITH an attn_mask (builder.py:107,130): the 2-D float and the 3-D boolean form."""
+    params = synth.make_params(pseed, D)
+    x, xm = synth.make_inputs(iseed, B)
+    m2, m3 = synth.make_attn_masks(iseed + 1, B, s)
+    mod = _ref_module(ref, params, s, D)
+    with torch.no_grad():
+        out = {"scale_factor": np.int64(s), "hidden_size": np.int64(D), "batch": np.int64(B), "param_seed": np.int64(pseed),
+               "input_seed": np.int64(iseed), "y_none": mod((x, xm)).numpy(), "y_2d_float": mod((x, xm), attn_mask=m2).numpy(),
+               "y_3d_bool": mod((x, xm), attn_mask=m3).numpy(),
+               "inputs_sha256": np.array(synth.tensor_digest(x, xm, m2, m3.float()))}
+    path = os.path.join(OUT_DIR, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: -> {path} ({os.path.getsize(path) / 1e6:.2f} MB); masks change the output by "
+          f"{float(np.abs(out['y_2d_float'] - out['y_none']).max()):.3f} / {float(np.abs(out['y_3d_bool'] - out['y_none']).max()):.3f}")
+
+
 def main():
     if not os.path.exists(REF_FILE):
         sys.exit(f"{REF_FILE} not found: goldens can only be regenerated in the build container")
     os.makedirs(OUT_DIR, exist_ok=True)
     torch.manual_seed(0)
     ref = load_reference()
-    which = sys.argv[1:] or ["cases", "adversarial", "grads"]
+    which = sys.argv[1:] or ["cases", "adversarial", "grads", "mask"]
+    if "mask" in which:
+        run_mask_case(ref)
     if "cases" in which:
         for case in CASES:
             run_case(ref, *case)

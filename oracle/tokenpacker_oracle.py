@@ -118,7 +118,21 @@ def region_gather(t: torch.Tensor, raw_grid: int, s: int) -> torch.Tensor:
     return (t.reshape(B, G, s, G, s, c).permute(0, 1, 3, 2, 4, 5).reshape(B, G, G, s * s, c))
 
 
-def region_attention(q1, k1, v1, in_w, in_b, raw_grid: int, s: int, heads: int = HEADS):
+def mask_to_regions(attn_mask: torch.Tensor, B: int, G: int, s: int, heads: int = HEADS) -> torch.Tensor:
+    """``attn_mask`` as nn.MultiheadAttention takes it from builder.py:126-130 — 2-D ``[1, s*s]`` or 3-D
+    ``[(M*B)*heads, 1, s*s]`` with the batch index ``region * B + image`` that ``divide_feature`` produces
+    (builder.py:96-105); boolean (True = masked out) or additive float — as an additive ``[B, G, G, heads, s*s]``."""
+    m = attn_mask
+    if m.dtype == torch.bool:
+        m = torch.zeros(m.shape, dtype=torch.float64).masked_fill(m, float("-inf"))
+    m = m.to(torch.float64)
+    S2, M = s * s, G * G
+    if m.dim() == 2:
+        return m.reshape(1, 1, 1, 1, S2).expand(B, G, G, heads, S2)
+    return m.reshape(M, B, heads, S2).permute(1, 0, 2, 3).reshape(B, G, G, heads, S2)
+
+
+def region_attention(q1, k1, v1, in_w, in_b, raw_grid: int, s: int, heads: int = HEADS, attn_mask=None):
     """Region-to-point cross attention (builder.py:122-130): every coarse query attends to the
     s*s fine tokens of its own region, 8 heads of d=128, softmax over the s*s keys, scale
     1/sqrt(d) applied to q.  Returns the concatenated heads [B, M, E] BEFORE out_proj."""
@@ -131,6 +145,8 @@ def region_attention(q1, k1, v1, in_w, in_b, raw_grid: int, s: int, heads: int =
     K = region_gather(linear(k1, wk, bk), raw_grid, s).reshape(B, G, G, s * s, heads, d)
     V = region_gather(linear(v1, wv, bv), raw_grid, s).reshape(B, G, G, s * s, heads, d)
     logits = torch.einsum("bijhd,bijkhd->bijhk", Q, K)
+    if attn_mask is not None:
+        logits = logits + mask_to_regions(attn_mask, B, G, s, heads).to(logits.dtype)
     P = torch.softmax(logits, dim=-1)
     O = torch.einsum("bijhk,bijkhd->bijhd", P, V)
     return O.reshape(B, M, E)
@@ -143,7 +159,7 @@ def forward(params: Dict[str, torch.Tensor], x: torch.Tensor, x_multi: torch.Ten
             scale_factor: int = 2, raw_grid: int = 24,
             compute_dtype: torch.dtype = torch.float64,
             io_dtype: Optional[torch.dtype] = None,
-            return_intermediates: bool = False):
+            return_intermediates: bool = False, attn_mask=None):
     """Oracle for ``TokenPacker.forward((x, x_multi))`` (builder.py:107-137).
 
     ``params`` uses the reference's state-dict names.  Inputs/weights are up-cast to
@@ -170,7 +186,7 @@ def forward(params: Dict[str, torch.Tensor], x: torch.Tensor, x_multi: torch.Ten
     q1 = layer_norm(linear(q0, p["q_proj_1.weight"]), p["ln_q_1.weight"], p["ln_q_1.bias"])
     # region-to-point attention (builder.py:122-130) and out_proj
     attn = region_attention(q1, k1, v1, p["clip_attn.in_proj_weight"], p["clip_attn.in_proj_bias"],
-                            raw_grid, s)
+                            raw_grid, s, attn_mask=attn_mask)
     o = linear(attn, p["clip_attn.out_proj.weight"], p["clip_attn.out_proj.bias"])
     # output MLP (builder.py:136)
     y = linear(gelu_erf(linear(o, p["mlp.0.weight"], p["mlp.0.bias"])),

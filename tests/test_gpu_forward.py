@@ -203,8 +203,8 @@ def test_errors_on_gpu_inputs():
         m((x.float(), xm.float()))
     with pytest.raises(ValueError):
         m((x[:, :500], xm[:, :500]))
-    with pytest.raises(NotImplementedError):
-        m((x, xm), attn_mask=torch.zeros(1))
+    with pytest.raises(ValueError):
+        m((x, xm), attn_mask=torch.zeros(1))                    # not a shape nn.MultiheadAttention would accept here
     m.requires_grad_(True)
     with pytest.raises(NotImplementedError):                    # CLIP features come from a frozen tower: no input grads
         m((x.clone().requires_grad_(True), xm))
@@ -311,3 +311,33 @@ def test_fused_layernorm_chain_is_the_same_function(dtype, B):
     m = _module(params, s, D, dtype)
     with torch.no_grad():
         assert torch.equal(m((x.cuda(), xm.cuda()))[:1], m((x[:1].cuda(), xm[:1].cuda())))
+
+
+@pytest.mark.parametrize("s", [2, 3])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_attn_mask_is_honoured(s, dtype):
+    """``forward(x, attn_mask)`` (builder.py:107,130): the 2-D additive and the 3-D boolean form, against the oracle —
+    whose mask semantics are pinned on the real reference module called with a mask (tests/golden/mask_s2_D256_B2.npz) —
+    on the plain (s = 2) and the absorbed (s = 3) schedule."""
+    D, B = 256, 2
+    params = synth.make_params(71, D)
+    x, xm = synth.make_inputs(171, B, dtype)
+    m2, m3 = synth.make_attn_masks(172, B, s)
+    m = _module(params, s, D, dtype)
+    m.output_fp32 = True
+    p_lp = {k: v.to(dtype) for k, v in params.items()}
+    with torch.no_grad():
+        y0 = m((x.cuda(), xm.cuda()))
+        for mask in (m2, m3, m3.cuda(), m2.to(dtype)):
+            y = m((x.cuda(), xm.cuda()), attn_mask=mask)
+            y_exact = orc.forward(p_lp, x, xm, scale_factor=s, compute_dtype=torch.float64, io_dtype=dtype,
+                                  attn_mask=mask.cpu().float() if mask.dtype != torch.bool else mask.cpu())
+            e = orc.rel_err(y, y_exact)
+            assert e <= 1.2e-3, (tuple(mask.shape), mask.dtype, e)
+            assert float((y - y0).abs().max()) > 0.05          # the mask changes the result
+    if s == 2:
+        z = np.load(os.path.join(os.path.dirname(__file__), "golden", "mask_s2_D256_B2.npz"))
+        for key, mask in (("y_2d_float", m2), ("y_3d_bool", m3)):
+            with torch.no_grad():
+                y = m((x.cuda(), xm.cuda()), attn_mask=mask)
+            assert orc.rel_err(y, torch.from_numpy(z[key])) < (3e-2 if dtype == torch.bfloat16 else 4e-3), key   # vs the REAL reference

@@ -96,3 +96,19 @@ def test_bad_scale_factor_raises():
     x, xm = synth.make_inputs(1, 1)
     with pytest.raises(ValueError):
         orc.forward(params, x, xm, scale_factor=5)
+
+
+def test_oracle_attn_mask_matches_the_reference_module():
+    """attn_mask semantics (2-D additive float, 3-D boolean with the reference's region*B+image batch index) pinned on
+    outputs of the REAL reference module called with a mask (oracle/make_golden.py ``mask``)."""
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "mask_s2_D256_B2.npz"))
+    s, D, B = int(z["scale_factor"]), int(z["hidden_size"]), int(z["batch"])
+    params = synth.make_params(int(z["param_seed"]), D)
+    x, xm = synth.make_inputs(int(z["input_seed"]), B)
+    m2, m3 = synth.make_attn_masks(int(z["input_seed"]) + 1, B, s)
+    assert synth.tensor_digest(x, xm, m2, m3.float()) == str(z["inputs_sha256"])
+    for key, mask in (("y_none", None), ("y_2d_float", m2), ("y_3d_bool", m3)):
+        y = orc.forward(params, x, xm, scale_factor=s, compute_dtype=torch.float64, attn_mask=mask)
+        assert orc.rel_err(y, torch.from_numpy(z[key])) < 2e-5, key
+    assert float(np.abs(z["y_3d_bool"] - z["y_none"]).max()) > 0.05        # the masks really change the result

@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = (
     "tp_train_workspace_bytes", "tp_backward_workspace_bytes", "tp_forward_train", "tp_backward",
     "tp_forward_parts", "tp_forward_train_parts", "tp_backward_parts", "tp_test_occupy_cus", "tp_hd_slice",
     "tp_wgrad", "tp_wgrad_workspace_bytes", "tp_packed_status_offset", "tp_debug_count_saturated",
-    "tp_region_attention_absorbed",
+    "tp_region_attention_absorbed", "tp_forward_masked",
 )
 
 # state-dict name -> tp_weights field order (include/tokenpacker.h)
@@ -125,6 +125,9 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.tp_forward.restype = c_int
     lib.tp_forward.argtypes = [POINTER(tp_desc), c_void_p, POINTER(c_int64), c_void_p, POINTER(c_int64),
                                c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.tp_forward_masked.restype = c_int
+    lib.tp_forward_masked.argtypes = [POINTER(tp_desc), c_void_p, POINTER(c_int64), c_void_p, POINTER(c_int64),
+                                      c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_void_p]
     lib.tp_forward_staged.restype = c_int
     lib.tp_forward_staged.argtypes = lib.tp_forward.argtypes + [POINTER(c_void_p), c_int]
     lib.tp_point_queries.restype = c_int

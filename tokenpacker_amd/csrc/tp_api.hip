@@ -478,7 +478,7 @@ static SideCtx* side_ctx_for(hipStream_t main) {
 int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3], const void* x_multi,
                  const int64_t xm_strides[3], const void* packed_weights, void* out, void* workspace,
                  size_t workspace_bytes, void* stream_, void* const* stage_events, bool train,
-                 const void* const* xm_parts) {
+                 const void* const* xm_parts, const float* attn_mask, int mask_mode) {
     TP_TRY(validate_desc(desc));
     TP_TRY(check_strides("x", x, x_strides));
     if (xm_parts) {                                     // x_multi given as the four [B, N, 1024] hidden-state slices
@@ -496,6 +496,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         const long long bc = max_images_per_launch(desc);
         if (bc < 1) { set_error("tp_forward: a single image exceeds the 4 GiB a GEMM launch can address"); return TP_ERR_INVALID_ARG; }
         if (desc->batch > bc) {
+            if (mask_mode == 2) { set_error("tp_forward: a per-head attn_mask needs the batch in one launch (%d > %lld images)", desc->batch, bc); return TP_ERR_INVALID_ARG; }
             if (train || stage_events) {
                 set_error("tp_forward: batch %d exceeds %lld images per call for the training / staged entry points", desc->batch, bc);
                 return TP_ERR_INVALID_ARG;
@@ -509,7 +510,9 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
                 TP_TRY(forward_impl(&d, (const char*)x + b0 * x_strides[0] * x_esz, x_strides,
                                     xm_parts ? nullptr : (const char*)x_multi + b0 * xm_strides[0] * x_esz, xm_strides, packed_weights,
                                     (char*)out + b0 * m_tok * desc->hidden_size * out_esz, workspace, workspace_bytes, stream_,
-                                    nullptr, false, xm_parts ? parts : nullptr));
+                                    nullptr, false, xm_parts ? parts : nullptr,
+                                    // (a per-(region, image, head) mask is laid out for the WHOLE batch: it cannot be chunked)
+                                    attn_mask, mask_mode));
             }
             return TP_OK;
         }
@@ -646,14 +649,14 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     // 7. region-to-point attention
     if (absorb) {
         TP_TRY(region_attention_absorbed_launch(qt, ws + W.h2, ws + W.h2 + kvE * 2, (const float*)(ws + W.mr_kv),
-                                                (const float*)(ws + W.mr_kv) + (size_t)rows_kv * 2, uu, B, g, s, stream));
+                                                (const float*)(ws + W.mr_kv) + (size_t)rows_kv * 2, uu, B, g, s, stream, attn_mask, mask_mode));
         // O[:, h*128:(h+1)*128] = u[:, h, :] · W'v[h*128:(h+1)*128, :]^T + b'v   (eight N = 128 groups)
         GemmArgs a = plain_gemm(uu, 8 * E, pw + P.w_in_kv + (size_t)E * E * 2, ws + W.o, E, rows_q, kHeadDim, E,
                                 (const float*)(pw + P.b_in_kv) + E, 0);
         a.groups = kHeads; a.a_gs = E * 2; a.w_gs = (long long)kHeadDim * E * 2; a.c_gs = kHeadDim * 2; a.bias_gs = kHeadDim;
         TP_TRY(launch(TP_F16, TP_F16, a, stream));
     } else
-    TP_TRY(region_attention_launch(ws + W.q, ws + W.kv, ws + W.kv + kvE * 2, ws + W.o, B, g, s, stream));
+    TP_TRY(region_attention_launch(ws + W.q, ws + W.kv, ws + W.kv + kvE * 2, ws + W.o, B, g, s, stream, attn_mask, mask_mode));
     TP_TRY(mark());
     // 8. out_proj — optionally folded into mlp[0] at pack time (TP_TUNE_FOLD_OUT_PROJ, default OFF): -2 % time, same
     //    rel-L2 error, but the max-error metric of one golden case moved from 0.92e-3 to 1.09e-3 (gate 1e-3)
@@ -689,6 +692,14 @@ int tp_forward(const tp_desc* desc, const void* x, const int64_t x_strides[3], c
                size_t workspace_bytes, void* stream) {
     return forward_impl(desc, x, x_strides, x_multi, xm_strides, packed_weights, out, workspace, workspace_bytes,
                         stream, nullptr, false);
+}
+
+int tp_forward_masked(const tp_desc* desc, const void* x, const int64_t x_strides[3], const void* x_multi,
+                      const int64_t xm_strides[3], const void* packed_weights, void* out, void* workspace,
+                      size_t workspace_bytes, const float* attn_mask, int mask_mode, void* stream) {
+    if ((mask_mode != 0 && !attn_mask) || mask_mode < 0 || mask_mode > 2) { set_error("tp_forward_masked: bad mask / mask_mode"); return TP_ERR_INVALID_ARG; }
+    return forward_impl(desc, x, x_strides, x_multi, xm_strides, packed_weights, out, workspace, workspace_bytes,
+                        stream, nullptr, false, nullptr, mask_mode ? attn_mask : nullptr, mask_mode);
 }
 
 int tp_forward_parts(const tp_desc* desc, const void* x, const int64_t x_strides[3], const void* const xm_parts[4],

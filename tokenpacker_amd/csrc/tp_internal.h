@@ -86,12 +86,13 @@ inline int gemm_stats_parts(int N) { return N / 128; }   // one (sum, sumsq) sla
 // element type of the caller's tensors (x, weights), outputs are fp16.
 int point_queries_launch(int dtype, const void* x, const int64_t st[3], void* q0_f16, int B, int grid,
                          int s, hipStream_t stream);
+// mask (optional, fp32): additive attn_mask — mask_mode 1: [s*s], 2: [(M B) 8, s*s] (batch index = region * B + image)
 int region_attention_launch(const void* q, const void* k, const void* v, void* o, int B,
-                            int grid, int s, hipStream_t stream);      // fp16 in / fp16 out
+                            int grid, int s, hipStream_t stream, const float* mask = nullptr, int mask_mode = 0);      // fp16 in / fp16 out
 // K/V in-projections absorbed into the query side (tp_kernels.hip): qt [B*M, 8, 1024], H2 k / v [B*N, 1024] fp16 with
 // their per-row (mean, rstd) -> u [B*M, 8, 1024] fp16
 int region_attention_absorbed_launch(const void* qt, const void* h2k, const void* h2v, const float* mr_k, const float* mr_v,
-                                     void* u, int B, int grid, int s, hipStream_t stream);
+                                     void* u, int B, int grid, int s, hipStream_t stream, const float* mask = nullptr, int mask_mode = 0);
 int pack_head_transpose_launch(const void* w_f16, void* dst_f16, hipStream_t stream);    // [8*128, 1024] -> [8][1024][128]
 bool absorb_kv(const tp_desc* desc, bool train);          // whether tp_forward runs the absorbed schedule for desc
 int hd_slice_launch(const float* img, int H, int W, int h_block, int w_block, int h_res, int w_res, int hg, int wg,
@@ -182,6 +183,6 @@ long long max_images_per_launch(const tp_desc* desc);
 int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3], const void* x_multi,
                  const int64_t xm_strides[3], const void* packed_weights, void* out, void* workspace,
                  size_t workspace_bytes, void* stream_, void* const* stage_events, bool train,
-                 const void* const* xm_parts = nullptr);
+                 const void* const* xm_parts = nullptr, const float* attn_mask = nullptr, int mask_mode = 0);
 
 }  // namespace tp

@@ -89,7 +89,7 @@ int point_queries_launch(int dtype, const void* x, const int64_t st[3], void* q0
 template <typename T>
 __global__ void __launch_bounds__(256)
 region_attention_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
-                        T* __restrict__ o, int B, int g, int s, float scale) {
+                        T* __restrict__ o, int B, int g, int s, float scale, const float* __restrict__ mask, int mask_mode) {
     constexpr int E = kEmbed;
     const int lane = threadIdx.x & 63;
     const int G = g / s, M = G * G, N = g * g, S2 = s * s;
@@ -107,6 +107,15 @@ region_attention_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
 
     const T* kb = k + (long long)b * N * E;
     const T* vb = v + (long long)b * N * E;
+    // additive attn_mask of nn.MultiheadAttention (builder.py:107,130): [S2] for every (image, region, head), or
+    // [(M B) 8, S2] with the reference's batch index (region m) * B + image b  (divide_feature's order, builder.py:96-105)
+    const float* mrow_a = nullptr; const float* mrow_b = nullptr;
+    if (mask_mode == 1) { mrow_a = mask; mrow_b = mask; }
+    else if (mask_mode == 2) {
+        const long long bi = (long long)m * B + b;
+        mrow_a = mask + (bi * kHeads + (lane >> 4)) * S2;
+        mrow_b = mask + (bi * kHeads + 4 + (lane >> 4)) * S2;
+    }
 
     float run_max_a = -INFINITY, run_max_b = -INFINITY, den_a = 0.f, den_b = 0.f;
     float acc_a[8], acc_b[8];
@@ -139,6 +148,11 @@ region_attention_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
                 lb[u] += __shfl_xor(lb[u], off);
             }
         }
+        if (mrow_a) {
+#pragma unroll
+            for (int u = 0; u < KU; ++u)
+                if (k0 + u < S2) { la[u] += mrow_a[k0 + u]; lb[u] += mrow_b[k0 + u]; }
+        }
         float gmax_a = run_max_a, gmax_b = run_max_b;
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
@@ -170,13 +184,13 @@ region_attention_kernel(const T* __restrict__ q, const T* __restrict__ k, const 
 }
 
 int region_attention_launch(const void* q, const void* k, const void* v, void* o, int B,
-                            int grid, int s, hipStream_t stream) {
+                            int grid, int s, hipStream_t stream, const float* mask, int mask_mode) {
     const int G = grid / s, M = G * G;
     const long long nq = (long long)B * M;
     const unsigned blocks = (unsigned)((nq + 3) / 4);
     const float scale = 0.08838834764831845f;   // 1/sqrt(128): q scaling of F.multi_head_attention_forward
     hipLaunchKernelGGL(region_attention_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream,
-                       (const f16_t*)q, (const f16_t*)k, (const f16_t*)v, (f16_t*)o, B, grid, s, scale);
+                       (const f16_t*)q, (const f16_t*)k, (const f16_t*)v, (f16_t*)o, B, grid, s, scale, mask, mask_mode);
     return check_launch("region_attention_kernel");
 }
 
@@ -206,7 +220,7 @@ constexpr int kAbsorbMaxKeys = 64;          // s*s <= 64 (s <= 8): logits of a r
 __global__ void __launch_bounds__(256)
 region_attention_absorbed_kernel(const f16_t* __restrict__ qt, const f16_t* __restrict__ h2k, const f16_t* __restrict__ h2v,
                                  const float* __restrict__ mr_k, const float* __restrict__ mr_v, f16_t* __restrict__ u,
-                                 int B, int g, int s, float scale) {
+                                 int B, int g, int s, float scale, const float* __restrict__ mask, int mask_mode) {
     constexpr int E = kEmbed, H = kHeads;
     __shared__ float logit_lds[4][kAbsorbMaxKeys * H];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -276,7 +290,13 @@ region_attention_absorbed_kernel(const f16_t* __restrict__ qt, const f16_t* __re
                 y = keep + __shfl_xor(send, 8);
             }
             y += __shfl_xor(y, 4); y += __shfl_xor(y, 2); y += __shfl_xor(y, 1);
-            if ((lane & 7) == 0) lg[t * H + ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1)] = y * scale;
+            if ((lane & 7) == 0) {
+                const int hsel = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+                float lgt = y * scale;
+                if (mask_mode == 1) lgt += mask[t];                                       // attn_mask, see region_attention_kernel
+                else if (mask_mode == 2) lgt += mask[(((long long)m * B + b) * H + hsel) * S2 + t];
+                lg[t * H + hsel] = lgt;
+            }
         }
     }
     // ---- softmax over the region's keys, one lane per head (LDS traffic of ONE wave is ordered; the asm keeps hipcc
@@ -318,13 +338,13 @@ region_attention_absorbed_kernel(const f16_t* __restrict__ qt, const f16_t* __re
 }
 
 int region_attention_absorbed_launch(const void* qt, const void* h2k, const void* h2v, const float* mr_k, const float* mr_v,
-                                     void* u, int B, int grid, int s, hipStream_t stream) {
+                                     void* u, int B, int grid, int s, hipStream_t stream, const float* mask, int mask_mode) {
     if (s * s > kAbsorbMaxKeys) { set_error("absorbed region attention: s*s = %d keys > %d", s * s, kAbsorbMaxKeys); return TP_ERR_INVALID_ARG; }
     const int G = grid / s, M = G * G;
     const long long nq = (long long)B * M;
     const unsigned blocks = (unsigned)((nq + 3) / 4);
     hipLaunchKernelGGL(region_attention_absorbed_kernel, dim3(blocks), dim3(256), 0, stream, (const f16_t*)qt, (const f16_t*)h2k,
-                       (const f16_t*)h2v, mr_k, mr_v, (f16_t*)u, B, grid, s, 0.08838834764831845f);
+                       (const f16_t*)h2v, mr_k, mr_v, (f16_t*)u, B, grid, s, 0.08838834764831845f, mask, mask_mode);
     return check_launch("region_attention_absorbed_kernel");
 }
 

@@ -207,8 +207,6 @@ class TokenPacker(nn.Module):
         return torch.empty(0, dtype=dt, device=x.device), (self.num_queries, self.hidden_size)
 
     def forward(self, x, attn_mask=None, _stage_events=None, _out=None):
-        if attn_mask is not None:
-            raise NotImplementedError("attn_mask is always None on the reference path (llava_arch.py:97)")
         x_multi = x[1]      # multi-level [B, N, 4096] — or its four [B, N, 1024] sources (tokenpacker_amd.tower)
         x = x[0]            # single-level [B, N, 1024]
         parts = None
@@ -244,6 +242,9 @@ class TokenPacker(nn.Module):
             raise NotImplementedError(
                 "the HIP projector does not differentiate with respect to the CLIP features (the reference's tower is "
                 "frozen and runs under no_grad, clip_encoder.py:46); detach them")
+        mask = self._attn_mask_operand(attn_mask, x.shape[0], x.device) if attn_mask is not None else None
+        if mask is not None and (parts or _stage_events is not None):
+            raise NotImplementedError("attn_mask takes the concatenated x_multi and no staged timing")
         if x.shape[0] == 0:                  # empty batch: the reference returns an empty [0, M, D] tensor
             out_dtype = torch.float32 if self.output_fp32 else x.dtype
             y = x.new_zeros((0, self.num_queries, self.hidden_size), dtype=out_dtype) if _out is None else _out
@@ -266,17 +267,37 @@ class TokenPacker(nn.Module):
         else:
             x_multi = self._addressable(x_multi)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            if _stage_events is not None or self.output_fp32 or fp32_caller or _out is not None:
-                raise NotImplementedError("staged timing / fp32 output / fp32_compute_dtype / _out are inference-only")
+            if _stage_events is not None or self.output_fp32 or fp32_caller or _out is not None or mask is not None:
+                raise NotImplementedError("staged timing / fp32 output / fp32_compute_dtype / _out / attn_mask are inference-only")
             if not all(p.requires_grad for p in self.parameters()):
                 raise NotImplementedError("training needs requires_grad on ALL projector parameters "
                                           "(the reference trains the whole projector, train.py:952-958)")
             xm = x_multi if parts else (x_multi,)
             return _ProjectFn.apply(self, x, len(xm), *xm, *self._named_weights())
-        return self._launch_forward(x, x_multi, train=False, _stage_events=_stage_events, fp32_out=fp32_caller, out=_out)[0]
+        return self._launch_forward(x, x_multi, train=False, _stage_events=_stage_events, fp32_out=fp32_caller, out=_out,
+                                    mask=mask)[0]
+
+    def _attn_mask_operand(self, attn_mask: torch.Tensor, B: int, device):
+        """``attn_mask`` as ``nn.MultiheadAttention`` receives it from the reference's forward (builder.py:107,130): 2-D
+        ``[1, s*s]`` or 3-D ``[(M*B)*num_heads, 1, s*s]`` (batch index = region * B + image, divide_feature's order),
+        boolean (True = masked out) or additive float -> ``(fp32 additive tensor on the device, mask_mode)``."""
+        S2 = self.scale_factor ** 2
+        m = attn_mask
+        if m.dim() == 2 and tuple(m.shape) == (1, S2):
+            mode = 1
+        elif m.dim() == 3 and tuple(m.shape) == (self.num_queries * B * self.num_heads, 1, S2):
+            mode = 2
+        else:
+            raise ValueError(f"attn_mask must be [1, {S2}] or [{self.num_queries} * B * {self.num_heads}, 1, {S2}] "
+                             f"(nn.MultiheadAttention with L = 1, S = {S2}); got {tuple(m.shape)}")
+        if m.dtype == torch.bool:
+            m = torch.zeros(m.shape, dtype=torch.float32, device=m.device).masked_fill(m, float("-inf"))
+        elif not m.dtype.is_floating_point:
+            raise TypeError("attn_mask must be boolean or floating point")
+        return m.to(device=device, dtype=torch.float32).contiguous(), mode
 
     # ------------------------------------------------------------------------------------------
-    def _launch_forward(self, x, x_multi, train: bool, _stage_events=None, fp32_out: bool = False, out=None):
+    def _launch_forward(self, x, x_multi, train: bool, _stage_events=None, fp32_out: bool = False, out=None, mask=None):
         B, device = x.shape[0], x.device
         parts = x_multi if isinstance(x_multi, tuple) else None
         if parts:
@@ -322,6 +343,11 @@ class TokenPacker(nn.Module):
                 _capi.check(lib.tp_forward_parts(ctypes.byref(desc), x.data_ptr(), _capi.strides3(x.stride()),
                                                  part_ptrs, part_strides, packed.data_ptr(), out.data_ptr(),
                                                  ws.data_ptr(), ws.numel(), stream_ptr), "tp_forward_parts")
+            elif mask is not None:
+                _capi.check(lib.tp_forward_masked(ctypes.byref(desc), x.data_ptr(), _capi.strides3(x.stride()),
+                                                  x_multi.data_ptr(), _capi.strides3(x_multi.stride()), packed.data_ptr(),
+                                                  out.data_ptr(), ws.data_ptr(), ws.numel(), mask[0].data_ptr(), mask[1],
+                                                  stream_ptr), "tp_forward_masked")
             elif _stage_events is None:
                 _capi.check(lib.tp_forward(ctypes.byref(desc),
                                            x.data_ptr(), _capi.strides3(x.stride()),

@@ -174,3 +174,15 @@ def grad_errors(got: dict, want: dict) -> dict:
         scale = max(rms[k], 0.1 * max(rms[j] for j in want if want[j].shape == w.shape))
         out[k] = float((got[k].double() - w.double()).norm()) / w.numel() ** 0.5 / (scale + 1e-300)
     return out
+
+
+def make_attn_masks(seed: int, B: int, s: int, raw_grid: int = RAW_GRID):
+    """Two attn_mask arguments for ``TokenPacker.forward(x, attn_mask)`` in the forms nn.MultiheadAttention accepts:
+    a 2-D additive float mask ``[1, s*s]`` and a 3-D boolean mask ``[(M*B)*8, 1, s*s]`` (True = masked out; at least
+    one key of every row stays visible)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    S2, M = s * s, (raw_grid // s) ** 2
+    m2 = 2.0 * torch.randn(1, S2, generator=g)
+    m3 = torch.rand(M * B * N_HEADS, 1, S2, generator=g) < 0.35
+    m3[:, 0, 0] = False
+    return m2, m3

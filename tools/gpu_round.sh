@@ -78,6 +78,23 @@ if has prof; then
   F=$(find $OUT/rocprof -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && head -16 "$F"
   find $OUT/rocprof -name "*kernel_trace.csv" -size +20M -delete
 fi
+if has prof3; then
+  echo "== rocprof kernel trace, scale_factor 3 (absorbed K/V schedule) =="
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/rocprof_s3 -o bench -- python $R/bench.py --scale-factor 3 --steps 10 --warmup 3 --no-cpu-baseline > $R/$OUT/rocprof_bench_s3.log 2>&1 ); echo "rocprof exit $?"
+  F=$(find $OUT/rocprof_s3 -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && head -16 "$F" | cut -c1-220
+  find $OUT/rocprof_s3 -name "*kernel_trace.csv" -size +20M -delete
+  for C in "FETCH_SIZE" "WRITE_SIZE"; do
+    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/pmc3_$C -o pmc -- python $R/bench.py --scale-factor 3 --steps 3 --warmup 2 --no-cpu-baseline > $R/$OUT/pmc3_$C.log 2>&1 ); echo "pmc3 $C exit $?"
+  done
+  mkdir -p $OUT/s3 && for C in FETCH_SIZE WRITE_SIZE; do mv $OUT/pmc3_$C $OUT/s3/pmc_$C; done
+  python tools/pmc_summary.py $OUT/s3 > $OUT/pmc_summary_s3.json 2> $OUT/pmc_summary.err; python - "$OUT/pmc_summary_s3.json" <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1]))
+for k,v in d.items():
+    if "attention" in k: print(k, {x: v.get(x) for x in ("dispatches","duration_ns","hbm_read_bytes_corrected","hbm_write_bytes_uncalibrated")})
+PY
+  find $OUT -name "*kernel_trace.csv" -size +20M -delete
+fi
 if has pmc; then
   echo "== rocprof PMC passes (own runs, kernel-trace only) =="
   for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
@@ -85,6 +102,7 @@ if has pmc; then
     ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/pmc_$N -o pmc -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $R/$OUT/pmc_$N.log 2>&1 ); echo "pmc $N exit $?"
   done
   python tools/pmc_summary.py $OUT > $OUT/pmc_summary.json 2> $OUT/pmc_summary.err; cat $OUT/pmc_summary.json | head -60; tail -3 $OUT/pmc_summary.err
+  python tools/make_traffic.py $OUT/pmc_summary.json $TAG && cp profiles/traffic.json $OUT/traffic.json
   find $OUT -name "*kernel_trace.csv" -size +20M -delete
 fi
 if has gemmpmc; then
