@@ -42,7 +42,7 @@ def main(root: str) -> None:
                                                   "Workgroup_Size", "Grid_Size")}
     out = {}
     for k, counters in sorted(acc.items()):
-        if not (k.startswith("tp::") or "gemm" in k or (ALL and "Cijk" in k)):
+        if not (k.startswith("tp::") or k.startswith("_ZN2tp") or "gemm" in k or (ALL and "Cijk" in k)):
             continue
         rec = {"dispatches": max(len(v) for v in counters.values()), **{m: meta[k][m] for m in meta.get(k, {})}}
         for c, vals in counters.items():
