@@ -166,3 +166,28 @@ def test_gradients_against_the_reference_modules_own_low_precision_error(path, d
           f"largest ratio ours/reference {errs[worst] / ref_own[worst]:.2f} ({worst})")
     for k in names:
         assert errs[k] <= 1.5 * ref_own[k] + 1e-4, (k, errs[k], ref_own[k])
+
+
+def test_partially_frozen_projector_trains():
+    """a projector with some parameters frozen (the reference toggles requires_grad per parameter,
+    llava_arch.py:75-76, train.py:952-958) used to be refused.  Frozen parameters get no .grad, the others the same
+    gradients as in the fully trainable module."""
+    dtype, s, D, B = torch.bfloat16, 2, 256, 2
+    params = synth.make_params(17, D)
+    x, xm = synth.make_inputs(18, B, dtype)
+
+    def run(freeze):
+        m = TokenPacker(hidden_size=D, scale_factor=s)
+        m.load_state_dict(params)
+        m = m.to(device="cuda", dtype=dtype).train()
+        for n, p in m.named_parameters():
+            if n.startswith(freeze):
+                p.requires_grad = False
+        m((x.cuda(), xm.cuda())).float().square().sum().backward()
+        return {n: (p.grad.clone() if p.grad is not None else None) for n, p in m.named_parameters()}
+    full, part = run(("~none~",)), run(("k_proj_1", "v_proj_1", "ln_k_1"))
+    for n in full:
+        if n.startswith(("k_proj_1", "v_proj_1", "ln_k_1")):
+            assert part[n] is None, n
+        else:
+            assert torch.equal(part[n], full[n]), n

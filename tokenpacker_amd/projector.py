@@ -269,9 +269,8 @@ class TokenPacker(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             if _stage_events is not None or self.output_fp32 or fp32_caller or _out is not None or mask is not None:
                 raise NotImplementedError("staged timing / fp32 output / fp32_compute_dtype / _out / attn_mask are inference-only")
-            if not all(p.requires_grad for p in self.parameters()):
-                raise NotImplementedError("training needs requires_grad on ALL projector parameters "
-                                          "(the reference trains the whole projector, train.py:952-958)")
+            # (partially frozen projectors — e.g. LoRA-style experiments freezing the K/V branches — go through the same
+            # node: tp_backward computes every gradient, autograd drops those of parameters that do not require one)
             xm = x_multi if parts else (x_multi,)
             return _ProjectFn.apply(self, x, len(xm), *xm, *self._named_weights())
         return self._launch_forward(x, x_multi, train=False, _stage_events=_stage_events, fp32_out=fp32_caller, out=_out,
