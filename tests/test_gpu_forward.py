@@ -341,3 +341,28 @@ def test_attn_mask_is_honoured(s, dtype):
             with torch.no_grad():
                 y = m((x.cuda(), xm.cuda()), attn_mask=mask)
             assert orc.rel_err(y, torch.from_numpy(z[key])) < (3e-2 if dtype == torch.bfloat16 else 4e-3), key   # vs the REAL reference
+
+
+@pytest.mark.parametrize("grid,s", [(24, 1), (24, 6), (24, 8), (24, 12), (24, 24), (16, 4), (12, 3), (8, 2)])
+def test_whole_path_other_scale_factors_and_grids(grid, s):
+    """Every scale factor dividing the grid, on every schedule: s = 1, 2 plain (fused LayerNorm chain), s = 3 … 8 absorbed
+    (s*s <= 64 keys per region live in LDS), s = 12, 24 plain again (144 / 576 keys: online softmax); other raw grids."""
+    dtype, D, B = torch.float16, 256, 2
+    params = synth.make_params(200 + s, D)
+    g = torch.Generator().manual_seed(300 + grid + s)
+    x = torch.randn(B, grid * grid, 1024, generator=g).to(dtype)
+    xm = torch.randn(B, grid * grid, 4096, generator=g).to(dtype)
+    m = TokenPacker(raw_grid=grid, hidden_size=D, scale_factor=s)
+    m.load_state_dict(params)
+    m = m.to(device="cuda", dtype=dtype).eval().requires_grad_(False)
+    m.output_fp32 = True
+    with torch.no_grad():
+        y = m((x.cuda(), xm.cuda()))
+    torch.cuda.synchronize()
+    p_lp = {k: v.to(dtype) for k, v in params.items()}
+    y_exact = orc.forward(p_lp, x, xm, scale_factor=s, raw_grid=grid, compute_dtype=torch.float64, io_dtype=dtype)
+    assert y.shape == (B, (grid // s) ** 2, D)
+    e = orc.rel_err(y, y_exact)
+    print(f"\n[parity] grid={grid} s={s}: rel_err {e:.3e}")
+    assert e <= 1.2e-3, e
+    assert sum(m.saturation_report().values()) == 0
