@@ -236,7 +236,10 @@ region_attention_absorbed_kernel(const f16_t* __restrict__ qt, const f16_t* __re
         return (long long)b * N + (long long)((i * s + a) * g + j * s + c);
     };
     // Rows are fetched ONE KEY AHEAD (packed, 8 VGPRs + the row's statistics) so that two rows per wave are in flight:
-    // at 2 waves / SIMD (the 128 fp32 accumulators of phase B) a CU would otherwise keep 16 KiB outstanding.
+    // at 2 waves / SIMD (the 128 fp32 accumulators of phase B) a CU would otherwise keep 16 KiB outstanding (3.9 -> 4.65
+    // TB/s).  Measured and NOT kept (r02g, same box): two keys ahead = the same; both phases as two passes of four heads
+    // (133 VGPRs -> 3 waves / SIMD, or 128 with 24 B of scratch -> 4) = 11 % SLOWER — the rows of the second pass cost
+    // more out of L2 than the extra waves hide.
     struct Row { f16x8 a, b; float2 st; };
     auto fetch = [&](const f16_t* __restrict__ base, const float* __restrict__ mr, int t) -> Row {
         const long long row = token_row(t < S2 ? t : S2 - 1);
