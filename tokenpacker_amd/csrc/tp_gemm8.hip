@@ -153,8 +153,15 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         }
     };
     auto setup_tile = [&](const int Lt) __attribute__((always_inline)) {
-        const int tm = Lt / tiles_n;
+        int tm = Lt / tiles_n;
         tile_n = Lt - tm * tiles_n;
+        if (xcd_swizzle == 2 && tiles_n == 8) {
+            // A/B (TP_TUNE_XCD_SWIZZLE = 2): blocks of 8 row-panels x 8 N-tiles walked as two halves of 8 x 4, so that the 32
+            // tiles an XCD has resident share HALF of W (4.2 MB ~ its L2) instead of all of it — W re-reads halve, A panels
+            // are fetched twice.  Total fabric traffic is the same to first order; measured: see profiles/.
+            const int blk = Lt >> 6, i = Lt & 63, half = i >> 5, j = i & 31;
+            if ((blk << 3) + 8 <= tiles_m) { tm = (blk << 3) + (j >> 2); tile_n = (half << 2) + (j & 3); }
+        }
         m0 = p.m_begin + tm * BM; n0 = tile_n * BN;
         // K-major operands: per-lane source offsets of DMA instruction idx = 2 wave + q of a group — k rows 4 idx ..
         // 4 idx + 3, chunk slot lane / 8 holds column block (lane / 8) ^ (wave & 1), row (lane % 8) / 2, half lane % 2
