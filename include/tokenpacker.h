@@ -367,7 +367,7 @@ int tp_test_occupy_cus(int workgroups, int microseconds, void* scratch_int, void
  * is reentrant (state is per call, per thread (error string) or per caller stream (the forked query-side stream; at
  * most 64 distinct caller streams per device get one, later ones run the query side on the caller's stream)). */
 enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all half tiles by CU rounds) | 128 | 256 */
-       TP_TUNE_XCD_SWIZZLE = 1, /* 1 (default) | 0                                                 */
+       TP_TUNE_XCD_SWIZZLE = 1, /* 1 (default) | 0 | 2 = A/B: W-half-resident blocking of an XCD's tiles (measured null) */
        TP_TUNE_GEMM_KERNEL = 2, /* 256-tile main loop: 0 persistent ping-pong (default; tile shape by round count)
                                    | 1 two-phase | 2 ping-pong, one tile per workgroup
                                    | 3 persistent ping-pong, every tile a 128x256 half tile            */
