@@ -82,3 +82,31 @@ def test_splice_oracle_matches_the_unmodified_prepare_inputs_labels_for_multimod
     got = hd_oracle.splice_inputs_embeds(ids, lambda t: table[t], feats, hb, wb, mk.SPLICE["sep_id"], mk.SPLICE["ret_id"])
     want = torch.from_numpy(z["new_input_embeds"])
     assert got.shape == want.shape and torch.equal(got, want)
+
+
+def test_splice_layout_reproduces_the_reference_embeds_on_cpu():
+    """hd.splice_layout (the host-side integer logic of hd.build_inputs_embeds) drives a plain torch-CPU reconstruction —
+    text rows scattered by the layout, image blocks by the oracle's assemble_one at the layout's rows — that must equal
+    the reference's ``new_input_embeds`` bit for bit.  (The GPU test checks the kernel that fills the same layout.)"""
+    import numpy as np
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle"))
+    import make_hd_golden as mk
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "hd_splice.npz"))
+    ids, hb, wb, feats, table = mk.splice_inputs()
+    M, D = feats.shape[1], feats.shape[2]
+    L, text_src, text_dst, img_plan, n_crops = hd.splice_layout(ids, hb, wb, M)
+    want = torch.from_numpy(z["new_input_embeds"])
+    assert L == want.shape[1] and n_crops == feats.shape[0]
+    out = torch.zeros(ids.shape[0] * L, D)
+    out[torch.tensor(text_dst)] = table[ids.reshape(-1)[torch.tensor(text_src)]]
+    sep, ret = table[mk.SPLICE["sep_id"]], table[mk.SPLICE["ret_id"]]
+    prev_end = -1
+    for row, first, h, w in img_plan:
+        blk, nxt = hd_oracle.assemble_one(feats, first, h, w, sep, ret)
+        assert blk.shape[0] == hd.hd_token_rows(h, w, M) and nxt - first == hd.hd_crop_count(h, w) and row > prev_end
+        out[row:row + blk.shape[0]] = blk
+        prev_end = row + blk.shape[0] - 1
+    assert torch.equal(out.view(ids.shape[0], L, D), want)
+    # the image-less sample consumed one crop index: the crops of the last sample start one later
+    assert [p[1] for p in img_plan] == [0, 7, 8, 10]

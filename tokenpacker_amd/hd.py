@@ -174,6 +174,43 @@ def assemble_hd_tokens(image_features: torch.Tensor, h_block: Sequence[int], w_b
     return [out[a:a + n] for a, n in spans]
 
 
+def splice_layout(input_ids: torch.Tensor, h_block: Sequence[int], w_block: Sequence[int], num_queries: int,
+                  image_token_index: int = -200):
+    """Host-side layout of ``new_input_embeds`` in ``mode == 'slice'`` (llava_arch.py:115-207): for ``input_ids [B, L]``
+    returns ``(max_len, text_src, text_dst, img_plan, n_crops)`` — flat source positions (``b * L + pos``) of the text
+    tokens, their flat destination rows (``b * max_len + row``), one ``(dest_row, first_crop, h_block, w_block)`` per image
+    token in (sample, position) order, and the number of crop indices consumed (a sample without an image token still
+    consumes one, :124-134).  Pure integer logic, no device work."""
+    ids = input_ids.detach().cpu().tolist()
+    per_sample, lengths, crop = [], [], 0
+    for b, row_ids in enumerate(ids):
+        hb, wb = int(h_block[b]), int(w_block[b])
+        segs, row, has_img = [], 0, False
+        for pos, tok in enumerate(row_ids):
+            if tok == image_token_index:
+                has_img = True
+                segs.append(("img", row, crop, hb, wb))
+                row += hd_token_rows(hb, wb, num_queries)
+                crop += hd_crop_count(hb, wb)
+            else:
+                segs.append(("txt", row, pos))
+                row += 1
+        if not has_img:
+            crop += 1                                     # llava_arch.py:124-134: cur_image_idx += 1
+        per_sample.append(segs)
+        lengths.append(row)
+    L_in, L = (len(ids[0]) if ids else 0), (max(lengths) if lengths else 0)
+    text_src, text_dst, img_plan = [], [], []
+    for b, segs in enumerate(per_sample):
+        for seg in segs:
+            if seg[0] == "txt":
+                text_src.append(b * L_in + seg[2])
+                text_dst.append(b * L + seg[1])
+            else:
+                img_plan.append((b * L + seg[1], seg[2], seg[3], seg[4]))
+    return L, text_src, text_dst, img_plan, crop
+
+
 def build_inputs_embeds(input_ids: torch.Tensor, embed_tokens, image_features: torch.Tensor, h_block: Sequence[int],
                         w_block: Sequence[int], sep_id: int, ret_id: int, image_token_index: int = -200,
                         crop_map: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -197,36 +234,10 @@ def build_inputs_embeds(input_ids: torch.Tensor, embed_tokens, image_features: t
         raise ValueError("input_ids must be [B, L] with one h_block / w_block entry per sample")
     M, D = image_features.shape[1], image_features.shape[2]
     device, dtype = image_features.device, image_features.dtype
-    # ---- host-side layout: per sample a list of (text span | image block)
-    text_src, text_dst, img_plan, lengths, crop = [], [], [], [], 0
-    per_sample = []
-    for b, ids in enumerate(ids_cpu.tolist()):
-        hb, wb = int(h_block[b]), int(w_block[b])
-        segs, row, has_img = [], 0, False
-        for pos, tok in enumerate(ids):
-            if tok == image_token_index:
-                has_img = True
-                segs.append(("img", row, crop, hb, wb))
-                row += hd_token_rows(hb, wb, M)
-                crop += hd_crop_count(hb, wb)
-            else:
-                segs.append(("txt", row, pos))
-                row += 1
-        if not has_img:
-            crop += 1                                     # llava_arch.py:124-134: cur_image_idx += 1
-        per_sample.append(segs)
-        lengths.append(row)
+    L, text_src, text_dst, img_plan, crop = splice_layout(ids_cpu, h_block, w_block, M, image_token_index)
     n_logical = crop_map.numel() if crop_map is not None else image_features.shape[0]
     if crop != n_logical:
         raise ValueError(f"input_ids / h_block / w_block describe {crop} crops, image_features holds {n_logical}")
-    L = max(lengths)
-    for b, segs in enumerate(per_sample):
-        for seg in segs:
-            if seg[0] == "txt":
-                text_src.append(b * ids_cpu.shape[1] + seg[2])
-                text_dst.append(b * L + seg[1])
-            else:
-                img_plan.append((b * L + seg[1], seg[2], seg[3], seg[4]))
     out = torch.zeros(ids_cpu.shape[0] * L, D, dtype=dtype, device=device)
     ids_dev = input_ids.to(device).reshape(-1)
     if text_src:
