@@ -74,3 +74,23 @@ def test_golden_param_digests_are_reproducible():
         z = np.load(path)
         p = synth.make_params(int(z["param_seed"]), int(z["hidden_size"]))
         assert synth.tensor_digest(*p.values()) == str(z["params_sha256"])
+
+
+def test_deepcopy_and_pickle_drop_the_kernel_side_caches():
+    """The reference module can be deep-copied and pickled (HF Trainer, EMA copies, torch.save(model)); ours carries
+    device caches that must not travel (a HIP event is not picklable; a copied weight image would alias the original)."""
+    import copy
+    import pickle
+    m = TokenPacker(hidden_size=256, scale_factor=3)
+    m._packed = torch.zeros(4)                           # stand-ins for what a GPU forward leaves behind
+    m._packed_key = ("k",)
+    m._packed_event = (i for i in range(1))              # a generator: neither picklable nor deep-copyable, like a HIP event
+    m._workspaces[("dev", 0)] = torch.zeros(8)
+    m._last_launch = (object(), torch.zeros(1), 0)
+    for clone in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+        assert clone._packed is None and clone._packed_key is None and clone._packed_event is None
+        assert clone._workspaces == {} and clone._last_launch is None
+        assert clone.scale_factor == 3 and clone.hidden_size == 256
+        for (k, a), (_, b) in zip(m.state_dict().items(), clone.state_dict().items()):
+            assert torch.equal(a, b) and a.data_ptr() != b.data_ptr(), k
+    assert m._packed is not None                         # the original keeps its caches

@@ -109,6 +109,23 @@ class TokenPacker(nn.Module):
         self._last_launch = None             # (desc, workspace) of the last inference forward: saturation_report()
 
     # ------------------------------------------------------------------------------------------
+    _CACHE_DEFAULTS = {"_packed": None, "_packed_key": None, "_packed_event": None, "_packed_stream": None,
+                       "_overflow_checked": False, "_last_launch": None}
+
+    def __getstate__(self):
+        """``copy.deepcopy`` / ``pickle`` / ``torch.save(module)`` carry the parameters and settings, never the kernel-side
+        caches (packed weight image, workspaces, HIP event): a copy re-packs on its first forward."""
+        state = self.__dict__.copy()
+        state.update(self._CACHE_DEFAULTS)
+        state["_workspaces"] = {}
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        for k, v in self._CACHE_DEFAULTS.items():
+            self.__dict__.setdefault(k, v)
+        self.__dict__.setdefault("_workspaces", {})
+
     def _reset_parameters(self) -> None:
         """Same initial distribution as the reference (builder.py:87-94): truncated normal
         (std 0.02) for every nn.Linear weight (out_proj included), zero biases, unit LayerNorm;
