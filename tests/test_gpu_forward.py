@@ -366,3 +366,26 @@ def test_whole_path_other_scale_factors_and_grids(grid, s):
     print(f"\n[parity] grid={grid} s={s}: rel_err {e:.3e}")
     assert e <= 1.2e-3, e
     assert sum(m.saturation_report().values()) == 0
+
+
+@pytest.mark.parametrize("s", [2, 3])
+def test_batch_invariance_across_tile_shapes_and_kernels(s):
+    """Images never interact, and the GEMM behind every layer changes shape with the batch: 128-tile kernel (few tiles),
+    256x256 persistent tiles, 128x256 half tiles for the tail round, row-window launches — including the statistics-only
+    and accumulator-pre-loaded variants of the fused LayerNorm chain (s = 2) and the eight-group K = 128 / N = 128 GEMMs of
+    the absorbed schedule (s = 3).  Every image of every batch must equal the same image projected alone, bit for bit."""
+    dtype, D = torch.bfloat16, 256
+    m = _module(synth.make_params(120 + s, D), s, D, dtype)
+    Bmax = 100
+    g = torch.Generator(device="cuda").manual_seed(77)
+    xb = torch.randn(Bmax, 577, 1024, generator=g, device="cuda").to(dtype)
+    xmb = torch.randn(Bmax, 577, 4096, generator=g, device="cuda").to(dtype)
+    x, xm = xb[:, 1:], xmb[:, 1:]                                   # tower layout
+    with torch.no_grad():
+        alone = {k: m((x[k:k + 1], xm[k:k + 1])) for k in (0, 2, 16, 32, 35, 46, 63, 99)}
+        for B in (3, 17, 33, 36, 47, 64, 100):
+            y = m((x[:B], xm[:B]))
+            for k, yk in alone.items():
+                if k < B:
+                    assert torch.equal(y[k:k + 1], yk), (s, B, k)
+    torch.cuda.synchronize()
