@@ -58,8 +58,12 @@ typedef struct tp_desc {
     int32_t dtype;         /* tp_dtype of x, x_multi and all weights: TP_BF16 or TP_F16           */
     int32_t out_dtype;     /* tp_dtype of `out`: == dtype, or TP_F32                              */
     float   ln_eps;        /* 1e-6 (builder.py:48)                                                */
-    int32_t reserved;      /* must be 0                                                           */
+    int32_t flags;         /* 0, or TP_DESC_TRAIN_PACK for tp_pack_weights (see below); other bits must be 0 */
 } tp_desc;
+/* tp_pack_weights only: the image will serve tp_forward_train / tp_backward — the weights that only the inference
+ * schedules read (Wc / d of the fused LayerNorm chain, the per-head transposes of the absorbed schedule, the out_proj fold)
+ * are not built.  A training step re-packs every step (the parameters just changed) and must not pay for them. */
+#define TP_DESC_TRAIN_PACK 1
 
 /* The 23 tensors of the reference state dict, all of element type desc.dtype,
  * each contiguous, nn.Linear layout [out_features, in_features]. */

@@ -59,7 +59,7 @@ class TokenPackerLibraryError(RuntimeError):
 class tp_desc(Structure):
     _fields_ = [("batch", c_int32), ("raw_grid", c_int32), ("scale_factor", c_int32),
                 ("hidden_size", c_int32), ("dtype", c_int32), ("out_dtype", c_int32),
-                ("ln_eps", c_float), ("reserved", c_int32)]
+                ("ln_eps", c_float), ("flags", c_int32)]
 
 
 class tp_weights(Structure):
@@ -198,10 +198,13 @@ def check(rc: int, what: str) -> None:
     raise RuntimeError(f"{what} failed ({rc}): {msg}")
 
 
+TP_DESC_TRAIN_PACK = 1
+
+
 def make_desc(batch: int, raw_grid: int, scale_factor: int, hidden_size: int, dtype: int,
-              out_dtype: int | None = None, ln_eps: float = 1e-6) -> tp_desc:
+              out_dtype: int | None = None, ln_eps: float = 1e-6, flags: int = 0) -> tp_desc:
     return tp_desc(batch, raw_grid, scale_factor, hidden_size, dtype,
-                   dtype if out_dtype is None else out_dtype, ln_eps, 0)
+                   dtype if out_dtype is None else out_dtype, ln_eps, flags)
 
 
 def strides3(st) -> "ctypes.Array":

@@ -124,6 +124,7 @@ int validate_desc(const tp_desc* d) {
         return TP_ERR_INVALID_ARG;
     }
     if (!(d->ln_eps > 0.f)) { set_error("tp_desc: ln_eps must be > 0"); return TP_ERR_INVALID_ARG; }
+    if (d->flags & ~TP_DESC_TRAIN_PACK) { set_error("tp_desc: unknown flags 0x%x", d->flags); return TP_ERR_INVALID_ARG; }
     return TP_OK;
 }
 
@@ -247,7 +248,8 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
     TP_TRY(pack_ln_fold_launch(dt, inw + 2 * E * E * 2, inb + 2 * E * 2, raw->ln_v_1_weight, raw->ln_v_1_bias,
                                P + L.w_in_kv + E * E * 2, (float*)(P + L.c_in_kv) + E, (float*)(P + L.b_in_kv) + E,
                                (int)E, (int)E, stream, sat));
-    TP_TRY(pack_head_transpose_launch(P + L.w_in_kv, P + L.w_qt, stream));      // of the ROUNDED W'k: the absorbed schedule
+    const bool train_pack = (desc->flags & TP_DESC_TRAIN_PACK) != 0;     // training image: inference-only weights are skipped
+    if (!train_pack) TP_TRY(pack_head_transpose_launch(P + L.w_in_kv, P + L.w_qt, stream));      // of the ROUNDED W'k: the absorbed schedule
     TP_TRY(pack_cast_f16_launch(dt, raw->clip_attn_out_proj_weight, P + L.w_out, (long long)(E * E), stream, sat));
     TP_TRY(pack_cast_f32_launch(dt, raw->clip_attn_out_proj_bias, (float*)(P + L.b_out), (int)E, stream));
     TP_TRY(pack_cast_f16_launch(dt, raw->mlp_0_weight, P + L.w_m0, (long long)D * E, stream, sat));
@@ -260,7 +262,7 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
     //   of H2 — which is then computed for those statistics only and never written (604 MB less written and read per
     //   B = 256 forward, 16 fewer output stores per tile of that GEMM).  W' is the ROUNDED folded weight, so the mean
     //   term still cancels against c = rowsum(W') exactly as in the unfused form.
-    if (tuning(TP_TUNE_FUSE_KV_LN) != 0) {
+    if (tuning(TP_TUNE_FUSE_KV_LN) != 0 && !train_pack) {
         for (int g = 0; g < 2; ++g) {
             TP_TRY(pack_transpose_f16_launch(P + L.w_kv2 + (size_t)g * E * E * 2, P + L.scratch_t, (int)E, stream));   // W2^T [k][j]
             GemmArgs a = plain_gemm(P + L.w_in_kv + (size_t)g * E * E * 2, E, P + L.scratch_t, P + L.scratch_p, E, (int)E, (int)E,
@@ -277,7 +279,7 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
     // out_proj folded into mlp[0]:  W_om = Wm0·Wout (fp32 accumulate on the MFMA kernel, rounded once to fp16),
     // b_om = Wm0·bout + bm0 — built only when the fold is switched on AT PACK TIME (TP_TUNE_FOLD_OUT_PROJ, default off:
     // a training step re-packs every step and must not pay for a product it never uses); status[1] records it.
-    if (tuning(TP_TUNE_FOLD_OUT_PROJ) != 0) {
+    if (tuning(TP_TUNE_FOLD_OUT_PROJ) != 0 && !train_pack) {
         TP_TRY(pack_transpose_f16_launch(P + L.w_out, P + L.scratch_t, (int)E, stream));
         {
             GemmArgs a = plain_gemm(P + L.w_m0, E, P + L.scratch_t, P + L.scratch_p, E, D, (int)E, (int)E, nullptr, 0);

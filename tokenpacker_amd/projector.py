@@ -179,7 +179,7 @@ class TokenPacker(nn.Module):
                                 f"the reference does, or run under torch.autocast")
         lib = _capi.load_library()
         desc = _capi.make_desc(1, self.raw_grid, self.scale_factor, self.hidden_size, _DTYPES[dtype],
-                               ln_eps=self._ln_eps())
+                               ln_eps=self._ln_eps(), flags=_capi.TP_DESC_TRAIN_PACK if force else 0)
         nbytes = lib.tp_packed_weight_bytes(ctypes.byref(desc))
         if nbytes == 0:
             raise RuntimeError(f"tp_packed_weight_bytes: {_capi.last_error()}")
