@@ -383,9 +383,10 @@ enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all hal
                                      r CUs per XCD to kernels of other streams (RCCL's all-gather overlapping the next forward) */
        TP_TUNE_ABSORB_KV = 7,     /* K/V in-projection absorbed into the query side (see tp_forward): 0 auto (scale_factor >= 3),
                                      1 never, 2 always */
-       TP_TUNE_FUSE_KV_LN = 8,    /* 1 (default): inference, plain schedule: the K/V second layer is computed for its LayerNorm
-                                     statistics only (no H2 written) and the in-projection reads Hkv through the pre-multiplied
-                                     weight Wc = W'·W2 (tp_forward's header) | 0: H2 written and read back */
+       TP_TUNE_FUSE_KV_LN = 8,    /* 1 (default): inference: the layer in front of every LayerNorm is computed for its row statistics
+                                     only and the in-projection behind it reads that layer's INPUT through a pre-multiplied weight
+                                     (K/V side on the plain schedule: Wc = W'·W2, no H2 written; query side on every schedule:
+                                     W'q·Wq1, no Q1pre written) | 0: the pre-LayerNorm activations are written and read back */
        TP_TUNE_COUNT_ = 12 };
 int tp_set_tuning(int key, int value);
 

@@ -41,8 +41,8 @@ def test_sizes_and_descriptor_validation():
     # 36,722,688 parameters in 2-byte elements, + fp32 biases/colsums + alignment, + the optional
     # out_proj∘mlp[0] fold (W_om [D,1024] fp16) and its pack-time scratch (Wout^T fp16, fp32 product [D,1024])
     # + the per-head transposes of the folded K in-projection the absorbed schedule reads (w_qt, 2 MiB)
-    # + Wc = W'·W2 for k and v (the fused LayerNorm chain, 4 MiB)
-    fold = 4096 * 1024 * 2 + 1024 * 1024 * 2 + 4096 * 1024 * 4 + 1024 * 1024 * 2 + 2 * 1024 * 1024 * 2
+    # + Wc = W'·W2 for k and v and W'q·Wq1 for q (the fused LayerNorm chains, 6 MiB)
+    fold = 4096 * 1024 * 2 + 1024 * 1024 * 2 + 4096 * 1024 * 4 + 1024 * 1024 * 2 + 3 * 1024 * 1024 * 2
     assert 36_722_688 * 2 + fold <= packed < 36_722_688 * 2 + fold + 300_000
     ws = lib.tp_workspace_bytes(ctypes.byref(d))
     assert 1.5e9 < ws < 3.5e9

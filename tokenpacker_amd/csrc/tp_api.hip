@@ -57,6 +57,7 @@ PackedLayout packed_layout(int D) {
     L.w_in_q = take(E * E * 2);          L.c_in_q = take(E * 4);       L.b_in_q = take(E * 4);
     L.w_qt = take(E * E * 2);
     L.w_c_kv = take(2 * E * E * 2);      L.d_in_kv = take(2 * E * 4);
+    L.w_c_q = take(E * E * 2);
     L.w_out = take(E * E * 2);           L.b_out = take(E * 4);
     L.w_m0 = take((size_t)D * E * 2);    L.b_m0 = take((size_t)D * 4);
     L.w_m2 = take((size_t)D * D * 2);    L.b_m2 = take((size_t)D * 4);
@@ -273,6 +274,13 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
             TP_TRY(pack_bias_fold_launch(P + L.w_in_kv + (size_t)g * E * E * 2, (const float*)(P + L.b_kv2) + g * E, nullptr,
                                          (float*)(P + L.d_in_kv) + g * E, (int)E, (int)E, stream));
         }
+        {   // query side: Q = rstd·(q0·Wcq^T − mu·c_q) + b'_q,  Wcq = W'q·Wq1  (q_proj_1 has no bias)
+            TP_TRY(pack_transpose_f16_launch(P + L.w_q1, P + L.scratch_t, (int)E, stream));
+            GemmArgs a = plain_gemm(P + L.w_in_q, E, P + L.scratch_t, P + L.scratch_p, E, (int)E, (int)E, (int)E, nullptr, 0);
+            a.tile = 128;
+            TP_TRY(gemm_launch(TP_F16, TP_F32, a, stream));
+            TP_TRY(pack_round_f16_launch((const float*)(P + L.scratch_p), P + L.w_c_q, (long long)E * E, stream, sat));
+        }
         hipError_t e = hipMemsetD32Async((hipDeviceptr_t)(status + 2), 1, 1, stream);
         if (e != hipSuccess) { set_error("tp_pack_weights: hipMemsetD32Async(status): %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
     }
@@ -351,7 +359,8 @@ int tp_debug_count_saturated(const tp_desc* desc, const void* workspace, size_t 
         // (the absorbed schedule keeps qt | u [2][rows_q, 8, E] where K | V would be)
         {W.q0, rows_q * E}, {W.hkv, rows_kv * 2 * E},
         {W.h2, (!absorb_kv(desc, false) && tuning(TP_TUNE_FUSE_KV_LN) != 0) ? 0 : 2 * rows_kv * E},   // (fused chain: H2 is never written)
-        {W.kv, absorb_kv(desc, false) ? 2 * rows_q * 8 * E : 2 * rows_kv * E}, {W.q1pre, rows_q * E},
+        {W.kv, absorb_kv(desc, false) ? 2 * rows_q * 8 * E : 2 * rows_kv * E},
+        {W.q1pre, tuning(TP_TUNE_FUSE_KV_LN) != 0 ? 0 : rows_q * E},                                  // (fused chain: never written)
         {W.q, rows_q * E}, {W.o, rows_q * E}, {W.a1, rows_q * E}, {W.a2, rows_q * (long long)D}};
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * TP_NUM_DEBUG_BUFFERS, stream);
     if (e != hipSuccess) { set_error("tp_debug_count_saturated: hipMemsetAsync: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
@@ -551,15 +560,18 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     // query side on a side stream (not when the caller wants per-stage events: those need one stream)
     SideCtx* side = (tuning(TP_TUNE_Q_SIDE_STREAM) && !stage_events) ? side_ctx_for(stream) : nullptr;
     const int parts_q = gemm_stats_parts(E);
+    // (fused LayerNorm chain, inference: Q1pre is computed for its row statistics only; the in-projection reads q0)
+    const bool fuse_q = !train && tuning(TP_TUNE_FUSE_KV_LN) != 0;
     auto q_proj = [&](hipStream_t st) -> int {          // 5. Q1pre = q0 · Wq1^T (no bias), LayerNorm partials
-        GemmArgs a = plain_gemm(ws + W.q0, E, pw + P.w_q1, ws + W.q1pre, E, rows_q, E, E, nullptr, TP_LINEAR_ROW_STATS);
+        GemmArgs a = plain_gemm(ws + W.q0, E, pw + P.w_q1, fuse_q ? nullptr : ws + W.q1pre, E, rows_q, E, E, nullptr,
+                                TP_LINEAR_ROW_STATS | (fuse_q ? TP_LINEAR_NO_STORE : 0));
         a.stats_out = (float*)(ws + W.stats_q);
         return launch(TP_F16, TP_F16, a, st);
     };
     auto q_inproj = [&](hipStream_t st) -> int {        // 6. Q = LN(Q1pre) · Winq^T + b
         TP_TRY(ln_finalize_launch((const float*)(ws + W.stats_q), (float*)(ws + W.mr_q), rows_q, parts_q, 1, E,
                                   desc->ln_eps, st));
-        GemmArgs a = plain_gemm(ws + W.q1pre, E, pw + P.w_in_q, ws + W.q, E, rows_q, E, E,
+        GemmArgs a = plain_gemm(fuse_q ? ws + W.q0 : ws + W.q1pre, E, fuse_q ? pw + P.w_c_q : pw + P.w_in_q, ws + W.q, E, rows_q, E, E,
                                 (const float*)(pw + P.b_in_q), TP_LINEAR_LN_FOLD);
         a.stats_in = (const float*)(ws + W.mr_q);
         a.colsum = (const float*)(pw + P.c_in_q);

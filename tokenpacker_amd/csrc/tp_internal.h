@@ -123,6 +123,7 @@ struct PackedLayout {
     size_t w_in_kv, c_in_kv, b_in_kv;   // LN-folded in-proj for k, v: [2][1024,1024] f16, [2][1024] f32 x2
     size_t w_in_q, c_in_q, b_in_q;      // LN-folded in-proj for q
     size_t w_c_kv, d_in_kv;       // fused LayerNorm chain: Wc = W'·W2 [2][1024,1024] f16, d = W'·b2 [2][1024] f32
+    size_t w_c_q;                 // the same for the query side: W'q·Wq1 [1024,1024] f16 (q_proj_1 has no bias: d = 0)
     size_t w_qt;                  // [8][1024][128] f16: per-head transposes of the LN-folded K in-proj (absorbed schedule)
     size_t w_out, b_out;          // [1024,1024] f16, [1024] f32
     size_t w_m0, b_m0;            // [D,1024] f16, [D] f32
