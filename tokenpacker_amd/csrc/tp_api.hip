@@ -132,6 +132,16 @@ int validate_desc(const tp_desc* d) {
 // The absorbed schedule (region_attention_absorbed_kernel's header): auto = scale_factor >= 3, where the two in-projection
 // GEMMs over the B*576 fine tokens cost far more than the 1/s^2-sized query-side work that replaces them (at s = 2 the
 // [B M, 8, 1024] intermediates cost what the GEMMs save).  Inference only: the backward needs K and V.
+// out_proj folded into mlp[0] (W = Wm0·Wout): TP_TUNE_FOLD_OUT_PROJ 0 = auto, 1 = always, 2 = never.  Auto folds on the
+// absorbed schedule only: over the golden cases the fold moves the max-norm parity metric by its own noise — on s = 2 the
+// worst case sits at 0.984e-3 without and 0.992e-3 with it, so the 2 % stay on the table there; on s >= 3 the worst case
+// is 0.967e-3 without and 0.926e-3 with it (tools/fold_parity.py), and the fold removes a 2.25-round launch.
+bool fold_out_proj(const tp_desc* d, bool train) {
+    if (train) return false;                            // the backward needs A1 and the plain weights
+    const int mode = tuning(TP_TUNE_FOLD_OUT_PROJ);
+    return mode == 1 || (mode == 0 && absorb_kv(d, false));
+}
+
 bool absorb_kv(const tp_desc* d, bool train) {
     if (train) return false;
     const int s2 = d->scale_factor * d->scale_factor, mode = tuning(TP_TUNE_ABSORB_KV);
@@ -287,7 +297,7 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
     // out_proj folded into mlp[0]:  W_om = Wm0·Wout (fp32 accumulate on the MFMA kernel, rounded once to fp16),
     // b_om = Wm0·bout + bm0 — built only when the fold is switched on AT PACK TIME (TP_TUNE_FOLD_OUT_PROJ, default off:
     // a training step re-packs every step and must not pay for a product it never uses); status[1] records it.
-    if (tuning(TP_TUNE_FOLD_OUT_PROJ) != 0 && !train_pack) {
+    if (fold_out_proj(desc, train_pack)) {
         TP_TRY(pack_transpose_f16_launch(P + L.w_out, P + L.scratch_t, (int)E, stream));
         {
             GemmArgs a = plain_gemm(P + L.w_m0, E, P + L.scratch_t, P + L.scratch_p, E, D, (int)E, (int)E, nullptr, 0);
@@ -361,7 +371,7 @@ int tp_debug_count_saturated(const tp_desc* desc, const void* workspace, size_t 
         {W.h2, (!absorb_kv(desc, false) && tuning(TP_TUNE_FUSE_KV_LN) != 0) ? 0 : 2 * rows_kv * E},   // (fused chain: H2 is never written)
         {W.kv, absorb_kv(desc, false) ? 2 * rows_q * 8 * E : 2 * rows_kv * E},
         {W.q1pre, tuning(TP_TUNE_FUSE_KV_LN) != 0 ? 0 : rows_q * E},                                  // (fused chain: never written)
-        {W.q, rows_q * E}, {W.o, rows_q * E}, {W.a1, rows_q * E}, {W.a2, rows_q * (long long)D}};
+        {W.q, rows_q * E}, {W.o, rows_q * E}, {W.a1, fold_out_proj(desc, false) ? 0 : rows_q * E}, {W.a2, rows_q * (long long)D}};
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * TP_NUM_DEBUG_BUFFERS, stream);
     if (e != hipSuccess) { set_error("tp_debug_count_saturated: hipMemsetAsync: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
     for (int i = 0; i < TP_NUM_DEBUG_BUFFERS; ++i)
@@ -674,7 +684,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     TP_TRY(mark());
     // 8. out_proj — optionally folded into mlp[0] at pack time (TP_TUNE_FOLD_OUT_PROJ, default OFF): -2 % time, same
     //    rel-L2 error, but the max-error metric of one golden case moved from 0.92e-3 to 1.09e-3 (gate 1e-3)
-    const bool fold = tuning(TP_TUNE_FOLD_OUT_PROJ) != 0 && !train;     // backward needs A1 and the plain weights
+    const bool fold = fold_out_proj(desc, train);
     if (!fold) {
         GemmArgs a = plain_gemm(ws + W.o, E, pw + P.w_out, ws + W.a1, E, rows_q, E, E, (const float*)(pw + P.b_out), 0);
         TP_TRY(launch(TP_F16, TP_F16, a, stream));

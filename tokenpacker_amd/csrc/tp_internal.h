@@ -95,6 +95,7 @@ int region_attention_absorbed_launch(const void* qt, const void* h2k, const void
                                      void* u, int B, int grid, int s, hipStream_t stream, const float* mask = nullptr, int mask_mode = 0);
 int pack_head_transpose_launch(const void* w_f16, void* dst_f16, hipStream_t stream);    // [8*128, 1024] -> [8][1024][128]
 bool absorb_kv(const tp_desc* desc, bool train);          // whether tp_forward runs the absorbed schedule for desc
+bool fold_out_proj(const tp_desc* desc, bool train);      // whether out_proj is folded into mlp[0] for desc
 int hd_slice_launch(const float* img, int H, int W, int h_block, int w_block, int h_res, int w_res, int hg, int wg,
                     float* crops, int block, hipStream_t stream);
 int occupy_cus_launch(int blocks, int usec, int* sink, hipStream_t stream);
