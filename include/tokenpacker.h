@@ -134,7 +134,8 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
  * Schedules (same function, same parity gates; what differs is which intermediates exist):
  *   training (tp_forward_train)     : every layer as its own GEMM — the backward needs H2, K and V;
  *   inference, scale_factor 2       : fused LayerNorm chain (TP_TUNE_FUSE_KV_LN): the K/V second layer is computed for its
- *                                     LayerNorm statistics only, the in-projection reads Hkv through Wc = W'·W2;
+ *                                     LayerNorm statistics only, the in-projection reads Hkv through Wc = W'·W2, and region
+ *                                     attention runs in the epilogues of those two GEMMs (TP_TUNE_FUSE_ATTN): K, V are not written;
  *   inference, scale_factor >= 3    : K/V in-projections absorbed into the query side (TP_TUNE_ABSORB_KV, see
  *                                     tp_region_attention_absorbed). */
 int tp_forward(const tp_desc* desc,
@@ -174,7 +175,10 @@ int tp_forward_parts(const tp_desc* desc,
  * timing enabled) on `stream` at the TP_NUM_STAGES+1 stage boundaries, so a benchmark can time each
  * kernel of the schedule inside the real forward (bench.py's `roofline` object).  Stages, in order:
  * point_queries, kv_layer0(+GELU), kv_layer2(+stats), kv_inproj(LN-fold), q_proj_1(+stats),
- * q_inproj(LN-fold), region_attention, out_proj, mlp0(+GELU), mlp2. */
+ * q_inproj(LN-fold), region_attention, out_proj, mlp0(+GELU), mlp2.
+ * (The staged forward runs on ONE stream.  With attention in the in-projections' epilogues — TP_TUNE_FUSE_ATTN, the
+ * scale_factor-2 default — the K launch needs Q: the whole query side then runs inside the first stage, the two q stages are
+ * empty, `kv_inproj` is the K launch (logits) and `region_attention` the V launch (softmax-weighted sums -> O).) */
 #define TP_NUM_STAGES 10
 int tp_forward_staged(const tp_desc* desc,
                       const void* x, const int64_t x_strides[3],
@@ -388,6 +392,11 @@ enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all hal
                                      only and the in-projection behind it reads that layer's INPUT through a pre-multiplied weight
                                      (K/V side on the plain schedule: Wc = W'·W2, no H2 written; query side on every schedule:
                                      W'q·Wq1, no Q1pre written) | 0: the pre-LayerNorm activations are written and read back */
+       TP_TUNE_FUSE_ATTN = 10,    /* inference, scale_factor 2, fused LayerNorm chain, no attn_mask: 0 (default) the first K/V layer reads
+                                     the tower's rows in REGION-MAJOR order (a region's 4 tokens = 4 consecutive rows of every K/V-side
+                                     tensor) and region attention runs inside the epilogues of the K and V in-projection GEMMs — K, V
+                                     are never written, no attention kernel | 1 off (raster rows, tp_region_attention's kernel) |
+                                     2 region-major rows + the separate attention kernel (A/B, tests) */
        TP_TUNE_COUNT_ = 12 };
 int tp_set_tuning(int key, int value);
 

@@ -277,6 +277,57 @@ def test_absorbed_kv_schedule_is_the_same_function(s, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B", [1, 3, 9, 23])
+def test_attention_in_the_inprojection_epilogues_is_the_same_function(dtype, B):
+    """TP_TUNE_FUSE_ATTN (default 0; inference, s = 2): region-major K/V rows + region attention inside the epilogues of the
+    K and V in-projection GEMMs (K, V never written) against
+      2 = region-major rows + the separate attention kernel, and 1 = raster rows + the separate attention kernel.
+    1 and 2 differ only in the ORDER of the K/V rows: bit-identical.  0 keeps K and V in fp32 (no fp16 rounding between the
+    in-projection and attention): not bit-identical, within the gate of the fp64 oracle and no worse than the others.
+    B = 1, 3: 128-tile kernel; 9: 256-tile persistent (81 tiles_m... > 200 tiles); 23: full tiles + a half-tile tail."""
+    from tokenpacker_amd import _capi
+    D, s = 256, 2
+    params = synth.make_params(195, D)
+    x, xm = synth.make_inputs(196, B, dtype)
+    p_lp = {k: v.to(dtype) for k, v in params.items()}
+    y_exact = orc.forward(p_lp, x, xm, scale_factor=s, compute_dtype=torch.float64, io_dtype=dtype)
+    ys = {}
+    try:
+        for mode in (0, 1, 2):
+            _capi.set_tuning(_capi.TP_TUNE_FUSE_ATTN, mode)
+            m = _module(params, s, D, dtype)
+            m.output_fp32 = True
+            with torch.no_grad():
+                ys[mode] = m((x.cuda(), xm.cuda()))
+            torch.cuda.synchronize()
+            assert sum(m.saturation_report().values()) == 0
+    finally:
+        _capi.set_tuning(_capi.TP_TUNE_FUSE_ATTN, 0)
+    e = {k: orc.rel_err(v, y_exact) for k, v in ys.items()}
+    l = {k: orc.rel_l2(v, y_exact) for k, v in ys.items()}
+    print(f"\n[parity] fused attention B={B} {dtype}: rel_err fused {e[0]:.3e} / separate {e[1]:.3e}; "
+          f"l2 fused {l[0]:.3e} / separate {l[1]:.3e}; between them {orc.rel_err(ys[0], ys[1]):.3e}")
+    assert torch.equal(ys[1], ys[2]), "region-major rows must not change a single bit"
+    assert not torch.equal(ys[0], ys[1])                   # the knob really switches the schedule
+    assert e[0] <= 1e-3 and e[1] <= 1e-3, e
+    assert l[0] <= 1.05 * l[1] + 1e-5, l
+    if B == 23:
+        # the attention epilogues exist in three kernels (256x256 persistent tiles — what B = 23 selects —, 128x256 half
+        # tiles, the 128-tile kernel): one arithmetic, bit-identical results
+        for key, val in ((_capi.TP_TUNE_GEMM_KERNEL, 3), (_capi.TP_TUNE_GEMM_TILE, 128)):
+            _capi.set_tuning(key, val)
+            try:
+                m = _module(params, s, D, dtype)
+                m.output_fp32 = True
+                with torch.no_grad():
+                    y = m((x.cuda(), xm.cuda()))
+                torch.cuda.synchronize()
+            finally:
+                _capi.set_tuning(key, 0)
+            assert torch.equal(y, ys[0]), (key, val)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B", [2, 9])
 def test_fused_layernorm_chain_is_the_same_function(dtype, B):
     """TP_TUNE_FUSE_KV_LN (default on; inference, plain schedule): the K/V second layer computed for its LayerNorm

@@ -369,7 +369,9 @@ int tp_debug_count_saturated(const tp_desc* desc, const void* workspace, size_t 
         // (the absorbed schedule keeps qt | u [2][rows_q, 8, E] where K | V would be)
         {W.q0, rows_q * E}, {W.hkv, rows_kv * 2 * E},
         {W.h2, (!absorb_kv(desc, false) && tuning(TP_TUNE_FUSE_KV_LN) != 0) ? 0 : 2 * rows_kv * E},   // (fused chain: H2 is never written)
-        {W.kv, absorb_kv(desc, false) ? 2 * rows_q * 8 * E : 2 * rows_kv * E},
+        // (attention in the in-projections' epilogues, TP_TUNE_FUSE_ATTN: K | V are never written.  The mask-less forward is assumed.)
+        {W.kv, absorb_kv(desc, false) ? 2 * rows_q * 8 * E
+               : (s == 2 && tuning(TP_TUNE_FUSE_KV_LN) != 0 && tuning(TP_TUNE_FUSE_ATTN) == 0) ? 0 : 2 * rows_kv * E},
         {W.q1pre, tuning(TP_TUNE_FUSE_KV_LN) != 0 ? 0 : rows_q * E},                                  // (fused chain: never written)
         {W.q, rows_q * E}, {W.o, rows_q * E}, {W.a1, fold_out_proj(desc, false) ? 0 : rows_q * E}, {W.a2, rows_q * (long long)D}};
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * TP_NUM_DEBUG_BUFFERS, stream);
@@ -588,6 +590,11 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         return launch(TP_F16, TP_F16, a, st);
     };
     const bool absorb = absorb_kv(desc, train);
+    // (fused LayerNorm chain — inference, plain schedule: H2 is needed for its row statistics only and is not written)
+    const bool fuse_ln = !train && !absorb && tuning(TP_TUNE_FUSE_KV_LN) != 0;
+    // scale_factor 2 on that chain: region-major K/V rows, and region attention inside the in-projections' epilogues
+    const bool region_major = fuse_ln && s == 2 && !attn_mask && tuning(TP_TUNE_FUSE_ATTN) != 1;
+    const bool fuse_attn = region_major && tuning(TP_TUNE_FUSE_ATTN) == 0;
     char* const qt = ws + W.kv;                                        // [rows_q, 8, E] fp16 (absorbed schedule)
     char* const uu = ws + W.kv + (size_t)rows_q * 8 * E * 2;           // [rows_q, 8, E] fp16
     auto qt_gemm = [&](hipStream_t st) -> int {         // qt[m, h, :] = Q[m, h*128:(h+1)*128] · W'k[h*128:(h+1)*128, :]
@@ -618,6 +625,8 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     TP_TRY(mark());
     // 1. coarse point queries
     if (!side) TP_TRY(point_queries_launch(dt, x, x_strides, ws + W.q0, B, g, s, stream));
+    // (attention in the in-projections' epilogues: the K launch of step 4 needs Q — on one stream the whole query side runs here)
+    if (!side && fuse_attn) { TP_TRY(q_proj(stream)); TP_TRY(q_inproj(stream)); }
 
     TP_TRY(mark());
     // 2. Hkv = GELU(x_multi · [Wk0;Wv0]^T + b): strided A (tower hands over [:,1:] slices)
@@ -625,6 +634,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         GemmArgs a = plain_gemm(x_multi, xm_strides[1], pw + P.w_kv0, ws + W.hkv, 2 * E, rows_kv, 2 * E, kMulti,
                                 (const float*)(pw + P.b_kv0), TP_LINEAR_GELU | (train ? TP_LINEAR_SAVE_PRE : 0));
         a.rows_per_batch = N; a.a_batch_stride_bytes = xm_strides[0] * 2;
+        if (region_major) { a.a_region_g = g; a.a_region_s = s; }      // rows of Hkv (and of everything behind it) by region
         a.C2 = train ? ws + W.z1 : nullptr;
         if (xm_parts) {
             for (int i = 0; i < 4; ++i) a.A_parts[i] = (const char*)xm_parts[i];
@@ -635,8 +645,6 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     // 3. H2[g] = Hkv[:, g*1024:(g+1)*1024] · W{k,v}2^T + b, and LayerNorm partials of H2
     TP_TRY(mark());
     const int parts_kv = gemm_stats_parts(E);
-    // (fused LayerNorm chain — inference, plain schedule: H2 is needed for its row statistics only and is not written)
-    const bool fuse_ln = !train && !absorb && tuning(TP_TUNE_FUSE_KV_LN) != 0;
     {
         GemmArgs a = plain_gemm(ws + W.hkv, 2 * E, pw + P.w_kv2, fuse_ln ? nullptr : ws + W.h2, E, rows_kv, E, E,
                                 (const float*)(pw + P.b_kv2), TP_LINEAR_ROW_STATS | (fuse_ln ? TP_LINEAR_NO_STORE : 0));
@@ -647,7 +655,35 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     TP_TRY(mark());
     TP_TRY(ln_finalize_launch((const float*)(ws + W.stats_kv), (float*)(ws + W.mr_kv), rows_kv, parts_kv, 2, E,
                               desc->ln_eps, stream));
+    bool joined = false;
+    auto join_side = [&]() -> int {
+        if (side && !joined) {
+            hipError_t e = hipStreamWaitEvent(stream, side->join, 0);
+            if (e != hipSuccess) { set_error("tp_forward: side stream join wait: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
+        }
+        joined = true;
+        return TP_OK;
+    };
     // 4. {K,V} = LN(H2[g]) · Win{k,v}^T + b   (LayerNorm folded into the epilogue) — not in the absorbed schedule
+    auto attn_gemm = [&](const int kv) -> int {
+        // steps 4 + 7 as two launches: the K launch (step 4) turns its tile of K into logits against the region's query, the
+        // V launch (step 7) its tile of V into softmax-weighted sums -> O.  K and V are never written.
+        GemmArgs a = plain_gemm(ws + W.hkv + (size_t)kv * E * 2, 2 * E, pw + P.w_c_kv + (size_t)kv * E * E * 2,
+                                kv == 0 ? nullptr : ws + W.o, E, rows_kv, E, E, (const float*)(pw + P.b_in_kv) + kv * E,
+                                TP_LINEAR_LN_FOLD);
+        a.acc_init = (const float*)(pw + P.d_in_kv) + kv * E;
+        a.stats_in = (const float*)(ws + W.mr_kv) + (size_t)kv * rows_kv * 2;
+        a.colsum = (const float*)(pw + P.c_in_kv) + kv * E;
+        a.attn_mode = kv + 1;
+        a.attn_q = ws + W.q; a.attn_ldq_bytes = E * 2;
+        a.attn_logits = (float*)(ws + W.h2);            // [8 heads][rows_kv] fp32 (H2 is not written on this chain)
+        a.attn_scale = 0.08838834764831845f;            // 1/sqrt(128): q scaling of F.multi_head_attention_forward
+        return launch(TP_F16, TP_F16, a, stream);
+    };
+    if (fuse_attn) {
+        TP_TRY(join_side());                            // Q must be there
+        TP_TRY(attn_gemm(0));
+    } else
     if (!absorb) {
         GemmArgs a = plain_gemm(ws + W.h2, E, pw + P.w_in_kv, ws + W.kv, E, rows_kv, E, E,
                                 (const float*)(pw + P.b_in_kv), TP_LINEAR_LN_FOLD);
@@ -662,16 +698,15 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         TP_TRY(launch(TP_F16, TP_F16, a, stream));
     }
     TP_TRY(mark());
-    if (!side) TP_TRY(q_proj(stream));
+    if (!side && !fuse_attn) TP_TRY(q_proj(stream));
     TP_TRY(mark());
-    if (!side) { TP_TRY(q_inproj(stream)); if (absorb) TP_TRY(qt_gemm(stream)); }
+    if (!side && !fuse_attn) { TP_TRY(q_inproj(stream)); if (absorb) TP_TRY(qt_gemm(stream)); }
     TP_TRY(mark());
-    if (side) {
-        hipError_t e = hipStreamWaitEvent(stream, side->join, 0);
-        if (e != hipSuccess) { set_error("tp_forward: side stream join wait: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
-    }
+    TP_TRY(join_side());
     // 7. region-to-point attention
-    if (absorb) {
+    if (fuse_attn) {
+        TP_TRY(attn_gemm(1));
+    } else if (absorb) {
         TP_TRY(region_attention_absorbed_launch(qt, ws + W.h2, ws + W.h2 + kvE * 2, (const float*)(ws + W.mr_kv),
                                                 (const float*)(ws + W.mr_kv) + (size_t)rows_kv * 2, uu, B, g, s, stream, attn_mask, mask_mode));
         // O[:, h*128:(h+1)*128] = u[:, h, :] · W'v[h*128:(h+1)*128, :]^T + b'v   (eight N = 128 groups)
@@ -680,7 +715,8 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         a.groups = kHeads; a.a_gs = E * 2; a.w_gs = (long long)kHeadDim * E * 2; a.c_gs = kHeadDim * 2; a.bias_gs = kHeadDim;
         TP_TRY(launch(TP_F16, TP_F16, a, stream));
     } else
-    TP_TRY(region_attention_launch(ws + W.q, ws + W.kv, ws + W.kv + kvE * 2, ws + W.o, B, g, s, stream, attn_mask, mask_mode));
+    TP_TRY(region_attention_launch(ws + W.q, ws + W.kv, ws + W.kv + kvE * 2, ws + W.o, B, g, s, stream, attn_mask, mask_mode,
+                                   region_major ? 1 : 0));
     TP_TRY(mark());
     // 8. out_proj — optionally folded into mlp[0] at pack time (TP_TUNE_FOLD_OUT_PROJ, default OFF): -2 % time, same
     //    rel-L2 error, but the max-error metric of one golden case moved from 0.92e-3 to 1.09e-3 (gate 1e-3)

@@ -75,6 +75,7 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
             int row = m0 + c * 8 + (lane >> 3);
             row = row < p.M ? row : p.M - 1;
             if constexpr (AMODE != 0) {
+                if (p.a_region_s > 0) row = region_major_to_raster(row, p.a_region_g, p.a_region_s);
                 const int b = row / p.rows_per_batch;
                 const int t = row - b * p.rows_per_batch;
                 src[i] = Ag + (long long)b * p.a_batch_stride_bytes + (long long)t * p.lda_bytes + kslot * 16;
@@ -112,7 +113,7 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (XMODE == 2) {                         // accumulators start from a per-column constant (GemmArgs::acc_init)
+    if constexpr (XMODE >= 2) {                         // accumulators start from a per-column constant (GemmArgs::acc_init)
         const float* __restrict__ ai = p.acc_init + g * p.acc_init_gs + n0 + wn * WN + (lane >> 4) * 4;
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
@@ -161,7 +162,12 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
         }
     }
 
-    gemm_epilogue<TO, BM, BN, WM, WN, false, TRAIN_EPI, XMODE == 1>(acc, p, g, m0, n0, tile_n, wm, wn, lane, tid, mean_rstd, smem);
+    if constexpr (XMODE == 3)
+        attn_logits_epilogue<BM, BN, WM, WN, false>(acc, p, g, m0, n0, wm, wn, lane, tid, mean_rstd, smem);
+    else if constexpr (XMODE == 4)
+        attn_sum_epilogue<BM, BN, WM, WN, false>(acc, p, g, m0, n0, wm, wn, lane, mean_rstd);
+    else
+        gemm_epilogue<TO, BM, BN, WM, WN, false, TRAIN_EPI, XMODE == 1>(acc, p, g, m0, n0, tile_n, wm, wn, lane, tid, mean_rstd, smem);
 }
 
 // ---- host side ------------------------------------------------------------------------------------
@@ -198,7 +204,7 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
 template <typename TI, typename TO>
 static int launch_types(const GemmArgs& a, hipStream_t stream) {
     const int tile = gemm_pick_tile(a.M, a.N, a.tile, a.groups);
-    const bool strided = a.rows_per_batch < a.M;
+    const bool strided = a.rows_per_batch < a.M || a.a_region_s > 0;     // (region-major rows: the strided-A kernels)
     constexpr bool HALF_OUT = !std::is_same<TO, float>::value;
     const bool train_epi = (a.flags & (TP_LINEAR_SAVE_PRE | TP_LINEAR_GELU_BWD)) != 0;
     if ((a.flags & TP_LINEAR_NO_STORE) || a.acc_init) {     // the two GEMMs of the fused LayerNorm chain (128-tile form)
@@ -207,6 +213,9 @@ static int launch_types(const GemmArgs& a, hipStream_t stream) {
                 set_error("tp gemm: NO_STORE / acc_init take a contiguous A, no training epilogue, and not both at once");
                 return TP_ERR_INVALID_ARG;
             }
+            if (a.attn_mode)                                 // (validated by gemm_launch)
+                return a.attn_mode == 1 ? launch_cfg<TI, TO, 128, 128, 64, 64, 0, false, 3>(a, stream)
+                                        : launch_cfg<TI, TO, 128, 128, 64, 64, 0, false, 4>(a, stream);
             return (a.flags & TP_LINEAR_NO_STORE) ? launch_cfg<TI, TO, 128, 128, 64, 64, 0, false, 1>(a, stream)
                                                   : launch_cfg<TI, TO, 128, 128, 64, 64, 0, false, 2>(a, stream);
         }
@@ -247,6 +256,14 @@ int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stre
         if ((long long)(a.M + 256) * a.ldc * (out_dtype == TP_F32 ? 4 : 2) >= (1ll << 32)) {
             set_error("tp gemm: output of %lld bytes per group exceeds the 4 GiB a single launch can address "
                       "(M=%d ldc=%lld): split the rows over several calls", out_bytes, a.M, (long long)a.ldc);
+            return TP_ERR_INVALID_ARG;
+        }
+    }
+    if (a.attn_mode) {                                  // region attention in the epilogue (tp_gemm_common.h)
+        if ((a.attn_mode != 1 && a.attn_mode != 2) || in_dtype != TP_F16 || out_dtype != TP_F16 || !a.acc_init || !a.bias ||
+            !a.colsum || !a.stats_in || a.flags != TP_LINEAR_LN_FOLD || a.groups != 1 || a.M % 8 != 0 || a.K != 16 * BK ||
+            !a.attn_logits || (a.attn_mode == 1 ? (!a.attn_q || (a.attn_ldq_bytes & 15)) : !a.C)) {
+            set_error("tp gemm: attn_mode needs fp16 operands, the LayerNorm-fold operands with acc_init, one group, K = 1024, M %% 8 == 0");
             return TP_ERR_INVALID_ARG;
         }
     }

@@ -47,13 +47,15 @@ namespace tp {
 namespace {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N == 0 || N == 2 || N == 4 || N == 6 || N == 8 || N == 12, "unsupported count");
+    static_assert(N == 0 || N == 2 || N == 4 || N == 6 || N == 8 || N == 11 || N == 12 || N == 13, "unsupported count");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
     if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    if constexpr (N == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
 }
 
 constexpr int G8_BM = 256, G8_BN = 256, G8_WN = 64;
@@ -61,9 +63,17 @@ constexpr int G8_GROUP = 128 * ROW_BYTES;          // 16 KiB: one DMA group (128
 constexpr int G8_BUF = 4 * G8_GROUP;               // 64 KiB: one K-tile (G0 | G1 | G2 | G3)
 constexpr int G8_RING = 2 * G8_BUF;                // 128 KiB of K-tile buffers
 // persistent kernel, behind the ring: bias[256] | colsum[256] | (mean, rstd)[256] | acc_init[256] (5 KiB), 8 KiB
-// row-statistics scratch, the next tile index drawn from the queue
+// row-statistics scratch, the next tile index drawn from the queue.
+// XMODE 3 / 4 (attention epilogues): the parameters arrive by LDS-DMA with the tile's prologue into one of TWO buffers (the
+// next tile's land while this tile's are still read): bias | colsum | (mean, rstd)[BM] | acc_init | logits [2 heads][BM]
+// (XMODE 4), and the scratch is what the logits reduction needs (XMODE 3: 16 B per tile row).
 constexpr int G8_PAR = 5120;
-constexpr int G8_LDS = G8_RING + G8_PAR + 8192 + 256;
+constexpr int g8_par_bytes(bool half, int xmode) { return xmode >= 3 ? 2 * (half ? 5120 : 7168) : G8_PAR; }
+constexpr int g8_red_bytes(bool half, int xmode) { return xmode == 3 ? (half ? 128 : 256) * 16 : (xmode == 4 ? 0 : 8192); }
+constexpr int g8_lds_bytes(bool half, bool persist, int xmode) {
+    return half ? 9 * 16384 + g8_par_bytes(true, xmode) + g8_red_bytes(true, xmode) + 256
+                : (persist ? 8 * 16384 + g8_par_bytes(false, xmode) + g8_red_bytes(false, xmode) + 256 : 8 * 16384);
+}
 constexpr int G8_DEPTH = 3;                        // DMA groups left in flight by the in-loop wait (3 or 4 are legal;
                                                    // 4 = the latest legal wait placement measured no faster: r01u)
 
@@ -88,6 +98,19 @@ constexpr int G8_DEPTH = 3;                        // DMA groups left in flight 
 // XMODE: 0 plain | 1 statistics only (TP_LINEAR_NO_STORE: no output) | 2 accumulators pre-loaded from GemmArgs::acc_init —
 // the two GEMMs of the fused LayerNorm chain; separate instantiations so that the common kernels' register budget is
 // not taxed (one more live value in the persistent loop tipped them into scratch).
+// XMODE 3 / 4: 2 + region attention in the epilogue (GemmArgs::attn_mode 1 / 2, tp_gemm_common.h), K = 1024 (nk = 16).
+//   3 (the K launch) needs the tile's queries [BM / 4 regions][256 columns] fp16 = 32 KiB (HALF: 16 KiB) in LDS when the
+//   K loop ends, and the ring is all there is.  During the LAST K-tile the buffer of K-tile nk-2 is idle: its G2 | G3 part
+//   (HALF: its G0 part) takes the queries, issued in the two phases of that K-tile that have no group of their own to issue
+//   (re-target distance 3 phases, HALF 2; the tail's waits leave them in flight).  The next tile's prologue must not land
+//   there: K-tile 0 of the next tile goes to the buffer of K-tile nk-1 instead (`ring_base` flips per tile, nk even), K-tile 1's
+//   G0 | G1 beside the queries; HALF: nk % 3 == 1 puts K-tile nk-2 in slot 2, which the prologue (slot 0, slot 1's G0 | G1)
+//   does not touch.  After the prologue one counted wait (its 12 / 10 instructions stay in flight) + a barrier publish the
+//   queries; the logits leave as 4 B per row and head, K itself is never stored.
+//   4 (the V launch) stages the tile's logits with the other epilogue parameters.
+//   Both take their epilogue parameters by LDS-DMA (one 1-KiB instruction per wave, issued with the prologue, two buffers)
+//   instead of the register-carried prefetch of the other modes: nothing rides through the epilogue in registers a
+//   compiler-inserted s_waitcnt could trip over, and the count of instructions behind the queries is the same in every wave.
 template <typename TI, typename TO, int AMODE, bool PERSIST, bool TRAIN_EPI, bool HALF = false, int XMODE = 0>
 __global__ void __launch_bounds__(512, 2)
 gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int xcd_swizzle) {
@@ -98,8 +121,19 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
     constexpr int FM = WM / 16, FN = WN / 16;          // 8 x 4 (HALF: 4 x 4) accumulator fragments per wave
     constexpr int KBUF = HALF ? 3 * G8_GROUP : G8_BUF;  // one K-tile in the ring
     constexpr int RING = HALF ? 3 * KBUF : G8_RING;     // HALF: 144 KiB (three K-tiles), else 128 KiB (two)
-    constexpr int L_PAR = RING, L_RED = RING + G8_PAR, L_NEXT = RING + G8_PAR + 8192;
-    auto ring_of = [](const int kt) __attribute__((always_inline)) -> int { if constexpr (HALF) return kt % 3; else return kt & 1; };
+    constexpr bool DMA_PAR = XMODE >= 3;                // epilogue parameters by LDS-DMA, double buffered
+    constexpr int PAR_SZ = DMA_PAR ? (HALF ? 5120 : 7168) : G8_PAR;
+    constexpr int PAR_MR = 2048, PAR_INIT = (DMA_PAR && HALF) ? 3072 : 4096, PAR_LG = HALF ? 4096 : 5120;
+    constexpr int L_PAR = RING, L_RED = RING + g8_par_bytes(HALF, XMODE), L_NEXT = L_RED + g8_red_bytes(HALF, XMODE);
+    static_assert(L_NEXT + 256 == g8_lds_bytes(HALF, true, XMODE) || !PERSIST, "LDS layout");
+    static_assert(XMODE < 3 || (PERSIST && AMODE == 0 && !TRAIN_EPI), "attention epilogues: persistent kernel, contiguous A");
+    int ring_base = 0;                                  // XMODE 3, full tiles: parity of the buffer K-tile 0 of this tile uses
+    int par_buf = 0;                                    // XMODE 3 / 4: the parameter buffer of the tile being computed
+    auto ring_of = [&](const int kt) __attribute__((always_inline)) -> int {
+        if constexpr (HALF) return kt % 3;
+        else if constexpr (XMODE == 3) return (kt ^ ring_base) & 1;
+        else return kt & 1;
+    };
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -145,6 +179,8 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
     //   W groups: rho -> tile col  (rho / 32) *  64 + sub * 32 + rho % 32     (sub = 0: G1, 1: G2)
     auto a_row_off = [&](int row) __attribute__((always_inline)) -> long long {
         if constexpr (AMODE != 0) {
+            if constexpr (AMODE == 1 || AMODE == 2)
+                if (p.a_region_s > 0) row = region_major_to_raster(row, p.a_region_g, p.a_region_s);
             const int b = row / p.rows_per_batch;
             const int t = row - b * p.rows_per_batch;
             return (long long)b * p.a_batch_stride_bytes + (long long)t * p.lda_bytes;
@@ -182,6 +218,8 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         long long a_tile_off = 0;
         if constexpr (!A_KMAJOR) {
             a_tile_off = a_row_off(m0);
+            if constexpr (AMODE == 1 || AMODE == 2)     // region-major rows scatter inside their image: address from its start
+                if (p.a_region_s > 0) a_tile_off = (long long)(m0 / p.rows_per_batch) * p.a_batch_stride_bytes;
             rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + g * p.a_gs + a_tile_off), 0, 0x7fffffff, 0x00020000);
             a_tile_off_cur = a_tile_off;
         }
@@ -198,14 +236,19 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
                 } else {
                     int row = HALF ? m0 + rho : m0 + (rho >> 6) * 128 + sub * 64 + (rho & 63);
                     row = row < p.M ? row : p.M - 1;
-                    voff_a[sub][q] = (int)(a_row_off(row) - a_tile_off) + kslot * 16;
+                    // (contiguous rows: a 24-bit multiply on purpose — row strides < 8 MiB, checked on the host.  The plain
+                    // form compiles to v_mad_u64_u32 with a don't-care high addend, for which hipcc picked the register a
+                    // parameter prefetch was still in flight to — and answered with s_waitcnt vmcnt(0) in front of every
+                    // tile's DMA prologue.)
+                    if constexpr (AMODE == 0) voff_a[sub][q] = __mul24(row - m0, (int)p.lda_bytes) + kslot * 16;
+                    else voff_a[sub][q] = (int)(a_row_off(row) - a_tile_off) + kslot * 16;
                 }
                 if constexpr (W_KMAJOR) {
                     const int wcol = (cb >> 1) * 64 + sub * 32 + (cb & 1) * 16 + (lane & 1) * 8;
                     voff_w[sub][q] = (int)(krow * ldw) + wcol * 2;
                 } else {
                     const int col = (rho >> 5) * 64 + sub * 32 + (rho & 31);
-                    voff_w[sub][q] = (int)(col * ldw) + kslot * 16;
+                    voff_w[sub][q] = __mul24(col, (int)ldw) + kslot * 16;
                 }
             }
     };
@@ -281,6 +324,34 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         } else {
             issue(I0{}, 0); issue(I1{}, 0); issue(I2{}, 0); issue(I3{}, 0);
             if (nk >= 2) { issue(I0{}, 1); issue(I1{}, 1); }
+        }
+    };
+
+    // XMODE 3: the tile's queries -> the idle part of K-tile nk-2's buffer as [region][256 columns] fp16 (512 B per region):
+    // DMA instruction q of wave w moves regions PART * 32 + 4 w + 2 q + {0, 1} (1 KiB), lane -> region + lane / 32, 16-B slot
+    // lane % 32.  (M / 4 is even — checked by gemm_launch — so a pair is inside Q or past its end as a whole.)
+    auto issue_q = [&](auto PART_) __attribute__((always_inline)) {
+        constexpr int PART = decltype(PART_)::value;
+        if constexpr (XMODE == 3) {
+            const long long row0 = m0 >> 2;
+            const unsigned long long addr = (unsigned long long)(p.attn_q + row0 * p.attn_ldq_bytes + (long long)n0 * 2);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)addr);
+            const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(addr >> 32));
+            const auto r = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+            char* dst = smem + ring_of(nk - 2) * KBUF + (HALF ? 0 : (2 + PART) * G8_GROUP) + wave * 2048;
+            // the per-lane part of the address is recomputed per tile (asm: not hoisted out of the tile loop — the K loop has
+            // no register to spare); the region pair travels in the scalar offset, clamped to the last pair of Q
+            int l = lane;
+            asm volatile("" : "+v"(l));
+            const int voff = (l >> 5) * (int)p.attn_ldq_bytes + (l & 31) * 16;
+            const int last_pair = (p.M >> 2) - 2 - (int)row0;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                int pair = PART * 32 + wave * 4 + q * 2;
+                pair = pair < last_pair ? pair : last_pair;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst + q * 1024), 16, voff,
+                                                         pair * (int)p.attn_ldq_bytes, 0, 0);
+            }
         }
     };
 
@@ -415,12 +486,12 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (XMODE == 2) {                         // accumulators start from a per-column constant (GemmArgs::acc_init)
+        if constexpr (XMODE >= 2) {                         // accumulators start from a per-column constant (GemmArgs::acc_init)
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 f32x4 dv;
                 if constexpr (PERSIST)                      // staged in LDS with the tile's other epilogue parameters
-                    dv = *(const f32x4*)(smem + L_PAR + 4096 + (wn * WN + (lane >> 4) * 4 + j * 16) * 4);
+                    dv = *(const f32x4*)(smem + L_PAR + par_buf * PAR_SZ + PAR_INIT + (wn * WN + (lane >> 4) * 4 + j * 16) * 4);
                 else
                     dv = *(const f32x4*)(p.acc_init + g * p.acc_init_gs + n0 + wn * WN + (lane >> 4) * 4 + j * 16);
 #pragma unroll
@@ -434,7 +505,9 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
             using W2_ = std::integral_constant<int, 2>; using W0_ = std::integral_constant<int, 0>;
             for (; t < nk - 2; ++t) { phase(I0{}, T_{}, WS_{}, t); phase(I1{}, T_{}, WS_{}, t); }
             phase(I0{}, T_{}, WS_{}, t); phase(I1{}, F_{}, W2_{}, t); ++t;     // tile nk-2: G2(nk-1) is the last group issued
-            phase(I0{}, F_{}, W0_{}, t); phase(I1{}, F_{}, WN_{}, t);          // tile nk-1: drain
+            if constexpr (XMODE == 3) { issue_q(I0{}); phase(I0{}, F_{}, W2_{}, t); }   // (the queries stay in flight)
+            else phase(I0{}, F_{}, W0_{}, t);                                  // tile nk-1: drain
+            phase(I1{}, F_{}, WN_{}, t);
             if (wm == 0) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             return;
@@ -452,8 +525,14 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
             phase(I3{}, F_{}, WB_{}, t);
             ++t;
         }
-        phase(I0{}, F_{}, WC_{}, t);                        // tile nk-1: drain
-        phase(I1{}, F_{}, WD_{}, t);
+        if constexpr (XMODE == 3) {                         // tile nk-1: drain; the queries go out and stay in flight
+            static_assert(G8_DEPTH == 3, "tail wait counts");
+            issue_q(I0{}); phase(I0{}, F_{}, std::integral_constant<int, 2>{}, t);
+            issue_q(I1{}); phase(I1{}, F_{}, WN_{}, t);
+        } else {
+            phase(I0{}, F_{}, WC_{}, t);                    // tile nk-1: drain
+            phase(I1{}, F_{}, WD_{}, t);
+        }
         phase(I2{}, F_{}, WN_{}, t);
         phase(I3{}, F_{}, WN_{}, t);
         if (wm == 0) __builtin_amdgcn_s_barrier();         // re-join: equal barrier counts for both halves
@@ -488,14 +567,43 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         const float* __restrict__ stats_in = (p.flags & TP_LINEAR_LN_FOLD) ? p.stats_in + g * p.stats_in_gs : nullptr;
         // every thread fetches column / row (tid & 255): no divergent control flow around the loads, nothing
         // consumes them before publish_params() — they ride out the epilogue in 4 VGPRs
-        const float* __restrict__ acc_init = (XMODE == 2) ? p.acc_init + g * p.acc_init_gs : nullptr;
+        const float* __restrict__ acc_init = (XMODE >= 2) ? p.acc_init + g * p.acc_init_gs : nullptr;
         float pf_bias = 0.f, pf_csum = 0.f, pf_init = 0.f;
         float2 pf_mr = make_float2(0.f, 1.f);
+        // XMODE 3 / 4: the parameters of the tile set up last -> parameter buffer `buf`, ONE 1-KiB DMA instruction per wave:
+        //   wave 0 bias | 1 colsum | 2 acc_init | 3 (mean, rstd) of rows 0..127 | 4 rows 128..255 (HALF: the logits, lanes
+        //   0..31 head 0, 32..63 head 1) | 5, 6 the logits of head 0 / 1 (XMODE 4, full tiles) | the others repeat wave 0's
+        auto issue_params = [&](const int buf) __attribute__((always_inline)) {
+            // (one branch per source, not one DMA fed by a select over the sources: a select between pointers loaded from the
+            // kernel-argument struct made hipcc keep the whole struct in scratch)
+            auto dma1k = [&](const char* src, long long len, const int dst, const int voff) __attribute__((always_inline)) {
+                len = len < 0 ? 0 : (len > 0x7fffffff ? 0x7fffffff : len);
+                const unsigned long long addr = (unsigned long long)src;
+                const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)addr);
+                const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(addr >> 32));
+                const int nr = __builtin_amdgcn_readfirstlane((int)len);
+                const auto r = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, nr, 0x00020000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(smem + L_PAR + buf * PAR_SZ + dst), 16, voff, 0, 0, 0);
+            };
+            const long long rows_left = (long long)p.M - m0;
+            const int lin = lane * 16;
+            if (wave == 1) dma1k((const char*)(colsum + n0), 1024, 1024, lin);
+            else if (wave == 2) dma1k((const char*)(acc_init + n0), 1024, PAR_INIT, lin);
+            else if (wave == 3) dma1k((const char*)(stats_in + (long long)m0 * 2), rows_left * 8, PAR_MR, lin);
+            else if (!HALF && wave == 4) dma1k((const char*)(stats_in + (long long)(m0 + 128) * 2), (rows_left - 128) * 8, PAR_MR + 1024, lin);
+            else if (!HALF && XMODE == 4 && (wave == 5 || wave == 6))
+                dma1k((const char*)(p.attn_logits + (long long)(n0 / 128 + (wave - 5)) * p.M + m0), rows_left * 4, PAR_LG + (wave - 5) * 1024, lin);
+            else if (HALF && XMODE == 4 && wave == 4)       // (rows past M read the neighbouring head / the workspace behind: never used)
+                dma1k((const char*)(p.attn_logits + (long long)(n0 / 128) * p.M + m0), 0x7fffffff, PAR_LG,
+                      (lane >> 5) * (p.M * 4) + (lane & 31) * 16);
+            else dma1k((const char*)(bias + n0), 1024, 0, lin);
+        };
         auto prefetch_params = [&]() __attribute__((always_inline)) {
+            if constexpr (DMA_PAR) return;
             const int e = tid & 255;
             if (bias) pf_bias = bias[n0 + e];
             if (colsum) pf_csum = colsum[n0 + e];
-            if constexpr (XMODE == 2) pf_init = acc_init[n0 + e];
+            if constexpr (XMODE >= 2) pf_init = acc_init[n0 + e];
             if (stats_in) {
                 int m = m0 + e;
                 m = m < p.M ? m : p.M - 1;
@@ -503,16 +611,18 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
             }
         };
         auto publish_params = [&]() __attribute__((always_inline)) {
+            if constexpr (DMA_PAR) return;
             float* par = (float*)(smem + L_PAR);
             if (tid < 256) {
                 par[tid] = pf_bias; par[BN + tid] = pf_csum;
-                if constexpr (XMODE == 2) par[4 * BN + tid] = pf_init;
+                if constexpr (XMODE >= 2) par[4 * BN + tid] = pf_init;
             }
             else *(float2*)(par + 2 * BN + 2 * (tid - 256)) = pf_mr;
         };
 
         setup_tile(L);
         prefetch_params();
+        if constexpr (DMA_PAR) issue_params(0);
         issue_prologue();
         // Tile order inside an XCD's run: the first round is static (workgroup i takes tile i); later tiles are drawn
         // from a per-XCD queue head, so a workgroup that starts late or shares its CU (a collective's kernels on
@@ -532,13 +642,23 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
             int Ln = L + L_step;
             if (queue) Ln = queue_base + __builtin_amdgcn_readfirstlane(*(const int*)(smem + L_NEXT));
             const bool has_next = Ln < L_end;               // wave-uniform
+            const char* lds_q = smem + ring_of(nk - 2) * KBUF + (HALF ? 0 : 2 * G8_GROUP);     // XMODE 3: where the queries are
             if (has_next) {
                 setup_tile(Ln);
+                if constexpr (XMODE == 3 && !HALF) ring_base ^= 1;
                 prefetch_params();
+                if constexpr (DMA_PAR) issue_params(par_buf ^ 1);
                 issue_prologue();
+            }
+            if constexpr (XMODE == 3) {                     // the queries have landed: all that was issued before the next tile's
+                if (has_next) wait_vmcnt<HALF ? 11 : 13>(); else wait_vmcnt<0>();     // 1 + 10 / 12 instructions has
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_sched_barrier(0);
             float2 mean_rstd[FM];
+            if constexpr (XMODE < 3)                        // (the attention epilogues read theirs row by row)
 #pragma unroll
             for (int i = 0; i < FM; ++i)
             {   // (ext_vector LDS reads: a struct-typed LDS load next to an in-flight LDS-DMA makes hipcc drain vmcnt)
@@ -546,10 +666,18 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
                 const f32x2_t v = *(const f32x2_t*)(smem + L_PAR + 2 * BN * 4 + (wm * WM + i * 16 + (lane & 15)) * 8);
                 mean_rstd[i] = make_float2(v[0], v[1]);
             }
+            if constexpr (XMODE == 3)
+                attn_logits_epilogue<BM, BN, WM, WN, true>(acc, p, g, m0c, n0c, wm, wn, lane, tid, mean_rstd, smem + L_RED,
+                                                           smem + L_PAR + par_buf * PAR_SZ, lds_q);
+            else if constexpr (XMODE == 4)
+                attn_sum_epilogue<BM, BN, WM, WN, true, PAR_LG>(acc, p, g, m0c, n0c, wm, wn, lane, mean_rstd,
+                                                                smem + L_PAR + par_buf * PAR_SZ);
+            else
             gemm_epilogue<TO, BM, BN, WM, WN, true, TRAIN_EPI, XMODE == 1>(acc, p, g, m0c, n0c, tile_nc, wm, wn, lane, tid,
                                                                            mean_rstd, smem + L_RED, smem + L_PAR);
             if (!has_next) break;
             L = Ln;
+            if constexpr (DMA_PAR) par_buf ^= 1;
             block_sync_lds();                               // everyone is done with this tile's parameters
         }
     }
@@ -579,7 +707,8 @@ int gemm8_persistent_cus() {
 template <typename TI, typename TO, int AMODE, bool PERSIST, bool TRAIN_EPI, bool HALF = false, int XMODE = 0>
 static int launch8_cfg(const GemmArgs& a, hipStream_t stream) {
     auto kern = gemm8_kernel<TI, TO, AMODE, PERSIST, TRAIN_EPI, HALF, XMODE>;
-    constexpr int lds = HALF ? 9 * G8_GROUP + G8_PAR + 8192 + 256 : (PERSIST ? G8_LDS : G8_RING);
+    constexpr int lds = g8_lds_bytes(HALF, PERSIST, XMODE);
+    static_assert(lds <= 160 * 1024, "LDS budget of a CU");
     constexpr int TBM = HALF ? G8_BM / 2 : G8_BM;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
@@ -614,6 +743,7 @@ static int launch8_var(const GemmArgs& a, hipStream_t stream) {
         set_error("tp gemm8: K-major operands are supported with fp32 output on the persistent kernel only");
         return TP_ERR_INVALID_ARG;
     }
+    const bool strided_a = a.rows_per_batch < a.M || a.a_region_s > 0;     // (region-major rows: the strided-A kernels)
     if (a.A_parts[0]) {                                // K split over four sources: the forward's first layer only
         if (a.half_tiles) { set_error("tp gemm8: half tiles do not take a multi-part A operand"); return TP_ERR_INVALID_ARG; }
         if constexpr (std::is_same<TO, f16_t>::value && PERSIST)
@@ -624,10 +754,14 @@ static int launch8_var(const GemmArgs& a, hipStream_t stream) {
     const bool half = a.half_tiles != 0;
     if ((a.flags & TP_LINEAR_NO_STORE) || a.acc_init) {       // the two GEMMs of the fused LayerNorm chain
         if constexpr (std::is_same<TI, f16_t>::value && std::is_same<TO, f16_t>::value && PERSIST) {
-            if (a.rows_per_batch < a.M || train_epi || ((a.flags & TP_LINEAR_NO_STORE) && a.acc_init) || (half && a.K < 2 * BK)) {
+            if (strided_a || train_epi || ((a.flags & TP_LINEAR_NO_STORE) && a.acc_init) || (half && a.K < 2 * BK)) {
                 set_error("tp gemm8: NO_STORE / acc_init take a contiguous A, no training epilogue, and not both at once");
                 return TP_ERR_INVALID_ARG;
             }
+            if (a.attn_mode == 1)
+                return half ? launch8_cfg<TI, TO, 0, PERSIST, false, true, 3>(a, stream) : launch8_cfg<TI, TO, 0, PERSIST, false, false, 3>(a, stream);
+            if (a.attn_mode == 2)
+                return half ? launch8_cfg<TI, TO, 0, PERSIST, false, true, 4>(a, stream) : launch8_cfg<TI, TO, 0, PERSIST, false, false, 4>(a, stream);
             if (a.flags & TP_LINEAR_NO_STORE)
                 return half ? launch8_cfg<TI, TO, 0, PERSIST, false, true, 1>(a, stream) : launch8_cfg<TI, TO, 0, PERSIST, false, false, 1>(a, stream);
             return half ? launch8_cfg<TI, TO, 0, PERSIST, false, true, 2>(a, stream) : launch8_cfg<TI, TO, 0, PERSIST, false, false, 2>(a, stream);
@@ -641,19 +775,19 @@ static int launch8_var(const GemmArgs& a, hipStream_t stream) {
     }
     if (train_epi) {
         if constexpr (HALF_OUT && PERSIST) {
-            if (half) return a.rows_per_batch < a.M ? launch8_cfg<TI, TO, 1, PERSIST, true, true>(a, stream)
+            if (half) return strided_a ? launch8_cfg<TI, TO, 1, PERSIST, true, true>(a, stream)
                                                     : launch8_cfg<TI, TO, 0, PERSIST, true, true>(a, stream);
-            return a.rows_per_batch < a.M ? launch8_cfg<TI, TO, 1, PERSIST, true>(a, stream)
+            return strided_a ? launch8_cfg<TI, TO, 1, PERSIST, true>(a, stream)
                                           : launch8_cfg<TI, TO, 0, PERSIST, true>(a, stream);
         }
         set_error("tp gemm8: training epilogues need a 16-bit output on the persistent kernel");
         return TP_ERR_INVALID_ARG;
     }
     if constexpr (PERSIST) {
-        if (half) return a.rows_per_batch < a.M ? launch8_cfg<TI, TO, 1, PERSIST, false, true>(a, stream)
+        if (half) return strided_a ? launch8_cfg<TI, TO, 1, PERSIST, false, true>(a, stream)
                                                 : launch8_cfg<TI, TO, 0, PERSIST, false, true>(a, stream);
     }
-    return a.rows_per_batch < a.M ? launch8_cfg<TI, TO, 1, PERSIST, false>(a, stream)
+    return strided_a ? launch8_cfg<TI, TO, 1, PERSIST, false>(a, stream)
                                   : launch8_cfg<TI, TO, 0, PERSIST, false>(a, stream);
 }
 
@@ -670,6 +804,10 @@ static int launch8_types(const GemmArgs& a, hipStream_t stream) {
 
 // Preconditions (checked by gemm_launch): N % 256 == 0, K % 64 == 0, (long long)N_tile_rows * K * 2 < 2^31.
 int gemm8_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream) {
+    if (a.tt_rows == 0 && (a.lda_bytes >= (1 << 23) || (a.ldw_bytes ? a.ldw_bytes : (long long)a.K * 2) >= (1 << 23))) {
+        set_error("tp gemm8: row strides must stay below 8 MiB (24-bit offset arithmetic)");
+        return TP_ERR_INVALID_ARG;
+    }
     if (in_dtype == TP_BF16) {
         if (out_dtype == TP_BF16) return launch8_types<bf16_t, bf16_t>(a, stream);
         if (out_dtype == TP_F16) return launch8_types<bf16_t, f16_t>(a, stream);

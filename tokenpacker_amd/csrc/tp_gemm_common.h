@@ -77,6 +77,16 @@ __device__ __forceinline__ f32x2_ev gelu_erf2(f32x2_ev v) {
     return __builtin_elementwise_fma(av * -0.5f, r, (v + av) * 0.5f);
 }
 
+// GemmArgs::a_region_s: region-major row index -> raster row index (reference divide_feature's grouping, builder.py:96-105)
+__device__ __forceinline__ int region_major_to_raster(int row, int g, int s) {
+    const int N = g * g, S2 = s * s, G = g / s;
+    const int b = row / N, t = row - b * N;
+    const int q = t / S2, kk = t - q * S2;
+    const int a = kk / s, c = kk - a * s;
+    const int qi = q / G, qj = q - qi * G;
+    return b * N + (qi * s + a) * g + qj * s + c;
+}
+
 constexpr int BK = 64;             // K-slab in elements
 constexpr int ROW_BYTES = BK * 2;  // 128 B of K per tile row
 
@@ -305,6 +315,171 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
                 *(float2*)so = make_float2(s1, s2);
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Region attention inside the epilogues of the K and V in-projections (GemmArgs::attn_mode; scale_factor 2).
+//
+// The rows of the operand are in region-major order (GemmArgs::a_region_s on the first K/V layer), so the s*s = 4 keys of a
+// region are 4 consecutive rows: in the accumulator layout (row = lane & 15) they are the 4 lanes of one QUAD, and with
+// ONE query per region (builder.py:122-130) attention needs nothing a quad and the two waves of a head (WN = 64, a head =
+// 128 columns) do not already hold.  K and V are therefore never written (2 x 302 MB at B = 256) nor read back by an
+// attention kernel:
+//   K launch  attn_logits_epilogue: K = LayerNorm-folded accumulators in fp32 (not rounded to fp16);  per row the partial
+//             dot product with the region's query over the lane's 16 columns, + xor 16, + xor 32 (the wave's 64 columns),
+//             + the partner wave of the head through LDS -> logit[head][row] (fp32, scaled), 4 B per row and head.
+//   V launch  attn_sum_epilogue:    p = softmax over the quad's 4 logits (every lane computes the same p in the same order),
+//             w = p_row * V, summed over the quad with two DPP quad_perm adds; lane k of the quad stores fragment j = k:
+//             O[region][cols] fp16, 8 B per lane, FM stores per wave and tile instead of FM * FN / 2 of 16 B.
+// The sums run in one fixed order whatever the tile shape (WN = 64 in every kernel), so the result does not depend on
+// the kernel a batch size selects.  `lds_q` (persistent kernel): the tile's queries [BM / 4][BN] fp16 staged in LDS;
+// `lds_par`: bias[BN] | colsum[BN] staged by the caller, and for the V launch the tile's logits [BN / 128][BM] at +LG_OFF.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, bool LDS_PARAMS>
+__device__ __forceinline__ void attn_logits_epilogue(f32x4 (&acc)[WM / 16][WN / 16], const GemmArgs& p, const int g,
+                                                     const int m0, const int n0, const int wm, const int wn,
+                                                     const int lane, const int tid, const float2 (&mean_rstd)[WM / 16],
+                                                     char* smem, const char* lds_par = nullptr, const char* lds_q = nullptr) {
+    constexpr int NWM = BM / WM, NWN = BN / WN, NW = NWM * NWN;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    static_assert(WN == 64 && BN % 128 == 0, "a head is two 64-column waves");
+    const int cg = lane >> 4, r16 = lane & 15;
+    const int col_base = n0 + wn * WN + cg * 4;
+    f32x4 bias_v[FN], csum_v[FN];
+    if constexpr (LDS_PARAMS) {
+        // (read from LDS at the point of use: 32 registers less across the epilogue of the persistent kernels)
+    } else {
+        const float* __restrict__ bias = p.bias + g * p.bias_gs;
+        const float* __restrict__ colsum = p.colsum + g * p.colsum_gs;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            bias_v[j] = *(const f32x4*)(bias + col_base + j * 16);
+            csum_v[j] = *(const f32x4*)(colsum + col_base + j * 16);
+        }
+    }
+    float part[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int rr = wm * WM + i * 16 + r16;             // row inside the tile
+        float mu = mean_rstd[i].x, rstd = mean_rstd[i].y;
+        if constexpr (LDS_PARAMS) {                        // (read per fragment row: 14 registers less across the epilogue)
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            const f32x2_t mr = *(const f32x2_t*)(lds_par + 2 * BN * 4 + rr * 8);
+            mu = mr[0]; rstd = mr[1];
+        }
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            f16x4 q;
+            if constexpr (LDS_PARAMS) {
+                q = *(const f16x4*)(lds_q + (rr >> 2) * (BN * 2) + (wn * WN + j * 16 + cg * 4) * 2);
+            } else {
+                int m = m0 + rr;
+                m = m < p.M ? m : p.M - 1;
+                q = *(const f16x4*)(p.attn_q + (long long)(m >> 2) * p.attn_ldq_bytes + (col_base + j * 16) * 2);
+            }
+            f32x4 bj, cj;
+            if constexpr (LDS_PARAMS) {
+                bj = *(const f32x4*)(lds_par + (wn * WN + cg * 4 + j * 16) * 4);
+                cj = *(const f32x4*)(lds_par + BN * 4 + (wn * WN + cg * 4 + j * 16) * 4);
+            } else { bj = bias_v[j]; cj = csum_v[j]; }
+            const f32x4 v = rstd * (acc[i][j] - mu * cj) + bj;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d = fmaf(v[r], (float)q[r], d);
+        }
+        d += __shfl_xor(d, 16);
+        d += __shfl_xor(d, 32);
+        part[i] = d;
+        __builtin_amdgcn_sched_barrier(0);                 // one fragment row at a time: the persistent kernels have no registers to spare
+    }
+    float* red = (float*)smem;                             // [NWN][BM]
+    block_sync_lds();                                      // everyone is done with the scratch / K-slab buffers
+    if (lane < 16) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) red[wn * BM + wm * WM + i * 16 + lane] = part[i];
+    }
+    block_sync_lds();
+    constexpr int HEADS = BN / 128;
+    for (int idx = tid; idx < BM * HEADS; idx += NW * 64) {
+        const int rr = idx % BM, hl = idx / BM;
+        const float lg = (red[(2 * hl) * BM + rr] + red[(2 * hl + 1) * BM + rr]) * p.attn_scale;
+        const int m = m0 + rr;
+        if (m < p.M) p.attn_logits[(long long)(n0 / 128 + hl) * p.M + m] = lg;
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool LDS_PARAMS, int LG_OFF = 0>
+__device__ __forceinline__ void attn_sum_epilogue(f32x4 (&acc)[WM / 16][WN / 16], const GemmArgs& p, const int g,
+                                                  const int m0, const int n0, const int wm, const int wn,
+                                                  const int lane, const float2 (&mean_rstd)[WM / 16],
+                                                  const char* lds_par = nullptr) {
+    constexpr int FM = WM / 16, FN = WN / 16;
+    static_assert(WN == 64 && FN == 4, "lane k of a quad stores fragment k");
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const int cg = lane >> 4, r16 = lane & 15, kq = lane & 3;
+    const int col_base = n0 + wn * WN + cg * 4;
+    const int hl = (wn * WN) / 128;                        // head inside the tile
+    // O has M / 4 rows: the hardware range check drops the stores of rows past the end (uniform store count per tile)
+    const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.C + g * p.c_gs), 0, (int)(unsigned)((long long)(p.M >> 2) * p.ldc * 2), 0x00020000);
+    f32x4 bias_v[FN], csum_v[FN];
+    if constexpr (LDS_PARAMS) {
+        // (read from LDS at the point of use: 32 registers less across the epilogue of the persistent kernels)
+    } else {
+        const float* __restrict__ bias = p.bias + g * p.bias_gs;
+        const float* __restrict__ colsum = p.colsum + g * p.colsum_gs;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            bias_v[j] = *(const f32x4*)(bias + col_base + j * 16);
+            csum_v[j] = *(const f32x4*)(colsum + col_base + j * 16);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int rr = wm * WM + i * 16 + r16;
+        const int m = m0 + rr;
+        f32x4 lg;                                          // the logits of the quad's 4 rows, this wave's head
+        if constexpr (LDS_PARAMS) {
+            lg = *(const f32x4*)(lds_par + LG_OFF + (hl * BM + (rr & ~3)) * 4);
+        } else {
+            const int mc = m < p.M ? m : p.M - 4;          // (M % 4 == 0: a quad is valid or past the end as a whole)
+            lg = *(const f32x4*)(p.attn_logits + (long long)(n0 / 128 + hl) * p.M + (mc & ~3));
+        }
+        const float mx = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+        const float e0 = __expf(lg[0] - mx), e1 = __expf(lg[1] - mx), e2 = __expf(lg[2] - mx), e3 = __expf(lg[3] - mx);
+        const float den = ((e0 + e1) + e2) + e3;
+        const float pr = (kq == 0 ? e0 : kq == 1 ? e1 : kq == 2 ? e2 : e3) / den;
+        float mu = mean_rstd[i].x, rstd = mean_rstd[i].y;
+        if constexpr (LDS_PARAMS) {
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            const f32x2_t mr = *(const f32x2_t*)(lds_par + 2 * BN * 4 + rr * 8);
+            mu = mr[0]; rstd = mr[1];
+        }
+        f32x4 mine = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            f32x4 bj, cj;
+            if constexpr (LDS_PARAMS) {
+                bj = *(const f32x4*)(lds_par + (wn * WN + cg * 4 + j * 16) * 4);
+                cj = *(const f32x4*)(lds_par + BN * 4 + (wn * WN + cg * 4 + j * 16) * 4);
+            } else { bj = bias_v[j]; cj = csum_v[j]; }
+            f32x4 w = pr * (rstd * (acc[i][j] - mu * cj) + bj);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = w[r];
+                x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+                x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+                w[r] = x;
+            }
+            if (kq == j) mine = w;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[r] = __builtin_amdgcn_fmed3f(mine[r], -65504.f, 65504.f);
+        const f16x4 o = __builtin_convertvector(mine, f16x4);
+        const long long off = ((long long)(m >> 2) * p.ldc + n0 + wn * WN + kq * 16 + cg * 4) * 2;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsrc_o, (int)(unsigned)off, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);                 // one fragment row at a time (register budget of the persistent kernels)
     }
 }
 

@@ -70,6 +70,21 @@ struct GemmArgs {
                                       // bound M and every per-row array stay those of the whole problem
     int half_tiles;                   // ping-pong kernel: 128 x 256 tiles (tp_gemm8.hip HALF) instead of 256 x 256
     int rows_per_batch;
+    int a_region_g, a_region_s;       // a_region_s > 0: the M rows are the fine tokens in REGION-MAJOR order (image, region in
+                                      // raster order of the (g/s)^2 regions, key a*s + c inside the region): row r of the result
+                                      // is computed from the raster token (qi*s + a)*g + qj*s + c of that image — the first K/V
+                                      // layer reads the tower's rows in this order so that every later per-row tensor of the
+                                      // K/V side holds a region's s*s tokens in consecutive rows (strided-A kernels only)
+    // Region attention fused into the epilogues of the K and V in-projections (scale_factor 2: a region = 4 consecutive
+    // rows of a region-major operand = one lane quad of the accumulator layout; tp_gemm_common.h attn_*_epilogue):
+    //   attn_mode 1 (the K launch): nothing of K is stored; logit[h][r] = attn_scale * K[r, head h] . Q[r / 4, head h]
+    //   attn_mode 2 (the V launch): O[r / 4, :] = sum over the region's 4 rows of softmax(logit)[r] * V[r, :] — C is O,
+    //               fp16 [M / 4, ldc]
+    int attn_mode;
+    const char* attn_q;               // attn_mode 1: fp16 queries [M / 4, attn_ldq_bytes]
+    long long attn_ldq_bytes;
+    float* attn_logits;               // fp32 [N / 128][M]  (head-major)
+    float attn_scale;
     int flags;                        // TP_LINEAR_*
     int groups;
     int tile;                         // 0 auto, 128, 256
@@ -87,8 +102,10 @@ inline int gemm_stats_parts(int N) { return N / 128; }   // one (sum, sumsq) sla
 int point_queries_launch(int dtype, const void* x, const int64_t st[3], void* q0_f16, int B, int grid,
                          int s, hipStream_t stream);
 // mask (optional, fp32): additive attn_mask — mask_mode 1: [s*s], 2: [(M B) 8, s*s] (batch index = region * B + image)
+// region_major: K / V rows are in region-major order (GemmArgs::a_region_s) instead of the tower's raster order
 int region_attention_launch(const void* q, const void* k, const void* v, void* o, int B,
-                            int grid, int s, hipStream_t stream, const float* mask = nullptr, int mask_mode = 0);      // fp16 in / fp16 out
+                            int grid, int s, hipStream_t stream, const float* mask = nullptr, int mask_mode = 0,
+                            int region_major = 0);                                                                      // fp16 in / fp16 out
 // K/V in-projections absorbed into the query side (tp_kernels.hip): qt [B*M, 8, 1024], H2 k / v [B*N, 1024] fp16 with
 // their per-row (mean, rstd) -> u [B*M, 8, 1024] fp16
 int region_attention_absorbed_launch(const void* qt, const void* h2k, const void* h2v, const float* mr_k, const float* mr_v,
