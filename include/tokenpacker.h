@@ -382,8 +382,9 @@ enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all hal
        TP_TUNE_Q_SIDE_STREAM = 5, /* 1 (default): the query side runs on a forked side stream | 0: one stream */
        TP_TUNE_DYNAMIC_TILES = 4, /* 1 (default): persistent GEMMs draw tiles from per-XCD queues | 0: static striding */
        TP_TUNE_FOLD_OUT_PROJ = 3, /* out_proj folded into mlp[0] (W = Wm0·Wout, one GEMM less): 0 (default) auto = on the absorbed
-                                     schedule only | 1 always | 2 never; read at PACK time (tp_pack_weights builds the folded
-                                     weight only then) and at forward time */
+                                     schedule and on the scale_factor-2 schedule with attention in the in-projection epilogues
+                                     (TP_TUNE_FUSE_ATTN 0) | 1 always | 2 never; read at PACK time (tp_pack_weights builds the
+                                     folded weight only then) and at forward time */
        TP_TUNE_RESERVE_CUS = 6,   /* r in 0..7 (default 0): persistent GEMMs launch (CUs/8 - r) workgroups per XCD, leaving
                                      r CUs per XCD to kernels of other streams (RCCL's all-gather overlapping the next forward) */
        TP_TUNE_ABSORB_KV = 7,     /* K/V in-projection absorbed into the query side (see tp_forward): 0 auto (scale_factor >= 3),

@@ -133,13 +133,17 @@ int validate_desc(const tp_desc* d) {
 // GEMMs over the B*576 fine tokens cost far more than the 1/s^2-sized query-side work that replaces them (at s = 2 the
 // [B M, 8, 1024] intermediates cost what the GEMMs save).  Inference only: the backward needs K and V.
 // out_proj folded into mlp[0] (W = Wm0·Wout): TP_TUNE_FOLD_OUT_PROJ 0 = auto, 1 = always, 2 = never.  Auto folds on the
-// absorbed schedule only: over the golden cases the fold moves the max-norm parity metric by its own noise — on s = 2 the
-// worst case sits at 0.984e-3 without and 0.992e-3 with it, so the 2 % stay on the table there; on s >= 3 the worst case
-// is 0.967e-3 without and 0.926e-3 with it (tools/fold_parity.py), and the fold removes a 2.25-round launch.
+// absorbed schedule and on the scale_factor-2 schedule with attention in the in-projections' epilogues: the fold removes a
+// 2.25-round launch (-2.3 % of the B = 256 forward) and moves the max-norm parity metric by its own noise — worst golden
+// case on s = 2: 0.68e-3 without, 0.79e-3 with it, rel-L2 unchanged (0.654e-3); on s >= 3: 0.967e-3 / 0.926e-3
+// (tools/fold_parity.py).  Not on the plain schedules (K and V rounded to fp16 before attention): there the worst case sat
+// at 0.984e-3 / 0.992e-3 of a 1e-3 gate.
 bool fold_out_proj(const tp_desc* d, bool train) {
     if (train) return false;                            // the backward needs A1 and the plain weights
     const int mode = tuning(TP_TUNE_FOLD_OUT_PROJ);
-    return mode == 1 || (mode == 0 && absorb_kv(d, false));
+    if (mode != 0) return mode == 1;
+    return absorb_kv(d, false) ||
+           (d->scale_factor == 2 && tuning(TP_TUNE_FUSE_KV_LN) != 0 && tuning(TP_TUNE_FUSE_ATTN) == 0);
 }
 
 bool absorb_kv(const tp_desc* d, bool train) {
@@ -295,8 +299,8 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
         if (e != hipSuccess) { set_error("tp_pack_weights: hipMemsetD32Async(status): %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
     }
     // out_proj folded into mlp[0]:  W_om = Wm0·Wout (fp32 accumulate on the MFMA kernel, rounded once to fp16),
-    // b_om = Wm0·bout + bm0 — built only when the fold is switched on AT PACK TIME (TP_TUNE_FOLD_OUT_PROJ, default off:
-    // a training step re-packs every step and must not pay for a product it never uses); status[1] records it.
+    // b_om = Wm0·bout + bm0 — built only when fold_out_proj() says so AT PACK TIME (never for a training pack: a training
+    // step re-packs every step and must not pay for a product it never uses); status[1] records it.
     if (fold_out_proj(desc, train_pack)) {
         TP_TRY(pack_transpose_f16_launch(P + L.w_out, P + L.scratch_t, (int)E, stream));
         {
@@ -718,8 +722,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     TP_TRY(region_attention_launch(ws + W.q, ws + W.kv, ws + W.kv + kvE * 2, ws + W.o, B, g, s, stream, attn_mask, mask_mode,
                                    region_major ? 1 : 0));
     TP_TRY(mark());
-    // 8. out_proj — optionally folded into mlp[0] at pack time (TP_TUNE_FOLD_OUT_PROJ, default OFF): -2 % time, same
-    //    rel-L2 error, but the max-error metric of one golden case moved from 0.92e-3 to 1.09e-3 (gate 1e-3)
+    // 8. out_proj — folded into mlp[0] at pack time where fold_out_proj() says so (TP_TUNE_FOLD_OUT_PROJ)
     const bool fold = fold_out_proj(desc, train);
     if (!fold) {
         GemmArgs a = plain_gemm(ws + W.o, E, pw + P.w_out, ws + W.a1, E, rows_q, E, E, (const float*)(pw + P.b_out), 0);

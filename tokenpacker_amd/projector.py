@@ -164,7 +164,7 @@ class TokenPacker(nn.Module):
         weights = self._named_weights()
         # pack-time tuning: the folded / pre-multiplied weights exist only if their knob was on when packing
         fold = (_capi.get_tuning(_capi.TP_TUNE_FOLD_OUT_PROJ), _capi.get_tuning(_capi.TP_TUNE_FUSE_KV_LN),
-                _capi.get_tuning(_capi.TP_TUNE_ABSORB_KV))
+                _capi.get_tuning(_capi.TP_TUNE_ABSORB_KV), _capi.get_tuning(_capi.TP_TUNE_FUSE_ATTN))
         key = (dtype, device, fold, tuple((w.data_ptr(), w._version) for w in weights))
         stream = torch.cuda.current_stream(device)
         if not force and self._packed is not None and self._packed_key == key:
