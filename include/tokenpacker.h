@@ -393,6 +393,8 @@ enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all hal
                                      only and the in-projection behind it reads that layer's INPUT through a pre-multiplied weight
                                      (K/V side on the plain schedule: Wc = W'·W2, no H2 written; query side on every schedule:
                                      W'q·Wq1, no Q1pre written) | 0: the pre-LayerNorm activations are written and read back */
+       TP_TUNE_LN_MERGE = 9,      /* 0 (default): inference, a LayerNorm's consumer on the 128-tile kernel (small batches) merges the
+                                     producer's (mean, M2) slabs itself — no ln_finalize launch | 1: always the separate launch */
        TP_TUNE_FUSE_ATTN = 10,    /* inference, scale_factor 2, fused LayerNorm chain, no attn_mask: 0 (default) the first K/V layer reads
                                      the tower's rows in REGION-MAJOR order (a region's 4 tokens = 4 consecutive rows of every K/V-side
                                      tensor) and region attention runs inside the epilogues of the K and V in-projection GEMMs — K, V

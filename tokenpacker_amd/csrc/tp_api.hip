@@ -584,13 +584,24 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         a.stats_out = (float*)(ws + W.stats_q);
         return launch(TP_F16, TP_F16, a, st);
     };
+    // Small M (the 128-tile kernel): the consumer of a LayerNorm merges the producer's (mean, M2) slabs itself — one launch
+    // less per LayerNorm on a path where, at B = 1, every launch is 6 % of the forward.  Inference only: the backward reads
+    // the (mean, rstd) buffers.
+    auto merge_in_kernel = [&](GemmArgs& a, const float* slabs, long long slabs_gs) -> bool {
+        if (train || tuning(TP_TUNE_LN_MERGE) == 1 || !gemm_uses_small_kernel(a)) return false;
+        a.stats_parts = slabs; a.stats_parts_gs = slabs_gs; a.ln_inv_dim = 1.0f / E; a.ln_eps = desc->ln_eps;
+        a.stats_in = nullptr;
+        return true;
+    };
+    static_assert(kEmbed / 128 == 8, "ln_merge_slabs<8>");
     auto q_inproj = [&](hipStream_t st) -> int {        // 6. Q = LN(Q1pre) · Winq^T + b
-        TP_TRY(ln_finalize_launch((const float*)(ws + W.stats_q), (float*)(ws + W.mr_q), rows_q, parts_q, 1, E,
-                                  desc->ln_eps, st));
         GemmArgs a = plain_gemm(fuse_q ? ws + W.q0 : ws + W.q1pre, E, fuse_q ? pw + P.w_c_q : pw + P.w_in_q, ws + W.q, E, rows_q, E, E,
                                 (const float*)(pw + P.b_in_q), TP_LINEAR_LN_FOLD);
         a.stats_in = (const float*)(ws + W.mr_q);
         a.colsum = (const float*)(pw + P.c_in_q);
+        if (!merge_in_kernel(a, (const float*)(ws + W.stats_q), 0))
+            TP_TRY(ln_finalize_launch((const float*)(ws + W.stats_q), (float*)(ws + W.mr_q), rows_q, parts_q, 1, E,
+                                      desc->ln_eps, st));
         return launch(TP_F16, TP_F16, a, st);
     };
     const bool absorb = absorb_kv(desc, train);
@@ -657,8 +668,13 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         TP_TRY(launch(TP_F16, TP_F16, a, stream));
     }
     TP_TRY(mark());
-    TP_TRY(ln_finalize_launch((const float*)(ws + W.stats_kv), (float*)(ws + W.mr_kv), rows_kv, parts_kv, 2, E,
-                              desc->ln_eps, stream));
+    bool kv_finalized = false;
+    auto kv_finalize = [&]() -> int {                   // (mean, rstd) of both K/V groups, unless the consumer merges the slabs
+        if (kv_finalized) return TP_OK;
+        kv_finalized = true;
+        return ln_finalize_launch((const float*)(ws + W.stats_kv), (float*)(ws + W.mr_kv), rows_kv, parts_kv, 2, E,
+                                  desc->ln_eps, stream);
+    };
     bool joined = false;
     auto join_side = [&]() -> int {
         if (side && !joined) {
@@ -682,6 +698,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         a.attn_q = ws + W.q; a.attn_ldq_bytes = E * 2;
         a.attn_logits = (float*)(ws + W.h2);            // [8 heads][rows_kv] fp32 (H2 is not written on this chain)
         a.attn_scale = 0.08838834764831845f;            // 1/sqrt(128): q scaling of F.multi_head_attention_forward
+        if (!merge_in_kernel(a, (const float*)(ws + W.stats_kv) + (size_t)kv * parts_kv * rows_kv * 2, 0)) TP_TRY(kv_finalize());
         return launch(TP_F16, TP_F16, a, stream);
     };
     if (fuse_attn) {
@@ -689,6 +706,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         TP_TRY(attn_gemm(0));
     } else
     if (!absorb) {
+        TP_TRY(kv_finalize());
         GemmArgs a = plain_gemm(ws + W.h2, E, pw + P.w_in_kv, ws + W.kv, E, rows_kv, E, E,
                                 (const float*)(pw + P.b_in_kv), TP_LINEAR_LN_FOLD);
         a.groups = 2; a.a_gs = kvE * 2; a.w_gs = (long long)E * E * 2; a.c_gs = kvE * 2; a.bias_gs = E;
@@ -711,6 +729,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     if (fuse_attn) {
         TP_TRY(attn_gemm(1));
     } else if (absorb) {
+        TP_TRY(kv_finalize());
         TP_TRY(region_attention_absorbed_launch(qt, ws + W.h2, ws + W.h2 + kvE * 2, (const float*)(ws + W.mr_kv),
                                                 (const float*)(ws + W.mr_kv) + (size_t)rows_kv * 2, uu, B, g, s, stream, attn_mask, mask_mode));
         // O[:, h*128:(h+1)*128] = u[:, h, :] · W'v[h*128:(h+1)*128, :]^T + b'v   (eight N = 128 groups)

@@ -132,7 +132,10 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
         if (p.flags & TP_LINEAR_LN_FOLD) {
             int m = m0 + wm * WM + i * 16 + (lane & 15);
             m = m < p.M ? m : p.M - 1;
-            mean_rstd[i] = *(const float2*)(p.stats_in + g * p.stats_in_gs + (long long)m * 2);
+            if (p.stats_parts)                          // the producer's slabs, merged here (no ln_finalize launch)
+                mean_rstd[i] = ln_merge_slabs<8>(p.stats_parts + g * p.stats_parts_gs, p.M, m, p.ln_inv_dim, p.ln_eps);
+            else
+                mean_rstd[i] = *(const float2*)(p.stats_in + g * p.stats_in_gs + (long long)m * 2);
         }
     }
 
@@ -245,6 +248,51 @@ static int launch_types(const GemmArgs& a, hipStream_t stream) {
                    : launch_cfg<TI, TO, 128, 128, 64, 64, 0>(a, stream);
 }
 
+// Where gemm_launch sends a K-contiguous problem.
+// Tile shape by a round count.  256x256 tiles are the scheduling grain of the persistent kernel: a last round that
+// fills a fraction of the chip costs a whole tile time.  When the choice is ours (no forced tile / kernel), compare
+//   (a) all full tiles, (b) the full rounds as full tiles + the remaining rows as 128x256 half tiles (a second
+//   launch over a row window), (c) all half tiles
+// with a half tile at 0.75 of a full tile's time (0.60 in a long launch; a one-round tail also pays its first tile's
+// un-hidden DMA latency) and a second launch at ~8 us (dependent-launch gap) relative to a full tile's
+// 8.4 + 1.47 K/64 us (profiles/README.md).  Same epilogue, bit-identical results whatever the shape.
+enum { ROUTE_SMALL = 0, ROUTE_G8 = 1, ROUTE_G8_HALF = 2, ROUTE_G8_SPLIT = 3 };
+static int gemm_route(const GemmArgs& a, long long* head_rows_out) {
+    const bool free_choice = a.tile == 0 && tuning(TP_TUNE_GEMM_TILE) == 0 && tuning(TP_TUNE_GEMM_KERNEL) == 0 &&
+                             a.m_begin == 0 && a.m_end == 0 && !a.half_tiles && !a.A_parts[0] && a.N % 256 == 0 && a.K >= 2 * BK;
+    if (free_choice) {
+        const int cus = gemm8_persistent_cus(), groups = a.groups > 0 ? a.groups : 1;
+        // (one group only: the workgroups of a second group start on the CUs the first group's last round leaves idle,
+        // so a grouped launch has no empty tail to fill — measured: no gain on the two-group K/V GEMMs)
+        if (groups == 1) {
+            const long long per = cus, tiles_n = a.N / 256;
+            const long long T = (long long)((a.M + 255) / 256) * tiles_n, TH = (long long)((a.M + 127) / 128) * tiles_n;
+            auto rounds = [&](long long tiles) { return (tiles + per - 1) / per; };
+            const double half = 0.75, launch = 8.0 / (8.4 + 1.47 * (a.K / BK));
+            const double cost_a = (double)rounds(T), cost_c = half * (double)rounds(TH);
+            double cost_b = 1e30;
+            long long head_rows = 0;
+            if (T > per && per % tiles_n == 0) {
+                const long long full = T / per;
+                head_rows = full * per / tiles_n * 256;
+                const long long tail_half = (long long)((a.M - head_rows + 127) / 128) * tiles_n;
+                if (head_rows < a.M) cost_b = (double)full + half * (double)rounds(tail_half) + launch;
+            }
+            if (TH >= 64 && cost_c < cost_a - 0.05 && cost_c <= cost_b) return ROUTE_G8_HALF;
+            if (cost_b < cost_a - 0.05) { *head_rows_out = head_rows; return ROUTE_G8_SPLIT; }
+        }
+    }
+    if ((a.half_tiles && a.N % 256 == 0) ||
+        (gemm_pick_tile(a.M, a.N, a.tile, a.groups) == 256 && tuning(TP_TUNE_GEMM_KERNEL) != 1))
+        return ROUTE_G8;
+    return ROUTE_SMALL;
+}
+
+bool gemm_uses_small_kernel(const GemmArgs& a) {
+    long long h = 0;
+    return a.tt_rows == 0 && gemm_route(a, &h) == ROUTE_SMALL;
+}
+
 int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.N % 128 != 0 || a.K % BK != 0) {
         set_error("tp gemm: unsupported shape M=%d N=%d K=%d (need N%%128==0, K%%64==0)", a.M, a.N, a.K);
@@ -261,7 +309,7 @@ int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stre
     }
     if (a.attn_mode) {                                  // region attention in the epilogue (tp_gemm_common.h)
         if ((a.attn_mode != 1 && a.attn_mode != 2) || in_dtype != TP_F16 || out_dtype != TP_F16 || !a.acc_init || !a.bias ||
-            !a.colsum || !a.stats_in || a.flags != TP_LINEAR_LN_FOLD || a.groups != 1 || a.M % 8 != 0 || a.K != 16 * BK ||
+            !a.colsum || (!a.stats_in && !a.stats_parts) || a.flags != TP_LINEAR_LN_FOLD || a.groups != 1 || a.M % 8 != 0 || a.K != 16 * BK ||
             !a.attn_logits || (a.attn_mode == 1 ? (!a.attn_q || (a.attn_ldq_bytes & 15)) : !a.C)) {
             set_error("tp gemm: attn_mode needs fp16 operands, the LayerNorm-fold operands with acc_init, one group, K = 1024, M %% 8 == 0");
             return TP_ERR_INVALID_ARG;
@@ -283,49 +331,26 @@ int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stre
         set_error("tp gemm: bad row window [%d, %d) of %d rows", a.m_begin, a.m_end, a.M);
         return TP_ERR_INVALID_ARG;
     }
-    // Tile shape by a round count.  256x256 tiles are the scheduling grain of the persistent kernel: a last round that
-    // fills a fraction of the chip costs a whole tile time.  When the choice is ours (no forced tile / kernel), compare
-    //   (a) all full tiles, (b) the full rounds as full tiles + the remaining rows as 128x256 half tiles (a second
-    //   launch over a row window), (c) all half tiles
-    // with a half tile at 0.75 of a full tile's time (0.60 in a long launch; a one-round tail also pays its first tile's
-    // un-hidden DMA latency) and a second launch at ~8 us (dependent-launch gap) relative to a full tile's
-    // 8.4 + 1.47 K/64 us (profiles/README.md).  Same epilogue, bit-identical results whatever the shape.
-    const bool free_choice = a.tile == 0 && tuning(TP_TUNE_GEMM_TILE) == 0 && tuning(TP_TUNE_GEMM_KERNEL) == 0 &&
-                             a.m_begin == 0 && a.m_end == 0 && !a.half_tiles && !a.A_parts[0] && a.N % 256 == 0 && a.K >= 2 * BK;
-    if (free_choice) {
-        const int cus = gemm8_persistent_cus(), groups = a.groups > 0 ? a.groups : 1;
-        // (one group only: the workgroups of a second group start on the CUs the first group's last round leaves idle,
-        // so a grouped launch has no empty tail to fill — measured: no gain on the two-group K/V GEMMs)
-        if (groups == 1) {
-            const long long per = cus, tiles_n = a.N / 256;
-            const long long T = (long long)((a.M + 255) / 256) * tiles_n, TH = (long long)((a.M + 127) / 128) * tiles_n;
-            auto rounds = [&](long long tiles) { return (tiles + per - 1) / per; };
-            const double half = 0.75, launch = 8.0 / (8.4 + 1.47 * (a.K / BK));
-            const double cost_a = (double)rounds(T), cost_c = half * (double)rounds(TH);
-            double cost_b = 1e30;
-            long long head_rows = 0;
-            if (T > per && per % tiles_n == 0) {
-                const long long full = T / per;
-                head_rows = full * per / tiles_n * 256;
-                const long long tail_half = (long long)((a.M - head_rows + 127) / 128) * tiles_n;
-                if (head_rows < a.M) cost_b = (double)full + half * (double)rounds(tail_half) + launch;
-            }
-            if (TH >= 64 && cost_c < cost_a - 0.05 && cost_c <= cost_b) {
-                GemmArgs h = a; h.half_tiles = 1;
-                return gemm8_launch(in_dtype, out_dtype, h, stream);
-            }
-            if (cost_b < cost_a - 0.05) {
-                GemmArgs head = a, rest = a;
-                head.m_end = (int)head_rows;
-                rest.m_begin = (int)head_rows; rest.half_tiles = 1; rest.tile_counters = nullptr;
-                if (int rc = gemm8_launch(in_dtype, out_dtype, head, stream)) return rc;
-                return gemm8_launch(in_dtype, out_dtype, rest, stream);
-            }
+    {
+        long long head_rows = 0;
+        const int route = gemm_route(a, &head_rows);
+        if (a.stats_parts && route != ROUTE_SMALL) {
+            set_error("tp gemm: stats_parts (in-kernel LayerNorm merge) is served by the 128-tile kernel only (see gemm_uses_small_kernel)");
+            return TP_ERR_INVALID_ARG;
         }
+        if (route == ROUTE_G8_HALF) {
+            GemmArgs h = a; h.half_tiles = 1;
+            return gemm8_launch(in_dtype, out_dtype, h, stream);
+        }
+        if (route == ROUTE_G8_SPLIT) {
+            GemmArgs head = a, rest = a;
+            head.m_end = (int)head_rows;
+            rest.m_begin = (int)head_rows; rest.half_tiles = 1; rest.tile_counters = nullptr;
+            if (int rc = gemm8_launch(in_dtype, out_dtype, head, stream)) return rc;
+            return gemm8_launch(in_dtype, out_dtype, rest, stream);
+        }
+        if (route == ROUTE_G8) return gemm8_launch(in_dtype, out_dtype, a, stream);
     }
-    if ((a.half_tiles && a.N % 256 == 0) ||
-        (gemm_pick_tile(a.M, a.N, a.tile, a.groups) == 256 && tuning(TP_TUNE_GEMM_KERNEL) != 1))
-        return gemm8_launch(in_dtype, out_dtype, a, stream);
     if (in_dtype == TP_BF16) {
         if (out_dtype == TP_BF16) return launch_types<bf16_t, bf16_t>(a, stream);
         if (out_dtype == TP_F16) return launch_types<bf16_t, f16_t>(a, stream);

@@ -38,6 +38,11 @@ struct GemmArgs {
     const char* A; const char* W; char* C;
     const float* bias;
     const float* stats_in;            // LN_FOLD: per-row (mean, rstd) [M][2]
+    // LN_FOLD on the 128-tile kernel (small M: every launch on the critical path counts): instead of (mean, rstd) from a
+    // separate ln_finalize launch, the producing GEMM's (mean, M2) slabs [8][M][2] — merged per row by the kernel itself
+    // with ln_merge_slabs(), the very code ln_finalize runs (same bits).  gemm_uses_small_kernel() tells the caller
+    // whether a launch takes that route.
+    const float* stats_parts; long long stats_parts_gs; float ln_inv_dim, ln_eps;
     const float* colsum; float* stats_out;
     const float* acc_init;            // optional fp32 [N]: initial value of the accumulators per output column (a constant row
                                       // vector added BEFORE the LayerNorm fold: rstd·(A·W^T + acc_init − mu·colsum) + bias)
@@ -90,6 +95,26 @@ struct GemmArgs {
     int tile;                         // 0 auto, 128, 256
 };
 int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream);
+bool gemm_uses_small_kernel(const GemmArgs& a);        // whether gemm_launch would run `a` on the 128-tile kernel (tp_gemm.hip)
+
+// LayerNorm statistics of one row from the producing GEMM's NPARTS (mean, M2) slabs of 128 columns each ([NPARTS][M][2];
+// M2 = sum of squared deviations from the slab's own mean): Chan's merge in slab order -> (mean, rstd) of nn.LayerNorm
+// (biased variance).  All slabs are fetched before any is used (independent loads in flight).  Used by ln_finalize_kernel
+// and by the 128-tile GEMM's LN-fold prologue: one arithmetic, identical bits.
+template <int NPARTS>
+__device__ __forceinline__ float2 ln_merge_slabs(const float* __restrict__ pg, long long M, long long m, float inv_dim, float eps) {
+    float2 st[NPARTS];
+#pragma unroll
+    for (int pp = 0; pp < NPARTS; ++pp) st[pp] = *(const float2*)(pg + ((long long)pp * M + m) * 2);
+    float s1 = 0.f, q = 0.f, between = 0.f;
+#pragma unroll
+    for (int pp = 0; pp < NPARTS; ++pp) { s1 += st[pp].x; q += st[pp].y; }
+    const float mu = s1 / (float)NPARTS;                        // slabs are equally sized (128 columns each)
+#pragma unroll
+    for (int pp = 0; pp < NPARTS; ++pp) { const float d = st[pp].x - mu; between = fmaf(d, d, between); }
+    const float var = (q + 128.0f * between) * inv_dim;         // biased variance (nn.LayerNorm); >= 0 by construction
+    return make_float2(mu, 1.0f / sqrtf(var + eps));
+}
 int gemm_pick_tile(int M, int N, int forced, int groups = 1);     // -> 128 or 256
 // 256x256x64 ping-pong kernel (tp_gemm8.hip); gemm_launch routes tile-256 problems to it
 int gemm8_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream);

@@ -537,17 +537,11 @@ ln_finalize_kernel(const float* __restrict__ parts, float* __restrict__ mean_rst
     const int g = blockIdx.y;
     if (m >= M) return;
     const float* pg = parts + (long long)g * nparts * M * 2;
-    float s1 = 0.f, q = 0.f, between = 0.f, mu;
     if constexpr (NPARTS > 0) {
-        float2 st[NPARTS];
-#pragma unroll
-        for (int pp = 0; pp < NPARTS; ++pp) st[pp] = *(const float2*)(pg + ((long long)pp * M + m) * 2);
-#pragma unroll
-        for (int pp = 0; pp < NPARTS; ++pp) { s1 += st[pp].x; q += st[pp].y; }
-        mu = s1 / (float)NPARTS;                                // slabs are equally sized (128 columns each)
-#pragma unroll
-        for (int pp = 0; pp < NPARTS; ++pp) { const float d = st[pp].x - mu; between = fmaf(d, d, between); }
+        *(float2*)(mean_rstd + ((long long)g * M + m) * 2) = ln_merge_slabs<NPARTS>(pg, M, m, inv_dim, eps);
+        return;
     } else {
+        float s1 = 0.f, q = 0.f, between = 0.f, mu;
         for (int pp = 0; pp < nparts; ++pp) {
             const float2 st = *(const float2*)(pg + ((long long)pp * M + m) * 2);
             s1 += st.x; q += st.y;
@@ -557,9 +551,9 @@ ln_finalize_kernel(const float* __restrict__ parts, float* __restrict__ mean_rst
             const float d = pg[((long long)pp * M + m) * 2] - mu;
             between = fmaf(d, d, between);
         }
+        const float var = (q + 128.0f * between) * inv_dim;    // biased variance (nn.LayerNorm); >= 0 by construction
+        *(float2*)(mean_rstd + ((long long)g * M + m) * 2) = make_float2(mu, 1.0f / sqrtf(var + eps));
     }
-    const float var = (q + 128.0f * between) * inv_dim;        // biased variance (nn.LayerNorm); >= 0 by construction
-    *(float2*)(mean_rstd + ((long long)g * M + m) * 2) = make_float2(mu, 1.0f / sqrtf(var + eps));
 }
 
 int ln_finalize_launch(const float* parts, float* mean_rstd, long long M, int nparts, int groups, int ln_dim,
