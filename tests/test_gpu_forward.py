@@ -327,6 +327,37 @@ def test_attention_in_the_inprojection_epilogues_is_the_same_function(dtype, B):
             assert torch.equal(y, ys[0]), (key, val)
 
 
+@pytest.mark.parametrize("B,D", [(1, 4096), (2, 4096), (3, 4096)])
+def test_split_k_for_small_batches_is_the_same_function(B, D):
+    """TP_TUNE_SPLIT_K = 1 (opt-in): the two K = 4096 GEMMs of a small batch as K-groups with fp32 partials + a fixed-order
+    reduction.  Not the summation order of the unsplit kernels (so not bit-identical to them), deterministic, and within
+    the gate of the fp64 oracle at the same error level."""
+    from tokenpacker_amd import _capi
+    dtype, s = torch.bfloat16, 2
+    params = synth.make_params(205, D)
+    x, xm = synth.make_inputs(206, B, dtype)
+    p_lp = {k: v.to(dtype) for k, v in params.items()}
+    y_exact = orc.forward(p_lp, x, xm, scale_factor=s, compute_dtype=torch.float64, io_dtype=dtype)
+    ys = {}
+    try:
+        for mode in (0, 1, 1):
+            _capi.set_tuning(_capi.TP_TUNE_SPLIT_K, mode)
+            m = _module(params, s, D, dtype)
+            m.output_fp32 = True
+            with torch.no_grad():
+                ys.setdefault(mode, []).append(m((x.cuda(), xm.cuda())))
+            torch.cuda.synchronize()
+    finally:
+        _capi.set_tuning(_capi.TP_TUNE_SPLIT_K, 0)
+    e0, e1 = orc.rel_err(ys[0][0], y_exact), orc.rel_err(ys[1][0], y_exact)
+    l0, l1 = orc.rel_l2(ys[0][0], y_exact), orc.rel_l2(ys[1][0], y_exact)
+    print(f"\n[parity] split-K B={B} D={D}: unsplit rel_err {e0:.3e} (l2 {l0:.3e}), split {e1:.3e} (l2 {l1:.3e})")
+    assert torch.equal(ys[1][0], ys[1][1]), "fixed-order reduction: deterministic"
+    assert not torch.equal(ys[0][0], ys[1][0])              # the knob really switches the path
+    assert e0 <= 1e-3 and e1 <= 1e-3, (e0, e1)
+    assert l1 <= 1.05 * l0 + 1e-5
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B", [2, 9])
 def test_fused_layernorm_chain_is_the_same_function(dtype, B):

@@ -40,7 +40,7 @@ int check_launch(const char* what) {
     return TP_OK;
 }
 
-static std::atomic<int> g_tuning[TP_TUNE_COUNT_] = {{0}, {1}, {0}, {0}, {1}, {1}, {0}, {0}, {1}, {0}, {0}, {0}};   // [6] RESERVE_CUS, [7] ABSORB_KV, [8] FUSE_KV_LN
+static std::atomic<int> g_tuning[TP_TUNE_COUNT_] = {{0}, {1}, {0}, {0}, {1}, {1}, {0}, {0}, {1}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};   // [6] RESERVE_CUS, [7] ABSORB_KV, [8] FUSE_KV_LN
 int tuning(int key) { return (key >= 0 && key < TP_TUNE_COUNT_) ? g_tuning[key].load() : 0; }
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
@@ -91,6 +91,7 @@ WorkspaceLayout workspace_layout(int B, int grid, int s, int D, bool train) {
     L.a1 = take(rows_q * E * 2);
     L.a2 = take(rows_q * (size_t)D * 2);
     L.counters = take(4096);
+    L.splitk = take(B <= 8 ? kSplitKBytes : 0);
     L.z1 = L.z2 = 0;
     if (train) { L.z1 = take(rows_kv * 2 * E * 2); L.z2 = take(rows_q * (size_t)D * 2); }
     L.total = off;
@@ -166,6 +167,7 @@ GemmArgs plain_gemm(const void* A, long long lda_elems, const void* W, void* C, 
 }  // namespace tp
 
 using namespace tp;
+static constexpr int BK_ELEMS = 64;                  // K-slab of the GEMM kernels (tp_gemm_common.h BK)
 
 extern "C" {
 
@@ -573,6 +575,24 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         a.tile_counters = counters ? counters + 64 * launch_no++ : nullptr;      // [groups <= 8][8 XCDs] heads per launch
         return gemm_launch(in_dt, out_dt, a, st);
     };
+    // TP_TUNE_SPLIT_K: a latency-bound K = 4096 GEMM of a small batch as S K-groups of the 128-tile kernel (fp32 partials)
+    // + one reduction kernel that applies the epilogue.  `a` is the un-split launch (bias, GELU flag, destination).
+    auto launch_maybe_splitk = [&](int in_dt, int out_dt, GemmArgs& a, hipStream_t st) -> int {
+        const long long tiles = (long long)((a.M + 127) / 128) * (a.N / 128);
+        int S = 1;
+        if (tuning(TP_TUNE_SPLIT_K) == 1 && !train && B <= 8 && !a.A_parts[0] && a.groups == 1 && (a.flags & ~TP_LINEAR_GELU) == 0)
+            while (S < 8 && tiles * (S * 2) <= 512 && a.K / (S * 2) >= 4 * BK_ELEMS && a.K % (S * 2 * BK_ELEMS) == 0) S *= 2;
+        if (S < 4) return launch(in_dt, out_dt, a, st);    // (two K-groups do not pay for the partials' round trip: measured)
+        GemmArgs p = a;
+        p.groups = S; p.K = a.K / S;
+        p.a_gs = (long long)p.K * 2; p.w_gs = (long long)p.K * 2;
+        p.ldw_bytes = a.ldw_bytes ? a.ldw_bytes : (long long)a.K * 2;
+        p.C = ws + W.splitk; p.ldc = a.N; p.c_gs = (long long)a.M * a.N * 4;
+        p.bias = nullptr; p.flags = 0; p.tile = 128;
+        TP_TRY(launch(in_dt, TP_F32, p, st));
+        return splitk_reduce_launch((const float*)(ws + W.splitk), S, a.M, a.N, a.bias, (a.flags & TP_LINEAR_GELU) ? 1 : 0, a.C, a.ldc,
+                                    out_dt, st);
+    };
     // query side on a side stream (not when the caller wants per-stage events: those need one stream)
     SideCtx* side = (tuning(TP_TUNE_Q_SIDE_STREAM) && !stage_events) ? side_ctx_for(stream) : nullptr;
     const int parts_q = gemm_stats_parts(E);
@@ -655,7 +675,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
             for (int i = 0; i < 4; ++i) a.A_parts[i] = (const char*)xm_parts[i];
             a.k_part = kMulti / 4;
         }
-        TP_TRY(launch(dt, TP_F16, a, stream));      // raw operands in the io dtype, fp16 activations out
+        TP_TRY(launch_maybe_splitk(dt, TP_F16, a, stream));      // raw operands in the io dtype, fp16 activations out
     }
     // 3. H2[g] = Hkv[:, g*1024:(g+1)*1024] · W{k,v}2^T + b, and LayerNorm partials of H2
     TP_TRY(mark());
@@ -760,7 +780,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     {
         GemmArgs a = plain_gemm(ws + W.a2, D, pw + P.w_m2, out, D, rows_q, D, D, (const float*)(pw + P.b_m2),
                                 0);
-        TP_TRY(launch(TP_F16, desc->out_dtype, a, stream));
+        TP_TRY(launch_maybe_splitk(TP_F16, desc->out_dtype, a, stream));
     }
     TP_TRY(mark());
     return TP_OK;

@@ -108,6 +108,9 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
     const int frag_off0 = (lane & 15) * ROW_BYTES + ((((lane >> 4)) ^ (lane & 7)) << 4);
     const int frag_off1 = (lane & 15) * ROW_BYTES + (((4 + (lane >> 4)) ^ (lane & 7)) << 4);
 
+    // the first K-slabs go out before anything else touches memory: the parameter loads below then wait WITH them
+    const int nk = p.K / BK;
+    issue(0, 0);
     f32x4 acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -124,23 +127,33 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
     }
 
     // LayerNorm-fold operands (per-row mean, rstd) do not depend on the contraction: fetch them now so
-    // their latency hides under the whole K loop instead of serialising the epilogue.
+    // their latency hides under the K loop instead of serialising the epilogue.
     float2 mean_rstd[FM];
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        mean_rstd[i] = make_float2(0.f, 1.f);
-        if (p.flags & TP_LINEAR_LN_FOLD) {
-            int m = m0 + wm * WM + i * 16 + (lane & 15);
-            m = m < p.M ? m : p.M - 1;
-            if (p.stats_parts)                          // the producer's slabs, merged here (no ln_finalize launch)
-                mean_rstd[i] = ln_merge_slabs<8>(p.stats_parts + g * p.stats_parts_gs, p.M, m, p.ln_inv_dim, p.ln_eps);
-            else
+    for (int i = 0; i < FM; ++i) mean_rstd[i] = make_float2(0.f, 1.f);
+    if (p.flags & TP_LINEAR_LN_FOLD) {
+        if (p.stats_parts) {                            // the producer's slabs, merged here (no ln_finalize launch):
+            float2 st[FM][8];                           // every load of every row first, ONE wait, then the arithmetic
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                int m = m0 + wm * WM + i * 16 + (lane & 15);
+                m = m < p.M ? m : p.M - 1;
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp)
+                    st[i][pp] = *(const float2*)(p.stats_parts + g * p.stats_parts_gs + ((long long)pp * p.M + m) * 2);
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) mean_rstd[i] = ln_merge_values<8>(st[i], p.ln_inv_dim, p.ln_eps);
+        } else {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                int m = m0 + wm * WM + i * 16 + (lane & 15);
+                m = m < p.M ? m : p.M - 1;
                 mean_rstd[i] = *(const float2*)(p.stats_in + g * p.stats_in_gs + (long long)m * 2);
+            }
         }
     }
 
-    const int nk = p.K / BK;
-    issue(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         // slab kt has landed for every wave; every wave is done reading the other buffer
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -183,8 +196,17 @@ int gemm_pick_tile(int M, int N, int forced, int groups) {
     return tiles256 >= 200 ? 256 : 128;     // the persistent 256-tile kernel from ~0.8 of a CU round up, else finer tiles
 }
 
-template <typename TI, typename TO, int BM, int BN, int WM, int WN, int AMODE, bool TRAIN_EPI = false, int XMODE = 0>
+// The 128 x 128 tile exists as 4 waves of 64 x 64 (two workgroups = 8 waves per CU) and as 8 waves of 32 x 64 (16 waves per CU):
+// a launch that leaves most CUs with ONE workgroup (a small batch) runs one wave per SIMD with the first and hides neither
+// its LDS nor its barrier latency.  Same MFMA shape, same K order: bit-identical.  WIDE selects the 8-wave form.
+template <typename TI, typename TO, int BM, int BN, int WM, int WN, int AMODE, bool TRAIN_EPI = false, int XMODE = 0, bool WIDE = false>
 static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
+    if constexpr (!WIDE && BM == 128 && BN == 128 && WM == 64 && WN == 64) {
+        const long long wgs = (long long)((a.M + BM - 1) / BM) * (a.N / BN) * (a.groups > 0 ? a.groups : 1);
+        const int mode = tuning(TP_TUNE_SMALL_GEMM_WAVES);
+        if (mode == 8 || (mode == 0 && wgs <= 512))
+            return launch_cfg<TI, TO, BM, BN, 32, 64, AMODE, TRAIN_EPI, XMODE, true>(a, stream);
+    }
     constexpr int lds = gemm_lds_bytes<BM, BN>();
     constexpr int threads = (BM / WM) * (BN / WN) * 64;
     auto kern = gemm_kernel<TI, TO, BM, BN, WM, WN, AMODE, TRAIN_EPI, XMODE>;
@@ -253,7 +275,7 @@ static int launch_types(const GemmArgs& a, hipStream_t stream) {
 // fills a fraction of the chip costs a whole tile time.  When the choice is ours (no forced tile / kernel), compare
 //   (a) all full tiles, (b) the full rounds as full tiles + the remaining rows as 128x256 half tiles (a second
 //   launch over a row window), (c) all half tiles
-// with a half tile at 0.75 of a full tile's time (0.60 in a long launch; a one-round tail also pays its first tile's
+// with a half tile at 0.75 of a full tile's time (0.63 at K <= 1024; a one-round tail also pays its first tile's
 // un-hidden DMA latency) and a second launch at ~8 us (dependent-launch gap) relative to a full tile's
 // 8.4 + 1.47 K/64 us (profiles/README.md).  Same epilogue, bit-identical results whatever the shape.
 enum { ROUTE_SMALL = 0, ROUTE_G8 = 1, ROUTE_G8_HALF = 2, ROUTE_G8_SPLIT = 3 };
@@ -268,7 +290,9 @@ static int gemm_route(const GemmArgs& a, long long* head_rows_out) {
             const long long per = cus, tiles_n = a.N / 256;
             const long long T = (long long)((a.M + 255) / 256) * tiles_n, TH = (long long)((a.M + 127) / 128) * tiles_n;
             auto rounds = [&](long long tiles) { return (tiles + per - 1) / per; };
-            const double half = 0.75, launch = 8.0 / (8.4 + 1.47 * (a.K / BK));
+            // (half-tile time over full-tile time: 18.3 / 29 us measured at K = 1024 — the fixed per-tile cost halves with
+            // the tile —, 0.75 for the long K loops; profiles/README.md)
+            const double half = a.K <= 1024 ? 0.63 : 0.75, launch = 8.0 / (8.4 + 1.47 * (a.K / BK));
             const double cost_a = (double)rounds(T), cost_c = half * (double)rounds(TH);
             double cost_b = 1e30;
             long long head_rows = 0;

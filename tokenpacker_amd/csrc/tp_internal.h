@@ -102,10 +102,7 @@ bool gemm_uses_small_kernel(const GemmArgs& a);        // whether gemm_launch wo
 // (biased variance).  All slabs are fetched before any is used (independent loads in flight).  Used by ln_finalize_kernel
 // and by the 128-tile GEMM's LN-fold prologue: one arithmetic, identical bits.
 template <int NPARTS>
-__device__ __forceinline__ float2 ln_merge_slabs(const float* __restrict__ pg, long long M, long long m, float inv_dim, float eps) {
-    float2 st[NPARTS];
-#pragma unroll
-    for (int pp = 0; pp < NPARTS; ++pp) st[pp] = *(const float2*)(pg + ((long long)pp * M + m) * 2);
+__device__ __forceinline__ float2 ln_merge_values(const float2 (&st)[NPARTS], float inv_dim, float eps) {
     float s1 = 0.f, q = 0.f, between = 0.f;
 #pragma unroll
     for (int pp = 0; pp < NPARTS; ++pp) { s1 += st[pp].x; q += st[pp].y; }
@@ -115,6 +112,14 @@ __device__ __forceinline__ float2 ln_merge_slabs(const float* __restrict__ pg, l
     const float var = (q + 128.0f * between) * inv_dim;         // biased variance (nn.LayerNorm); >= 0 by construction
     return make_float2(mu, 1.0f / sqrtf(var + eps));
 }
+template <int NPARTS>
+__device__ __forceinline__ float2 ln_merge_slabs(const float* __restrict__ pg, long long M, long long m, float inv_dim, float eps) {
+    float2 st[NPARTS];
+#pragma unroll
+    for (int pp = 0; pp < NPARTS; ++pp) st[pp] = *(const float2*)(pg + ((long long)pp * M + m) * 2);
+    return ln_merge_values<NPARTS>(st, inv_dim, eps);
+}
+
 int gemm_pick_tile(int M, int N, int forced, int groups = 1);     // -> 128 or 256
 // 256x256x64 ping-pong kernel (tp_gemm8.hip); gemm_launch routes tile-256 problems to it
 int gemm8_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream);
@@ -182,11 +187,18 @@ PackedLayout packed_layout(int D);
 struct WorkspaceLayout {
     size_t q0, hkv, h2, stats_kv, mr_kv, kv, q1pre, stats_q, mr_q, q, o, a1, a2;
     size_t counters;              // zeroed once per forward: tile-queue heads of the persistent GEMM launches
+    size_t splitk;                // small batches: fp32 partial results of a K-split GEMM (TP_TUNE_SPLIT_K), kSplitKBytes
     size_t z1, z2;                // training forward only: fp16 pre-GELU activations [B*N, 2048], [B*M, D]
     size_t total;
     int stats_parts_kv, stats_parts_q;
 };
 WorkspaceLayout workspace_layout(int B, int grid, int s, int D, bool train = false);
+// K-split of a latency-bound GEMM (TP_TUNE_SPLIT_K): S * tiles <= 512 workgroups of 128 x 128 (two per CU) -> at most
+// 512 * 128 * 128 fp32 partial values
+constexpr size_t kSplitKBytes = (size_t)512 * 128 * 128 * 4;
+// out[m, n] = epilogue(sum over the S partials [S][M][N] fp32, in split order): + bias, optional erf GELU, cast to out_dtype
+int splitk_reduce_launch(const float* partials, int S, int M, int N, const float* bias, int gelu, void* out, long long ldc,
+                         int out_dtype, hipStream_t stream);
 
 // ---- backward helpers (tp_bwd.hip) -------------------------------------------------------------
 int bw_transpose_launch(int src_dtype, int dst_dtype, const void* src, long long ld, int rows_per_batch,

@@ -567,6 +567,57 @@ int ln_finalize_launch(const float* parts, float* mean_rstd, long long M, int np
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Second half of a K-split GEMM (TP_TUNE_SPLIT_K, small batches): the S fp32 partial products [S][M][N] of the 128-tile
+// kernel's grouped launch are summed in split order (deterministic; NOT the summation order of the unsplit kernels), then
+// bias, the erf GELU of tp_gemm_common.h, fp16 saturation and the cast — what the fused epilogue would have done.
+} // namespace tp
+#include "tp_gemm_common.h"
+namespace tp {
+template <typename TO>
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const float* __restrict__ part, int S, long long MN, int N, const float* __restrict__ bias, int gelu,
+                     TO* __restrict__ out, long long ldc) {
+    const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= MN) return;
+    const long long m = i4 / N;
+    const int n = (int)(i4 - m * N);
+    f32x4 acc = *(const f32x4*)(part + i4);
+    for (int sp = 1; sp < S; ++sp) acc += *(const f32x4*)(part + (long long)sp * MN + i4);
+    if (bias) acc += *(const f32x4*)(bias + n);
+    if (gelu) {
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+            const f32x2_ev gv = gelu_erf2(f32x2_ev{acc[r], acc[r + 1]});
+            acc[r] = gv[0]; acc[r + 1] = gv[1];
+        }
+    }
+    TO* o = out + m * ldc + n;
+    if constexpr (std::is_same<TO, float>::value) {
+        *(f32x4*)o = acc;
+    } else {
+        if constexpr (std::is_same<TO, f16_t>::value) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = __builtin_amdgcn_fmed3f(acc[r], -65504.f, 65504.f);
+        }
+        using O4 = typename Vec<TO>::x4;
+        *(O4*)o = __builtin_convertvector(acc, O4);
+    }
+}
+
+int splitk_reduce_launch(const float* partials, int S, int M, int N, const float* bias, int gelu, void* out, long long ldc,
+                         int out_dtype, hipStream_t stream) {
+    const long long MN = (long long)M * N;
+    const unsigned blocks = (unsigned)((MN / 4 + 255) / 256);
+    if (out_dtype == TP_F16)
+        hipLaunchKernelGGL(splitk_reduce_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream, partials, S, MN, N, bias, gelu, (f16_t*)out, ldc);
+    else if (out_dtype == TP_BF16)
+        hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, partials, S, MN, N, bias, gelu, (bf16_t*)out, ldc);
+    else
+        hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, partials, S, MN, N, bias, gelu, (float*)out, ldc);
+    return check_launch("splitk_reduce_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------
 // One-time weight preparation.
 template <typename T>
 __global__ void pack_cast_f32_kernel(const T* __restrict__ src, float* __restrict__ dst, int n) {
