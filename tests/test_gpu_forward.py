@@ -425,10 +425,12 @@ def test_attn_mask_is_honoured(s, dtype):
             assert orc.rel_err(y, torch.from_numpy(z[key])) < (3e-2 if dtype == torch.bfloat16 else 4e-3), key   # vs the REAL reference
 
 
-@pytest.mark.parametrize("grid,s", [(24, 1), (24, 6), (24, 8), (24, 12), (24, 24), (16, 4), (12, 3), (8, 2)])
+@pytest.mark.parametrize("grid,s", [(24, 1), (24, 6), (24, 8), (24, 12), (24, 24), (16, 4), (12, 3), (8, 2), (16, 2), (12, 2), (6, 2)])
 def test_whole_path_other_scale_factors_and_grids(grid, s):
     """Every scale factor dividing the grid, on every schedule: s = 1, 2 plain (fused LayerNorm chain), s = 3 … 8 absorbed
-    (s*s <= 64 keys per region live in LDS), s = 12, 24 plain again (144 / 576 keys: online softmax); other raw grids."""
+    (s*s <= 64 keys per region live in LDS), s = 12, 24 plain again (144 / 576 keys: online softmax); other raw grids —
+    s = 2 on grids 16, 12, 8 runs attention in the in-projection epilogues, on grid 6 (36 tokens per image: not a multiple of
+    8) the separate attention kernel."""
     dtype, D, B = torch.float16, 256, 2
     params = synth.make_params(200 + s, D)
     g = torch.Generator().manual_seed(300 + grid + s)

@@ -377,7 +377,7 @@ int tp_debug_count_saturated(const tp_desc* desc, const void* workspace, size_t 
         {W.h2, (!absorb_kv(desc, false) && tuning(TP_TUNE_FUSE_KV_LN) != 0) ? 0 : 2 * rows_kv * E},   // (fused chain: H2 is never written)
         // (attention in the in-projections' epilogues, TP_TUNE_FUSE_ATTN: K | V are never written.  The mask-less forward is assumed.)
         {W.kv, absorb_kv(desc, false) ? 2 * rows_q * 8 * E
-               : (s == 2 && tuning(TP_TUNE_FUSE_KV_LN) != 0 && tuning(TP_TUNE_FUSE_ATTN) == 0) ? 0 : 2 * rows_kv * E},
+               : (s == 2 && (g * g) % 8 == 0 && tuning(TP_TUNE_FUSE_KV_LN) != 0 && tuning(TP_TUNE_FUSE_ATTN) == 0) ? 0 : 2 * rows_kv * E},
         {W.q1pre, tuning(TP_TUNE_FUSE_KV_LN) != 0 ? 0 : rows_q * E},                                  // (fused chain: never written)
         {W.q, rows_q * E}, {W.o, rows_q * E}, {W.a1, fold_out_proj(desc, false) ? 0 : rows_q * E}, {W.a2, rows_q * (long long)D}};
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * TP_NUM_DEBUG_BUFFERS, stream);
@@ -628,7 +628,9 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     // (fused LayerNorm chain — inference, plain schedule: H2 is needed for its row statistics only and is not written)
     const bool fuse_ln = !train && !absorb && tuning(TP_TUNE_FUSE_KV_LN) != 0;
     // scale_factor 2 on that chain: region-major K/V rows, and region attention inside the in-projections' epilogues
-    const bool region_major = fuse_ln && s == 2 && !attn_mask && tuning(TP_TUNE_FUSE_ATTN) != 1;
+    // (the attention epilogues want 8 | rows per image — region pairs in the query DMA —: every even grid but 6, 10, 14, …;
+    // decided per image, not per batch, so that an image's bits do not depend on the batch it travels in)
+    const bool region_major = fuse_ln && s == 2 && (N % 8) == 0 && !attn_mask && tuning(TP_TUNE_FUSE_ATTN) != 1;
     const bool fuse_attn = region_major && tuning(TP_TUNE_FUSE_ATTN) == 0;
     char* const qt = ws + W.kv;                                        // [rows_q, 8, E] fp16 (absorbed schedule)
     char* const uu = ws + W.kv + (size_t)rows_q * 8 * E * 2;           // [rows_q, 8, E] fp16
