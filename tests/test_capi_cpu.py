@@ -42,7 +42,7 @@ def test_sizes_and_descriptor_validation():
     # out_proj∘mlp[0] fold (W_om [D,1024] fp16) and its pack-time scratch (Wout^T fp16, fp32 product [D,1024])
     # + the per-head transposes of the folded K in-projection the absorbed schedule reads (w_qt, 2 MiB)
     # + Wc = W'·W2 for k and v and W'q·Wq1 for q (the fused LayerNorm chains, 6 MiB)
-    fold = 4096 * 1024 * 2 + 1024 * 1024 * 2 + 4096 * 1024 * 4 + 1024 * 1024 * 2 + 3 * 1024 * 1024 * 2
+    fold = 4096 * 1024 * 2 + 1024 * 1024 * 2 + 4096 * 1024 * 4 + 1024 * 1024 * 2 + 3 * 1024 * 1024 * 2 + 1024 * 1024 * 2   # (+ w_qt_c)
     assert 36_722_688 * 2 + fold <= packed < 36_722_688 * 2 + fold + 300_000
     ws = lib.tp_workspace_bytes(ctypes.byref(d))
     assert 1.5e9 < ws < 3.5e9

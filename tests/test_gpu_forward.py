@@ -327,6 +327,41 @@ def test_attention_in_the_inprojection_epilogues_is_the_same_function(dtype, B):
             assert torch.equal(y, ys[0]), (key, val)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("s,B", [(3, 2), (3, 20), (4, 3), (6, 2)])
+def test_absorbed_schedule_on_the_fused_layernorm_chain(s, B, dtype):
+    """s >= 3 default: the absorbed schedule with H2 computed for its statistics only — the attention kernel walks the rows
+    of Hkv (RAW form), the second K/V layer rides in Wc = W'·W2, the per-head V GEMM is a LayerNorm-fold GEMM with
+    (mean, rstd) := (e_h / a_h, a_h) — against the absorbed schedule that stores H2 and normalises its rows on load
+    (TP_TUNE_FUSE_KV_LN = 0).  Same function: both within the gate of the fp64 oracle, the new one no worse.
+    B = 20 at s = 3 puts the per-head GEMMs' 1280 queries on more than one tile row."""
+    from tokenpacker_amd import _capi
+    D = 256
+    params = synth.make_params(215 + s, D)
+    x, xm = synth.make_inputs(216 + s, B, dtype)
+    p_lp = {k: v.to(dtype) for k, v in params.items()}
+    y_exact = orc.forward(p_lp, x, xm, scale_factor=s, compute_dtype=torch.float64, io_dtype=dtype)
+    ys = {}
+    try:
+        for mode in (0, 1):
+            _capi.set_tuning(_capi.TP_TUNE_FUSE_KV_LN, mode)
+            m = _module(params, s, D, dtype)
+            m.output_fp32 = True
+            with torch.no_grad():
+                ys[mode] = m((x.cuda(), xm.cuda()))
+            torch.cuda.synchronize()
+            assert sum(m.saturation_report().values()) == 0
+    finally:
+        _capi.set_tuning(_capi.TP_TUNE_FUSE_KV_LN, 1)
+    e0, e1 = orc.rel_err(ys[0], y_exact), orc.rel_err(ys[1], y_exact)
+    l0, l1 = orc.rel_l2(ys[0], y_exact), orc.rel_l2(ys[1], y_exact)
+    print(f"\n[parity] absorbed on Hkv s={s} B={B} {dtype}: H2 stored rel_err {e0:.3e} (l2 {l0:.3e}), statistics only {e1:.3e} (l2 {l1:.3e})")
+    assert not torch.equal(ys[0], ys[1])
+    # (the max-norm metric of a seed that is not one of the golden cases: 1.003e-3 on BOTH schedules for s = 3, B = 20, bf16)
+    assert e0 <= 1.1e-3 and e1 <= 1.1e-3 and e1 <= 1.1 * e0, (e0, e1)
+    assert l1 <= 1.05 * l0 + 1e-5
+
+
 @pytest.mark.parametrize("B,D", [(1, 4096), (2, 4096), (3, 4096)])
 def test_split_k_for_small_batches_is_the_same_function(B, D):
     """TP_TUNE_SPLIT_K = 1 (opt-in): the two K = 4096 GEMMs of a small batch as K-groups with fp32 partials + a fixed-order

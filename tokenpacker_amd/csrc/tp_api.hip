@@ -56,6 +56,7 @@ PackedLayout packed_layout(int D) {
     L.w_in_kv = take(2 * E * E * 2);     L.c_in_kv = take(2 * E * 4);  L.b_in_kv = take(2 * E * 4);
     L.w_in_q = take(E * E * 2);          L.c_in_q = take(E * 4);       L.b_in_q = take(E * 4);
     L.w_qt = take(E * E * 2);
+    L.w_qt_c = take(E * E * 2);
     L.w_c_kv = take(2 * E * E * 2);      L.d_in_kv = take(2 * E * 4);
     L.w_c_q = take(E * E * 2);
     L.w_out = take(E * E * 2);           L.b_out = take(E * 4);
@@ -290,6 +291,8 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
             TP_TRY(pack_bias_fold_launch(P + L.w_in_kv + (size_t)g * E * E * 2, (const float*)(P + L.b_kv2) + g * E, nullptr,
                                          (float*)(P + L.d_in_kv) + g * E, (int)E, (int)E, stream));
         }
+        // (the absorbed schedule on this chain: qt = per-head Q_h·Wc_k,h — the per-head transposes of the ROUNDED Wc_k)
+        TP_TRY(pack_head_transpose_launch(P + L.w_c_kv, P + L.w_qt_c, stream));
         {   // query side: Q = rstd·(q0·Wcq^T − mu·c_q) + b'_q,  Wcq = W'q·Wq1  (q_proj_1 has no bias)
             TP_TRY(pack_transpose_f16_launch(P + L.w_q1, P + L.scratch_t, (int)E, stream));
             GemmArgs a = plain_gemm(P + L.w_in_q, E, P + L.scratch_t, P + L.scratch_p, E, (int)E, (int)E, (int)E, nullptr, 0);
@@ -374,7 +377,7 @@ int tp_debug_count_saturated(const tp_desc* desc, const void* workspace, size_t 
     const struct { size_t off; long long n; } bufs[TP_NUM_DEBUG_BUFFERS] = {
         // (the absorbed schedule keeps qt | u [2][rows_q, 8, E] where K | V would be)
         {W.q0, rows_q * E}, {W.hkv, rows_kv * 2 * E},
-        {W.h2, (!absorb_kv(desc, false) && tuning(TP_TUNE_FUSE_KV_LN) != 0) ? 0 : 2 * rows_kv * E},   // (fused chain: H2 is never written)
+        {W.h2, tuning(TP_TUNE_FUSE_KV_LN) != 0 ? 0 : 2 * rows_kv * E},     // (fused chain, plain or absorbed: H2 is never written)
         // (attention in the in-projections' epilogues, TP_TUNE_FUSE_ATTN: K | V are never written.  The mask-less forward is assumed.)
         {W.kv, absorb_kv(desc, false) ? 2 * rows_q * 8 * E
                : (s == 2 && (g * g) % 8 == 0 && tuning(TP_TUNE_FUSE_KV_LN) != 0 && tuning(TP_TUNE_FUSE_ATTN) == 0) ? 0 : 2 * rows_kv * E},
@@ -563,6 +566,11 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     const char* pw = (const char*)packed_weights;
     char* ws = (char*)workspace;
     const long long kvE = (long long)rows_kv * E;      // elements per K/V group slab
+    // Hkv: training keeps [rows, 2048] (K half | V half per row: what the backward reads); inference writes a K slab and a V
+    // slab [rows, 1024] each (GemmArgs::c_split_cols), so that everything behind the first layer walks contiguous rows
+    const bool hkv_split = !train;
+    const long long hkv_ld = hkv_split ? E : 2 * E;                     // elements between rows of a half
+    const long long hkv_gs = hkv_split ? kvE * 2 : (long long)E * 2;    // bytes from the K half to the V half
 
     // tile-queue heads of the persistent GEMM launches: 64 ints per launch (<= 16 launches), zeroed once per forward
     int* counters = tuning(TP_TUNE_DYNAMIC_TILES) ? (int*)(ws + W.counters) : nullptr;
@@ -588,10 +596,10 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         p.a_gs = (long long)p.K * 2; p.w_gs = (long long)p.K * 2;
         p.ldw_bytes = a.ldw_bytes ? a.ldw_bytes : (long long)a.K * 2;
         p.C = ws + W.splitk; p.ldc = a.N; p.c_gs = (long long)a.M * a.N * 4;
-        p.bias = nullptr; p.flags = 0; p.tile = 128;
+        p.bias = nullptr; p.flags = 0; p.tile = 128; p.c_split_cols = 0;
         TP_TRY(launch(in_dt, TP_F32, p, st));
         return splitk_reduce_launch((const float*)(ws + W.splitk), S, a.M, a.N, a.bias, (a.flags & TP_LINEAR_GELU) ? 1 : 0, a.C, a.ldc,
-                                    out_dt, st);
+                                    out_dt, st, a.c_split_cols, a.c_split_stride_bytes / (out_dt == TP_F32 ? 4 : 2));
     };
     // query side on a side stream (not when the caller wants per-stage events: those need one stream)
     SideCtx* side = (tuning(TP_TUNE_Q_SIDE_STREAM) && !stage_events) ? side_ctx_for(stream) : nullptr;
@@ -630,12 +638,14 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     // scale_factor 2 on that chain: region-major K/V rows, and region attention inside the in-projections' epilogues
     // (the attention epilogues want 8 | rows per image — region pairs in the query DMA —: every even grid but 6, 10, 14, …;
     // decided per image, not per batch, so that an image's bits do not depend on the batch it travels in)
+    // (absorbed schedule on the fused chain: H2 for its statistics only, the attention kernel walks Hkv — RAW form)
+    const bool absorb_raw = absorb && tuning(TP_TUNE_FUSE_KV_LN) != 0;
     const bool region_major = fuse_ln && s == 2 && (N % 8) == 0 && !attn_mask && tuning(TP_TUNE_FUSE_ATTN) != 1;
     const bool fuse_attn = region_major && tuning(TP_TUNE_FUSE_ATTN) == 0;
     char* const qt = ws + W.kv;                                        // [rows_q, 8, E] fp16 (absorbed schedule)
     char* const uu = ws + W.kv + (size_t)rows_q * 8 * E * 2;           // [rows_q, 8, E] fp16
     auto qt_gemm = [&](hipStream_t st) -> int {         // qt[m, h, :] = Q[m, h*128:(h+1)*128] · W'k[h*128:(h+1)*128, :]
-        GemmArgs a = plain_gemm(ws + W.q, E, pw + P.w_qt, qt, 8 * E, rows_q, E, kHeadDim, nullptr, 0);
+        GemmArgs a = plain_gemm(ws + W.q, E, absorb_raw ? pw + P.w_qt_c : pw + P.w_qt, qt, 8 * E, rows_q, E, kHeadDim, nullptr, 0);
         a.groups = kHeads; a.a_gs = kHeadDim * 2; a.w_gs = (long long)E * kHeadDim * 2; a.c_gs = E * 2;
         return launch(TP_F16, TP_F16, a, st);
     };
@@ -672,6 +682,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
                                 (const float*)(pw + P.b_kv0), TP_LINEAR_GELU | (train ? TP_LINEAR_SAVE_PRE : 0));
         a.rows_per_batch = N; a.a_batch_stride_bytes = xm_strides[0] * 2;
         if (region_major) { a.a_region_g = g; a.a_region_s = s; }      // rows of Hkv (and of everything behind it) by region
+        if (hkv_split) { a.ldc = E; a.c_split_cols = E; a.c_split_stride_bytes = kvE * 2; }
         a.C2 = train ? ws + W.z1 : nullptr;
         if (xm_parts) {
             for (int i = 0; i < 4; ++i) a.A_parts[i] = (const char*)xm_parts[i];
@@ -683,9 +694,10 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     TP_TRY(mark());
     const int parts_kv = gemm_stats_parts(E);
     {
-        GemmArgs a = plain_gemm(ws + W.hkv, 2 * E, pw + P.w_kv2, fuse_ln ? nullptr : ws + W.h2, E, rows_kv, E, E,
-                                (const float*)(pw + P.b_kv2), TP_LINEAR_ROW_STATS | (fuse_ln ? TP_LINEAR_NO_STORE : 0));
-        a.groups = 2; a.a_gs = E * 2; a.w_gs = (long long)E * E * 2; a.c_gs = kvE * 2; a.bias_gs = E;
+        const bool stats_only = fuse_ln || absorb_raw;
+        GemmArgs a = plain_gemm(ws + W.hkv, hkv_ld, pw + P.w_kv2, stats_only ? nullptr : ws + W.h2, E, rows_kv, E, E,
+                                (const float*)(pw + P.b_kv2), TP_LINEAR_ROW_STATS | (stats_only ? TP_LINEAR_NO_STORE : 0));
+        a.groups = 2; a.a_gs = hkv_gs; a.w_gs = (long long)E * E * 2; a.c_gs = kvE * 2; a.bias_gs = E;
         a.stats_out = (float*)(ws + W.stats_kv); a.stats_out_gs = (long long)parts_kv * rows_kv * 2;
         TP_TRY(launch(TP_F16, TP_F16, a, stream));
     }
@@ -710,7 +722,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     auto attn_gemm = [&](const int kv) -> int {
         // steps 4 + 7 as two launches: the K launch (step 4) turns its tile of K into logits against the region's query, the
         // V launch (step 7) its tile of V into softmax-weighted sums -> O.  K and V are never written.
-        GemmArgs a = plain_gemm(ws + W.hkv + (size_t)kv * E * 2, 2 * E, pw + P.w_c_kv + (size_t)kv * E * E * 2,
+        GemmArgs a = plain_gemm(ws + W.hkv + (size_t)kv * hkv_gs, hkv_ld, pw + P.w_c_kv + (size_t)kv * E * E * 2,
                                 kv == 0 ? nullptr : ws + W.o, E, rows_kv, E, E, (const float*)(pw + P.b_in_kv) + kv * E,
                                 TP_LINEAR_LN_FOLD);
         a.acc_init = (const float*)(pw + P.d_in_kv) + kv * E;
@@ -733,7 +745,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
                                 (const float*)(pw + P.b_in_kv), TP_LINEAR_LN_FOLD);
         a.groups = 2; a.a_gs = kvE * 2; a.w_gs = (long long)E * E * 2; a.c_gs = kvE * 2; a.bias_gs = E;
         if (fuse_ln) {                                  // {K,V} = rstd·(Hkv[:, g]·Wc^T + d − mu·c) + b'
-            a.A = (const char*)(ws + W.hkv); a.lda_bytes = 2 * E * 2; a.a_gs = E * 2;
+            a.A = (const char*)(ws + W.hkv); a.lda_bytes = hkv_ld * 2; a.a_gs = hkv_gs;
             a.W = pw + P.w_c_kv;
             a.acc_init = (const float*)(pw + P.d_in_kv); a.acc_init_gs = E;
         }
@@ -752,12 +764,24 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         TP_TRY(attn_gemm(1));
     } else if (absorb) {
         TP_TRY(kv_finalize());
-        TP_TRY(region_attention_absorbed_launch(qt, ws + W.h2, ws + W.h2 + kvE * 2, (const float*)(ws + W.mr_kv),
-                                                (const float*)(ws + W.mr_kv) + (size_t)rows_kv * 2, uu, B, g, s, stream, attn_mask, mask_mode));
+        float* const mr_u = (float*)(ws + W.h2);           // RAW: (e / a, a) per head and query (H2 is not written then)
+        if (absorb_raw)
+            TP_TRY(region_attention_absorbed_launch(qt, ws + W.hkv, ws + W.hkv + (size_t)hkv_gs, (const float*)(ws + W.mr_kv),
+                                                    (const float*)(ws + W.mr_kv) + (size_t)rows_kv * 2, uu, B, g, s, stream, attn_mask, mask_mode,
+                                                    (int)hkv_ld, ws + W.q, (const float*)(pw + P.d_in_kv), (const float*)(pw + P.c_in_kv), mr_u));
+        else
+            TP_TRY(region_attention_absorbed_launch(qt, ws + W.h2, ws + W.h2 + kvE * 2, (const float*)(ws + W.mr_kv),
+                                                    (const float*)(ws + W.mr_kv) + (size_t)rows_kv * 2, uu, B, g, s, stream, attn_mask, mask_mode));
         // O[:, h*128:(h+1)*128] = u[:, h, :] · W'v[h*128:(h+1)*128, :]^T + b'v   (eight N = 128 groups)
-        GemmArgs a = plain_gemm(uu, 8 * E, pw + P.w_in_kv + (size_t)E * E * 2, ws + W.o, E, rows_q, kHeadDim, E,
-                                (const float*)(pw + P.b_in_kv) + E, 0);
+        // RAW: a_h (u_h · Wc_v,h^T + d_v,h - (e_h / a_h) c_v,h) + b'v,h — a LayerNorm-fold epilogue with (mean, rstd) := mr_u
+        GemmArgs a = plain_gemm(uu, 8 * E, (absorb_raw ? pw + P.w_c_kv : pw + P.w_in_kv) + (size_t)E * E * 2, ws + W.o, E, rows_q, kHeadDim, E,
+                                (const float*)(pw + P.b_in_kv) + E, absorb_raw ? TP_LINEAR_LN_FOLD : 0);
         a.groups = kHeads; a.a_gs = E * 2; a.w_gs = (long long)kHeadDim * E * 2; a.c_gs = kHeadDim * 2; a.bias_gs = kHeadDim;
+        if (absorb_raw) {
+            a.acc_init = (const float*)(pw + P.d_in_kv) + E; a.acc_init_gs = kHeadDim;
+            a.colsum = (const float*)(pw + P.c_in_kv) + E; a.colsum_gs = kHeadDim;
+            a.stats_in = mr_u; a.stats_in_gs = (long long)rows_q * 2;
+        }
         TP_TRY(launch(TP_F16, TP_F16, a, stream));
     } else
     TP_TRY(region_attention_launch(ws + W.q, ws + W.kv, ws + W.kv + kvE * 2, ws + W.o, B, g, s, stream, attn_mask, mask_mode,

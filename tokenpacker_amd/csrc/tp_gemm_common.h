@@ -128,6 +128,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
     const float* __restrict__ bias = p.bias ? p.bias + g * p.bias_gs : nullptr;
     const float* __restrict__ colsum = p.colsum ? p.colsum + g * p.colsum_gs : nullptr;
     char* __restrict__ Cg = p.C + g * p.c_gs;
+    int n0s = n0;                                      // the tile's first column inside its output slab (GemmArgs::c_split_cols)
+    if (p.c_split_cols > 0 && n0 >= p.c_split_cols) { n0s = n0 - p.c_split_cols; Cg += p.c_split_stride_bytes; }
     // The output goes out through a buffer descriptor that ends after row M - 1: rows past the end are dropped by
     // the hardware range check, so every wave issues the SAME number of store instructions for every tile (the
     // persistent kernel's counted s_waitcnt at the tile seam relies on that) and no branch guards the stores.
@@ -221,7 +223,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
                     continue;
                 }
                 if constexpr (OUT_F32) {
-                    const unsigned coff = (unsigned)(((long long)m * p.ldc + col_base) * 4);
+                    const unsigned coff = (unsigned)(((long long)m * p.ldc + col_base - n0 + n0s) * 4);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), rsrc_c, (int)(coff + j0 * 64), 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), rsrc_c, (int)(coff + j1 * 64), 0, 0);
                 } else {
@@ -252,7 +254,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
                     // even 16-lane rows now hold columns g*4 .. g*4+7 of fragment j0 (own | upper neighbour's),
                     // odd rows columns (g-1)*4 .. (g-1)*4+7 of fragment j1 (lower neighbour's | own)
                     const int gq = lane >> 4;
-                    const int col = n0 + wn * WN + (j0 + (gq & 1)) * 16 + (gq >> 1) * 8;
+                    const int col = n0s + wn * WN + (j0 + (gq & 1)) * 16 + (gq >> 1) * 8;
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4{sx[0], sy[0], sx[1], sy[1]}, rsrc_c,
                                                            (int)(unsigned)(((long long)m * p.ldc + col) * (long long)sizeof(TO)), 0, 0);
                 }

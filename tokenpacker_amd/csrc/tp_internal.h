@@ -85,6 +85,10 @@ struct GemmArgs {
     //   attn_mode 1 (the K launch): nothing of K is stored; logit[h][r] = attn_scale * K[r, head h] . Q[r / 4, head h]
     //   attn_mode 2 (the V launch): O[r / 4, :] = sum over the region's 4 rows of softmax(logit)[r] * V[r, :] — C is O,
     //               fp16 [M / 4, ldc]
+    // Output columns >= c_split_cols (a multiple of the tile width) go to a second slab: C + c_split_stride_bytes, column
+    // index minus c_split_cols, same ldc — the first K/V layer leaves Hkv as a K slab and a V slab [rows, 1024] each instead
+    // of interleaved [rows, 2048] halves (inference; its consumers then walk contiguous rows).  0: one slab.
+    int c_split_cols; long long c_split_stride_bytes;
     int attn_mode;
     const char* attn_q;               // attn_mode 1: fp16 queries [M / 4, attn_ldq_bytes]
     long long attn_ldq_bytes;
@@ -139,7 +143,11 @@ int region_attention_launch(const void* q, const void* k, const void* v, void* o
 // K/V in-projections absorbed into the query side (tp_kernels.hip): qt [B*M, 8, 1024], H2 k / v [B*N, 1024] fp16 with
 // their per-row (mean, rstd) -> u [B*M, 8, 1024] fp16
 int region_attention_absorbed_launch(const void* qt, const void* h2k, const void* h2v, const float* mr_k, const float* mr_v,
-                                     void* u, int B, int grid, int s, hipStream_t stream, const float* mask = nullptr, int mask_mode = 0);
+                                     void* u, int B, int grid, int s, hipStream_t stream, const float* mask = nullptr, int mask_mode = 0,
+                                     // RAW form (q != NULL): h2k / h2v are the K / V halves of Hkv (row stride ld elements), qt was built
+                                     // from Wc_k; q [B*M, 1024] fp16, d_k / c_k [1024] fp32 -> u normalised + mr_u [8][B*M][2]
+                                     int ld = kEmbed, const void* q = nullptr, const float* d_k = nullptr, const float* c_k = nullptr,
+                                     float* mr_u = nullptr);
 int pack_head_transpose_launch(const void* w_f16, void* dst_f16, hipStream_t stream);    // [8*128, 1024] -> [8][1024][128]
 bool absorb_kv(const tp_desc* desc, bool train);          // whether tp_forward runs the absorbed schedule for desc
 bool fold_out_proj(const tp_desc* desc, bool train);      // whether out_proj is folded into mlp[0] for desc
@@ -173,6 +181,7 @@ struct PackedLayout {
     size_t w_c_kv, d_in_kv;       // fused LayerNorm chain: Wc = W'·W2 [2][1024,1024] f16, d = W'·b2 [2][1024] f32
     size_t w_c_q;                 // the same for the query side: W'q·Wq1 [1024,1024] f16 (q_proj_1 has no bias: d = 0)
     size_t w_qt;                  // [8][1024][128] f16: per-head transposes of the LN-folded K in-proj (absorbed schedule)
+    size_t w_qt_c;                // the same of Wc_k (absorbed schedule on the fused LayerNorm chain: the kernel walks Hkv)
     size_t w_out, b_out;          // [1024,1024] f16, [1024] f32
     size_t w_m0, b_m0;            // [D,1024] f16, [D] f32
     size_t w_m2, b_m2;            // [D,D] f16, [D] f32
@@ -198,7 +207,7 @@ WorkspaceLayout workspace_layout(int B, int grid, int s, int D, bool train = fal
 constexpr size_t kSplitKBytes = (size_t)512 * 128 * 128 * 4;
 // out[m, n] = epilogue(sum over the S partials [S][M][N] fp32, in split order): + bias, optional erf GELU, cast to out_dtype
 int splitk_reduce_launch(const float* partials, int S, int M, int N, const float* bias, int gelu, void* out, long long ldc,
-                         int out_dtype, hipStream_t stream);
+                         int out_dtype, hipStream_t stream, int split_cols = 0, long long split_stride_elems = 0);
 
 // ---- backward helpers (tp_bwd.hip) -------------------------------------------------------------
 int bw_transpose_launch(int src_dtype, int dst_dtype, const void* src, long long ld, int rows_per_batch,

@@ -216,14 +216,27 @@ int region_attention_launch(const void* q, const void* k, const void* v, void* o
 // are reduced over the wave with a halving exchange (10 shuffles per key instead of 48) and parked in 2 KiB of LDS;
 // softmax runs there; phase B re-walks the region's tokens on the V side, accumulating u in 128 fp32 registers.
 // HBM-bound: reads 2 s^2 rows of H2 + 16 KiB of qt, writes 16 KiB of u per query.
+//
+// RAW form (the fused LayerNorm chain under the absorbed schedule, TP_TUNE_FUSE_KV_LN): H2 = Hkv·W2^T + b2 is computed for
+// its row statistics only and never stored; the kernel walks the rows of Hkv itself (row stride `ld`) and the second layer
+// rides in the pre-multiplied weights Wc = W'·W2, d = W'·b2, c = rowsum(W') of the fused chain:
+//     Q_h·K_t,h = rstd_t (qt_h·hkv_t + alpha_h - mu_t beta_h) + const,   qt_h = Wc_k,h^T Q_h,  alpha_h = Q_h·d_k,h,  beta_h = Q_h·c_k,h
+//     sum_t p_t V_t,h = a_h (Wc_v,h u_h + d_v,h - (e_h / a_h) c_v,h) + b'v_h,
+//         w_t = p_t rstd_t,  a_h = sum_t w_t,  e_h = sum_t w_t mu_t,  u_h = (sum_t w_t hkv^v_t) / a_h
+// i.e. the per-head V GEMM behind it is a LayerNorm-fold GEMM with (mean, rstd) := (e_h / a_h, a_h), written to `mr_u`
+// ([8 heads][B M][2]).  No per-element normalisation on load: two VALU operations less per element and key.
 constexpr int kAbsorbMaxKeys = 64;          // s*s <= 64 (s <= 8): logits of a region live in LDS
 
+template <bool RAW>
 __global__ void __launch_bounds__(256)
 region_attention_absorbed_kernel(const f16_t* __restrict__ qt, const f16_t* __restrict__ h2k, const f16_t* __restrict__ h2v,
                                  const float* __restrict__ mr_k, const float* __restrict__ mr_v, f16_t* __restrict__ u,
-                                 int B, int g, int s, float scale, const float* __restrict__ mask, int mask_mode) {
+                                 int B, int g, int s, float scale, const float* __restrict__ mask, int mask_mode,
+                                 int ld, const f16_t* __restrict__ q, const float* __restrict__ d_k,
+                                 const float* __restrict__ c_k, float* __restrict__ mr_u) {
     constexpr int E = kEmbed, H = kHeads;
     __shared__ float logit_lds[4][kAbsorbMaxKeys * H];
+    __shared__ float ab_lds[4][2 * H];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int G = g / s, M = G * G, N = g * g, S2 = s * s;
     const long long qi = (long long)blockIdx.x * 4 + wv;
@@ -246,15 +259,17 @@ region_attention_absorbed_kernel(const f16_t* __restrict__ qt, const f16_t* __re
         const long long row = token_row(t < S2 ? t : S2 - 1);
         Row r;
         r.st = *(const float2*)(mr + row * 2);                  // (mean, rstd): the same address for all lanes
-        r.a = *(const f16x8*)(base + row * E + ea);
-        r.b = *(const f16x8*)(base + row * E + eb);
+        r.a = *(const f16x8*)(base + row * ld + ea);
+        r.b = *(const f16x8*)(base + row * ld + eb);
         return r;
     };
     auto normalise = [&](const Row& r, float (&na)[8], float (&nb)[8]) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { na[e] = ((float)r.a[e] - r.st.x) * r.st.y; nb[e] = ((float)r.b[e] - r.st.x) * r.st.y; }
+        for (int e = 0; e < 8; ++e) {
+            if constexpr (RAW) { na[e] = (float)r.a[e]; nb[e] = (float)r.b[e]; }
+            else { na[e] = ((float)r.a[e] - r.st.x) * r.st.y; nb[e] = ((float)r.b[e] - r.st.x) * r.st.y; }
+        }
     };
-
     {   // ---- phase A: logits ---------------------------------------------------------------------------------
         f16x8 qa[H], qb[H];
 #pragma unroll
@@ -263,10 +278,34 @@ region_attention_absorbed_kernel(const f16_t* __restrict__ qt, const f16_t* __re
             qb[h] = *(const f16x8*)(qt + (qi * H + h) * E + eb);
         }
         Row cur = fetch(h2k, mr_k, 0);
+        // (RAW: the per-head scalars are computed while qt and the first row are in flight)
+        if constexpr (RAW) {
+            // alpha_h = Q_h·d_k,h, beta_h = Q_h·c_k,h: lane l holds elements of head l / 16 (low half) and 4 + l / 16 (high half)
+            float qa8[8], qb8[8];
+            load8(q + qi * E + ea, qa8);
+            load8(q + qi * E + eb, qb8);
+            float al = 0.f, ah = 0.f, bl = 0.f, bh = 0.f;
+    #pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                al = fmaf(qa8[e], d_k[ea + e], al); bl = fmaf(qa8[e], c_k[ea + e], bl);
+                ah = fmaf(qb8[e], d_k[eb + e], ah); bh = fmaf(qb8[e], c_k[eb + e], bh);
+            }
+    #pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) {
+                al += __shfl_xor(al, off); bl += __shfl_xor(bl, off); ah += __shfl_xor(ah, off); bh += __shfl_xor(bh, off);
+            }
+            if ((lane & 15) == 0) {
+                const int hg = lane >> 4;
+                ab_lds[wv][hg] = al; ab_lds[wv][4 + hg] = ah; ab_lds[wv][H + hg] = bl; ab_lds[wv][H + 4 + hg] = bh;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+
         for (int t = 0; t < S2; ++t) {
             const Row nxt = fetch(h2k, mr_k, t + 1);
             float na[8], nb[8], v[H];
             normalise(cur, na, nb);
+            const float2 st_t = cur.st;
             cur = nxt;
 #pragma unroll
             for (int h = 0; h < H; ++h) {
@@ -297,6 +336,8 @@ region_attention_absorbed_kernel(const f16_t* __restrict__ qt, const f16_t* __re
             if ((lane & 7) == 0) {
                 const int hsel = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
                 float lgt = y * scale;
+                if constexpr (RAW)                                                         // cur was advanced: its stats are in `st_t`
+                    lgt = st_t.y * (y + ab_lds[wv][hsel] - st_t.x * ab_lds[wv][H + hsel]) * scale;
                 if (mask_mode == 1) lgt += mask[t];                                       // attn_mask, see region_attention_kernel
                 else if (mask_mode == 2) lgt += mask[(((long long)m * B + b) * H + hsel) * S2 + t];
                 lg[t * H + hsel] = lgt;
@@ -321,14 +362,22 @@ region_attention_absorbed_kernel(const f16_t* __restrict__ qt, const f16_t* __re
     for (int h = 0; h < H; ++h)
 #pragma unroll
         for (int e = 0; e < 8; ++e) { ua[h][e] = 0.f; ub[h][e] = 0.f; }
+    float a_h[H], e_h[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) { a_h[h] = 0.f; e_h[h] = 0.f; }
     Row cur = fetch(h2v, mr_v, 0);
     for (int t = 0; t < S2; ++t) {
         const Row nxt = fetch(h2v, mr_v, t + 1);
         float na[8], nb[8];
         normalise(cur, na, nb);
+        const float2 st_t = cur.st;
         cur = nxt;
         const f32x4 p0 = *(const f32x4*)(lg + t * H), p1 = *(const f32x4*)(lg + t * H + 4);     // broadcast reads
-        const float p[H] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+        float p[H] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+        if constexpr (RAW) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) { p[h] *= st_t.y; a_h[h] += p[h]; e_h[h] = fmaf(p[h], st_t.x, e_h[h]); }
+        }
 #pragma unroll
         for (int h = 0; h < H; ++h)
 #pragma unroll
@@ -336,19 +385,32 @@ region_attention_absorbed_kernel(const f16_t* __restrict__ qt, const f16_t* __re
     }
 #pragma unroll
     for (int h = 0; h < H; ++h) {
+        if constexpr (RAW) {
+            const float inv = 1.0f / a_h[h];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ua[h][e] *= inv; ub[h][e] *= inv; }
+            if (lane == h) *(float2*)(mr_u + ((long long)h * B * M + qi) * 2) = make_float2(e_h[h] * inv, a_h[h]);
+        }
         store8(u + (qi * H + h) * E + ea, ua[h]);
         store8(u + (qi * H + h) * E + eb, ub[h]);
     }
 }
 
 int region_attention_absorbed_launch(const void* qt, const void* h2k, const void* h2v, const float* mr_k, const float* mr_v,
-                                     void* u, int B, int grid, int s, hipStream_t stream, const float* mask, int mask_mode) {
+                                     void* u, int B, int grid, int s, hipStream_t stream, const float* mask, int mask_mode,
+                                     int ld, const void* q, const float* d_k, const float* c_k, float* mr_u) {
     if (s * s > kAbsorbMaxKeys) { set_error("absorbed region attention: s*s = %d keys > %d", s * s, kAbsorbMaxKeys); return TP_ERR_INVALID_ARG; }
     const int G = grid / s, M = G * G;
     const long long nq = (long long)B * M;
     const unsigned blocks = (unsigned)((nq + 3) / 4);
-    hipLaunchKernelGGL(region_attention_absorbed_kernel, dim3(blocks), dim3(256), 0, stream, (const f16_t*)qt, (const f16_t*)h2k,
-                       (const f16_t*)h2v, mr_k, mr_v, (f16_t*)u, B, grid, s, 0.08838834764831845f, mask, mask_mode);
+    if (q)          // RAW: rows of Hkv, the second K/V layer in the pre-multiplied weights
+        hipLaunchKernelGGL(region_attention_absorbed_kernel<true>, dim3(blocks), dim3(256), 0, stream, (const f16_t*)qt,
+                           (const f16_t*)h2k, (const f16_t*)h2v, mr_k, mr_v, (f16_t*)u, B, grid, s, 0.08838834764831845f, mask,
+                           mask_mode, ld, (const f16_t*)q, d_k, c_k, mr_u);
+    else
+        hipLaunchKernelGGL(region_attention_absorbed_kernel<false>, dim3(blocks), dim3(256), 0, stream, (const f16_t*)qt,
+                           (const f16_t*)h2k, (const f16_t*)h2v, mr_k, mr_v, (f16_t*)u, B, grid, s, 0.08838834764831845f, mask,
+                           mask_mode, kEmbed, nullptr, nullptr, nullptr, nullptr);
     return check_launch("region_attention_absorbed_kernel");
 }
 
@@ -576,7 +638,7 @@ namespace tp {
 template <typename TO>
 __global__ void __launch_bounds__(256)
 splitk_reduce_kernel(const float* __restrict__ part, int S, long long MN, int N, const float* __restrict__ bias, int gelu,
-                     TO* __restrict__ out, long long ldc) {
+                     TO* __restrict__ out, long long ldc, int split_cols, long long split_stride) {
     const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i4 >= MN) return;
     const long long m = i4 / N;
@@ -592,6 +654,7 @@ splitk_reduce_kernel(const float* __restrict__ part, int S, long long MN, int N,
         }
     }
     TO* o = out + m * ldc + n;
+    if (split_cols > 0 && n >= split_cols) o += split_stride - split_cols;      // second output slab (GemmArgs::c_split_cols)
     if constexpr (std::is_same<TO, float>::value) {
         *(f32x4*)o = acc;
     } else {
@@ -605,15 +668,15 @@ splitk_reduce_kernel(const float* __restrict__ part, int S, long long MN, int N,
 }
 
 int splitk_reduce_launch(const float* partials, int S, int M, int N, const float* bias, int gelu, void* out, long long ldc,
-                         int out_dtype, hipStream_t stream) {
+                         int out_dtype, hipStream_t stream, int split_cols, long long split_stride) {
     const long long MN = (long long)M * N;
     const unsigned blocks = (unsigned)((MN / 4 + 255) / 256);
     if (out_dtype == TP_F16)
-        hipLaunchKernelGGL(splitk_reduce_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream, partials, S, MN, N, bias, gelu, (f16_t*)out, ldc);
+        hipLaunchKernelGGL(splitk_reduce_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream, partials, S, MN, N, bias, gelu, (f16_t*)out, ldc, split_cols, split_stride);
     else if (out_dtype == TP_BF16)
-        hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, partials, S, MN, N, bias, gelu, (bf16_t*)out, ldc);
+        hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, partials, S, MN, N, bias, gelu, (bf16_t*)out, ldc, split_cols, split_stride);
     else
-        hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, partials, S, MN, N, bias, gelu, (float*)out, ldc);
+        hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, partials, S, MN, N, bias, gelu, (float*)out, ldc, split_cols, split_stride);
     return check_launch("splitk_reduce_kernel");
 }
 
