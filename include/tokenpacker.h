@@ -137,7 +137,8 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
  *                                     LayerNorm statistics only, the in-projection reads Hkv through Wc = W'·W2, and region
  *                                     attention runs in the epilogues of those two GEMMs (TP_TUNE_FUSE_ATTN): K, V are not written;
  *   inference, scale_factor >= 3    : K/V in-projections absorbed into the query side (TP_TUNE_ABSORB_KV, see
- *                                     tp_region_attention_absorbed). */
+ *                                     tp_region_attention_absorbed) — on the fused LayerNorm chain too: the second K/V layer is
+ *                                     computed for its statistics only and the attention kernel walks Hkv. */
 int tp_forward(const tp_desc* desc,
                const void* x, const int64_t x_strides[3],
                const void* x_multi, const int64_t xm_strides[3],
