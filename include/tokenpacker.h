@@ -392,8 +392,10 @@ enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all hal
                                      1 never, 2 always */
        TP_TUNE_FUSE_KV_LN = 8,    /* 1 (default): inference: the layer in front of every LayerNorm is computed for its row statistics
                                      only and the in-projection behind it reads that layer's INPUT through a pre-multiplied weight
-                                     (K/V side on the plain schedule: Wc = W'·W2, no H2 written; query side on every schedule:
-                                     W'q·Wq1, no Q1pre written) | 0: the pre-LayerNorm activations are written and read back */
+                                     (K/V side: Wc = W'·W2, no H2 written — on the plain schedule through the in-projection GEMM, on
+                                     the absorbed schedule through qt and the per-head V GEMM, the attention kernel walking Hkv; query
+                                     side: W'q·Wq1, no Q1pre written) | 0: the pre-LayerNorm activations are written and read back.
+                                     Read at PACK time (the pre-multiplied weights are built only then) and at forward time */
        TP_TUNE_LN_MERGE = 9,      /* 0 (default): inference, a LayerNorm's consumer on the 128-tile kernel (small batches) merges the
                                      producer's (mean, M2) slabs itself — no ln_finalize launch | 1: always the separate launch */
        TP_TUNE_FUSE_ATTN = 10,    /* inference, scale_factor 2, fused LayerNorm chain, no attn_mask: 0 (default) the first K/V layer reads
