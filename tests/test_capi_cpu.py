@@ -128,3 +128,33 @@ def test_train_hd_and_parts_entry_points_reject_bad_arguments():
     assert lib.tp_wgrad_workspace_bytes(1024, 4096) == 16 * 1024 * 4096 * 4
     assert lib.tp_wgrad_workspace_bytes(0, 4096) == 0
     assert lib.tp_wgrad(None, 1024, None, 4096, 0, 0, 4096, 1024, 4096, _capi.TP_BF16, None, _capi.TP_F32, 0, None, 0, None) == E
+
+
+def test_tuning_keys_match_the_header():
+    """Every TP_TUNE_* key of include/tokenpacker.h exists in the binding with the same number, the binding knows a default
+    for each, and tp_set_tuning accepts exactly the keys below TP_TUNE_COUNT_."""
+    src = open(os.path.join(ROOT, "include", "tokenpacker.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    keys = dict((k, int(v)) for k, v in re.findall(r"\b(TP_TUNE_[A-Z_0-9]+)\s*=\s*(\d+)", src))
+    count = keys.pop("TP_TUNE_COUNT_")
+    assert len(set(keys.values())) == len(keys) and max(keys.values()) < count
+    for name, num in keys.items():
+        assert getattr(_capi, name) == num, name
+        assert num in _capi._TUNING_DEFAULTS, f"{name}: no default in _capi._TUNING_DEFAULTS"
+    lib = _capi.load_library()
+    assert lib.tp_set_tuning(count, 0) == _capi.TP_ERR_INVALID_ARG
+    assert lib.tp_set_tuning(-1, 0) == _capi.TP_ERR_INVALID_ARG
+    for num in keys.values():
+        assert lib.tp_set_tuning(num, _capi._TUNING_DEFAULTS[num]) == _capi.TP_OK
+
+
+def test_workspace_covers_the_small_batch_split_k_partials():
+    """Batches of at most 8 images carry the fp32 partials of the opt-in K-split (512 tiles of 128 x 128) whatever the
+    tuning says at allocation time; larger batches do not pay for it, and the size grows with the batch."""
+    lib = _capi.load_library()
+    size = {b: lib.tp_workspace_bytes(ctypes.byref(_capi.make_desc(b, 24, 2, 4096, _capi.TP_BF16))) for b in (1, 8, 9, 16, 256)}
+    partials = 512 * 128 * 128 * 4
+    assert size[1] > partials and size[8] > partials
+    assert size[9] < size[8] + 1 or size[9] - size[8] < partials      # the 9th image does not carry another copy
+    assert size[16] > size[9] and size[256] > 15 * size[16] // 2
+
