@@ -112,3 +112,28 @@ def test_oracle_attn_mask_matches_the_reference_module():
         y = orc.forward(params, x, xm, scale_factor=s, compute_dtype=torch.float64, attn_mask=mask)
         assert orc.rel_err(y, torch.from_numpy(z[key])) < 2e-5, key
     assert float(np.abs(z["y_3d_bool"] - z["y_none"]).max()) > 0.05        # the masks really change the result
+
+
+def test_region_major_row_order_is_the_oracles_region_gather():
+    """The first K/V layer of the HIP path reads the tower's rows in REGION-MAJOR order (tp_gemm_common.h
+    region_major_to_raster, restated here line by line): row r of every K/V-side tensor is then token
+    region_gather(...)[b, i, j, kk] with r = b*N + (i*G + j)*s*s + kk — i.e. exactly ``divide_feature``'s grouping
+    (builder.py:96-105) flattened, and a bijection of the image's rows."""
+    import torch
+    from oracle import tokenpacker_oracle as orc
+
+    def region_major_to_raster(row, g, s):
+        N, S2, G = g * g, s * s, g // s
+        b, t = divmod(row, N)
+        q, kk = divmod(t, S2)
+        a, c = divmod(kk, s)
+        qi, qj = divmod(q, G)
+        return b * N + (qi * s + a) * g + qj * s + c
+
+    for g, s, B in ((24, 2, 3), (16, 2, 2), (12, 2, 1), (24, 3, 2), (24, 4, 1), (8, 2, 2)):
+        N = g * g
+        raster_ids = torch.arange(B * N, dtype=torch.float64).reshape(B, N, 1)
+        want = orc.region_gather(raster_ids, g, s).reshape(-1).to(torch.int64).tolist()       # [B, G, G, s*s] flattened
+        got = [region_major_to_raster(r, g, s) for r in range(B * N)]
+        assert got == want, (g, s)
+        assert sorted(got) == list(range(B * N))
