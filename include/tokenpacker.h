@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TP_ABI_VERSION 2
+#define TP_ABI_VERSION 3
 
 typedef enum tp_status {
     TP_OK = 0,
@@ -58,12 +58,16 @@ typedef struct tp_desc {
     int32_t dtype;         /* tp_dtype of x, x_multi and all weights: TP_BF16 or TP_F16           */
     int32_t out_dtype;     /* tp_dtype of `out`: == dtype, or TP_F32                              */
     float   ln_eps;        /* 1e-6 (builder.py:48)                                                */
-    int32_t flags;         /* 0, or TP_DESC_TRAIN_PACK for tp_pack_weights (see below); other bits must be 0 */
+    int32_t flags;         /* 0 | TP_DESC_TRAIN_PACK (tp_pack_weights) | TP_DESC_MASKED (sizes of a masked forward); other bits 0 */
 } tp_desc;
 /* tp_pack_weights only: the image will serve tp_forward_train / tp_backward — the weights that only the inference
  * schedules read (Wc / d of the fused LayerNorm chain, the per-head transposes of the absorbed schedule, the out_proj fold)
  * are not built.  A training step re-packs every step (the parameters just changed) and must not pay for them. */
 #define TP_DESC_TRAIN_PACK 1
+/* tp_workspace_bytes / tp_forward_masked: the forward carries an attn_mask.  The mask-less scale_factor-2 schedule never
+ * writes K | V (attention runs in the in-projections' epilogues) and its workspace has no room for them; a masked forward
+ * runs the plain schedule, which does — size its workspace with this flag set (tp_forward_masked checks). */
+#define TP_DESC_MASKED 2
 
 /* The 23 tensors of the reference state dict, all of element type desc.dtype,
  * each contiguous, nn.Linear layout [out_features, in_features]. */
@@ -110,6 +114,15 @@ size_t tp_packed_weight_bytes(const tp_desc* desc);
 size_t tp_packed_status_offset(const tp_desc* desc);
 /* Bytes of scratch tp_forward() needs for this descriptor (depends on batch); 0 on invalid args. */
 size_t tp_workspace_bytes(const tp_desc* desc);
+/* The first TP_WORKSPACE_STATUS_BYTES of every workspace are a STATUS BLOCK the caller zeroes once (after allocating):
+ *   int32[0]  sticky fp16-saturation bits.  Every activation between the kernels is fp16 and every epilogue CLAMPS to +-65504
+ *             where the reference's fp16 / bf16 arithmetic would have produced inf or a larger finite value; an inference
+ *             forward that clamps anything ORs bit k into this word (k = 1 + index of the stage in tp_forward_staged's list,
+ *             bit 0 = the query side).  The library never clears it: read it back whenever convenient (a 4-byte copy),
+ *             nonzero = some forward since the last clear differs from what the reference would have computed.
+ *             (Training forwards are not tracked — their epilogues have no register to spare; scan them with
+ *             tp_debug_count_saturated.) */
+#define TP_WORKSPACE_STATUS_BYTES 256
 
 /* ---- one-time weight preparation -------------------------------------------------------------
  * Replaces what `TokenPacker.__init__` + `load_state_dict` leave in the nn.Parameters
@@ -369,6 +382,8 @@ int tp_debug_count_saturated(const tp_desc* desc, const void* workspace, size_t 
 /* ---- test hook: occupy `workgroups` CUs for ~`microseconds` on `stream` (100 KiB LDS each; `scratch_int`: any
  * device int).  Stands in for another stream's kernels when the GEMM tile queue is measured (tools/hog_bench.py). */
 int tp_test_occupy_cus(int workgroups, int microseconds, void* scratch_int, void* stream);
+/* ---- test hook: entries of the per-caller-stream side-stream cache (tp_release_stream, LRU eviction) */
+int tp_test_side_cache_size(void);
 
 /* ---- tuning knobs (benchmarks / deployment policy; defaults are what tp_forward ships with) --------------------
  * The table is ONE process-wide array of atomics: tp_set_tuning is NOT scoped to a stream, a call or a thread — two
@@ -413,6 +428,42 @@ enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all hal
                                      auto by the number of workgroups of the launch | 4 | 8 */
        TP_TUNE_COUNT_ = 16 };
 int tp_set_tuning(int key, int value);
+int tp_get_tuning(int key);                  /* the library's current value (not a binding's shadow copy); -1: bad key */
+
+/* Per-caller-stream state: tp_forward forks the query side onto a side stream it keeps per (device, caller stream).
+ * A caller that destroys a stream it has passed to tp_forward releases that state first — a later stream the runtime
+ * hands out at the same address would otherwise inherit it.  Synchronises the side stream; a stream the library has
+ * never seen is not an error.  The cache holds 64 entries per process; beyond that the least recently used one is
+ * released the same way. */
+int tp_release_stream(void* stream);
+
+/* ---- CU-free all-gather of the projected tokens ("one all-gather ... before the LLM") ----------------
+ * One process per GPU.  Every rank's projector writes its shard into rows [lo, hi) of a receive buffer [total, M, D]
+ * (tp_forward's `out`), and the shard travels to the same rows of every peer's buffer by ONE hipMemcpyAsync per peer —
+ * SDMA engines over that peer's xGMI link, no compute unit — instead of RCCL's all-gather kernels, which need the CUs the
+ * next forward's persistent GEMMs own.  The reference has no counterpart (it never calls torch.distributed); this is the
+ * data-path step the north_star prescribes.  tokenpacker_amd/shard.py (DirectGather) drives it; INTEGRATION.md §4 shows
+ * the protocol.  Everything below only enqueues; buffers, flags, streams and events are the caller's.
+ *
+ *   tp_gather_export  IPC handle of the ALLOCATION `ptr` lives in + ptr's offset inside it (hipMemGetAddressRange +
+ *                     hipIpcGetMemHandle): what a peer process needs to address `ptr`.
+ *   tp_gather_open    maps a peer's allocation into this process (peer access enabled lazily); tp_gather_close unmaps it.
+ *   tp_gather_push    for each of n_peers: copy `bytes` from `src` to dst[j], then the 4-byte sequence number in
+ *                     *seq_cell to dst_flag[j], both on streams[j] (stream order: the flag cannot land before the data).
+ *                     use_cus = 0: hipMemcpyDeviceToDeviceNoCU (SDMA) | 1: the runtime's choice (A/B).
+ *   tp_gather_sync    ONE-wave kernel on `stream`: waits until flags[p] has reached wait_seq for every p != rank
+ *                     (wrap-safe signed distance), then stores publish_seq to *seq_cell (NULL: nothing).  A wait longer than
+ *                     timeout_ms (<= 0: 30 s) sets bit 0 of *status (device int32, may be NULL) and gives up — the caller
+ *                     reads status when it synchronises.  flags: device uint32[world] in THIS rank's memory, zeroed
+ *                     once, slot p written only by rank p's tp_gather_push. */
+#define TP_IPC_HANDLE_BYTES 64
+int tp_gather_export(const void* ptr, void* handle /* [TP_IPC_HANDLE_BYTES] */, uint64_t* offset);
+int tp_gather_open(const void* handle, void** base);
+int tp_gather_close(void* base);
+int tp_gather_push(int n_peers, void* const* dst, const void* src, size_t bytes, void* const* dst_flag,
+                   const uint32_t* seq_cell, void* const* streams, int use_cus);
+int tp_gather_sync(const uint32_t* flags, int world, int rank, uint32_t wait_seq, uint32_t* seq_cell,
+                   uint32_t publish_seq, int32_t* status, int timeout_ms, void* stream);
 
 #ifdef __cplusplus
 }

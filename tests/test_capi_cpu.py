@@ -45,7 +45,7 @@ def test_sizes_and_descriptor_validation():
     fold = 4096 * 1024 * 2 + 1024 * 1024 * 2 + 4096 * 1024 * 4 + 1024 * 1024 * 2 + 3 * 1024 * 1024 * 2 + 1024 * 1024 * 2   # (+ w_qt_c)
     assert 36_722_688 * 2 + fold <= packed < 36_722_688 * 2 + fold + 300_000
     ws = lib.tp_workspace_bytes(ctypes.byref(d))
-    assert 1.5e9 < ws < 3.5e9
+    assert 1.0e9 < ws < 1.3e9            # schedule-aware: the s = 2 default writes neither H2 nor K | V nor Q1pre
     # bad scale factor: the reference's ValueError (builder.py:51-52)
     bad = _capi.make_desc(1, 24, 5, 4096, _capi.TP_BF16)
     assert lib.tp_workspace_bytes(ctypes.byref(bad)) == 0
@@ -148,13 +148,68 @@ def test_tuning_keys_match_the_header():
         assert lib.tp_set_tuning(num, _capi._TUNING_DEFAULTS[num]) == _capi.TP_OK
 
 
-def test_workspace_covers_the_small_batch_split_k_partials():
-    """Batches of at most 8 images carry the fp32 partials of the opt-in K-split (512 tiles of 128 x 128) whatever the
-    tuning says at allocation time; larger batches do not pay for it, and the size grows with the batch."""
+def test_workspace_is_schedule_aware_and_an_upper_bound_for_the_tuning_at_call_time():
+    """tp_workspace_bytes sizes the slabs the schedule of the moment writes (plan_schedule): the scale_factor-2 default has no
+    H2 / K | V / Q1pre slab (1.2 GB less at B = 256); a masked forward (TP_DESC_MASKED), the unfused chain and the separate
+    attention kernel need K | V or H2 again; the K-split partials exist only while TP_TUNE_SPLIT_K is on."""
     lib = _capi.load_library()
-    size = {b: lib.tp_workspace_bytes(ctypes.byref(_capi.make_desc(b, 24, 2, 4096, _capi.TP_BF16))) for b in (1, 8, 9, 16, 256)}
-    partials = 512 * 128 * 128 * 4
-    assert size[1] > partials and size[8] > partials
-    assert size[9] < size[8] + 1 or size[9] - size[8] < partials      # the 9th image does not carry another copy
-    assert size[16] > size[9] and size[256] > 15 * size[16] // 2
+    B, N, E = 256, 576, 1024
+    slab = 2 * B * N * E * 2                       # one [2][B N, 1024] fp16 slab (H2, or K | V)
 
+    def size(b=B, s=2, flags=0):
+        d = _capi.make_desc(b, 24, s, 4096, _capi.TP_BF16, flags=flags)
+        return lib.tp_workspace_bytes(ctypes.byref(d))
+    base = size()
+    a1 = B * 144 * E * 2                           # out_proj's output: the fold is off where K | V are rounded in front of attention
+    try:
+        assert slab <= size(flags=_capi.TP_DESC_MASKED) - base <= slab + a1 + 4096    # + K | V (+ A1)
+        _capi.set_tuning(_capi.TP_TUNE_FUSE_ATTN, 1)
+        assert slab <= size() - base <= slab + a1 + 4096                                 # separate attention kernel: + K | V (+ A1)
+        _capi.set_tuning(_capi.TP_TUNE_FUSE_ATTN, 0)
+        _capi.set_tuning(_capi.TP_TUNE_FUSE_KV_LN, 0)
+        assert size() - base >= 2 * slab                                                 # + H2, + K | V, + Q1pre, (+ A1)
+        _capi.set_tuning(_capi.TP_TUNE_FUSE_KV_LN, 1)
+        assert size() == base
+        # absorbed schedule (s = 3): qt | u [2][B M, 8, 1024] instead of K | V, no H2
+        assert size(s=3) < base + 2 * 8 * B * 64 * E * 2
+        # K-split partials: only while the knob is on, only for batches of at most 8 images
+        partials = 512 * 128 * 128 * 4
+        small = size(b=1)
+        _capi.set_tuning(_capi.TP_TUNE_SPLIT_K, 1)
+        assert partials <= size(b=1) - small < partials + 4096 and size(b=9) == size(b=9)
+        big_on = size(b=16)
+        _capi.set_tuning(_capi.TP_TUNE_SPLIT_K, 0)
+        assert size(b=16) == big_on
+    finally:
+        for k, v in _capi._TUNING_DEFAULTS.items():
+            _capi.set_tuning(k, v)
+    assert size(b=16) > size(b=9) and size() > 15 * size(b=16) // 2
+
+
+def test_get_tuning_reads_the_library_table():
+    lib = _capi.load_library()
+    assert lib.tp_get_tuning(99) == -1 and lib.tp_get_tuning(-1) == -1
+    for k, v in _capi._TUNING_DEFAULTS.items():
+        assert _capi.get_tuning(k) == v, k
+    try:
+        assert lib.tp_set_tuning(_capi.TP_TUNE_RESERVE_CUS, 3) == _capi.TP_OK        # a direct call, past the wrapper
+        assert _capi.get_tuning(_capi.TP_TUNE_RESERVE_CUS) == 3
+    finally:
+        _capi.set_tuning(_capi.TP_TUNE_RESERVE_CUS, 0)
+
+
+def test_gather_entry_points_reject_bad_arguments():
+    lib = _capi.load_library()
+    E = _capi.TP_ERR_INVALID_ARG
+    off = ctypes.c_uint64(0)
+    assert lib.tp_gather_export(None, None, ctypes.byref(off)) == E
+    assert lib.tp_gather_open(None, None) == E
+    assert lib.tp_gather_close(None) == E
+    assert lib.tp_gather_sync(None, 2, 0, 0, None, 0, None, 0, None) == E
+    fake = ctypes.c_void_p(4096)
+    assert lib.tp_gather_sync(fake, 0, 0, 0, None, 0, None, 0, None) == E          # world < 1
+    assert lib.tp_gather_sync(fake, 65, 0, 0, None, 0, None, 0, None) == E         # one wave polls at most 64 sources
+    assert lib.tp_gather_sync(fake, 2, 2, 0, None, 0, None, 0, None) == E          # rank out of range
+    assert lib.tp_gather_push(1, None, fake, 16, None, fake, None, 0) == E
+    assert lib.tp_gather_push(0, None, None, 0, None, None, None, 0) == E          # no sequence cell
+    assert _capi.TP_IPC_HANDLE_BYTES == 64

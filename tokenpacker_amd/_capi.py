@@ -9,9 +9,9 @@ from __future__ import annotations
 import ctypes
 import os
 from ctypes import (POINTER, Structure, byref, c_char_p, c_float, c_int, c_int32, c_int64,
-                    c_size_t, c_void_p)
+                    c_size_t, c_uint32, c_uint64, c_void_p)
 
-TP_ABI_VERSION = 2
+TP_ABI_VERSION = 3
 TP_BF16, TP_F16, TP_F32 = 0, 1, 2
 TP_OK, TP_ERR_INVALID_ARG, TP_ERR_BAD_SCALE, TP_ERR_WORKSPACE, TP_ERR_LAUNCH = 0, -1, -2, -3, -4
 TP_LINEAR_GELU, TP_LINEAR_LN_FOLD, TP_LINEAR_ROW_STATS = 1, 2, 4
@@ -42,6 +42,8 @@ EXPORTED_SYMBOLS = (
     "tp_forward_parts", "tp_forward_train_parts", "tp_backward_parts", "tp_test_occupy_cus", "tp_hd_slice",
     "tp_wgrad", "tp_wgrad_workspace_bytes", "tp_packed_status_offset", "tp_debug_count_saturated",
     "tp_region_attention_absorbed", "tp_forward_masked",
+    "tp_get_tuning", "tp_release_stream", "tp_test_side_cache_size",
+    "tp_gather_export", "tp_gather_open", "tp_gather_close", "tp_gather_push", "tp_gather_sync",
 )
 
 # state-dict name -> tp_weights field order (include/tokenpacker.h)
@@ -148,6 +150,22 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.tp_linear_stats_parts.argtypes = [POINTER(tp_linear_args)]
     lib.tp_set_tuning.restype = c_int
     lib.tp_set_tuning.argtypes = [c_int, c_int]
+    lib.tp_get_tuning.restype = c_int
+    lib.tp_get_tuning.argtypes = [c_int]
+    lib.tp_release_stream.restype = c_int
+    lib.tp_release_stream.argtypes = [c_void_p]
+    lib.tp_test_side_cache_size.restype = c_int
+    lib.tp_test_side_cache_size.argtypes = []
+    lib.tp_gather_export.restype = c_int
+    lib.tp_gather_export.argtypes = [c_void_p, c_void_p, POINTER(c_uint64)]
+    lib.tp_gather_open.restype = c_int
+    lib.tp_gather_open.argtypes = [c_void_p, POINTER(c_void_p)]
+    lib.tp_gather_close.restype = c_int
+    lib.tp_gather_close.argtypes = [c_void_p]
+    lib.tp_gather_push.restype = c_int
+    lib.tp_gather_push.argtypes = [c_int, POINTER(c_void_p), c_void_p, c_size_t, POINTER(c_void_p), c_void_p, POINTER(c_void_p), c_int]
+    lib.tp_gather_sync.restype = c_int
+    lib.tp_gather_sync.argtypes = [c_void_p, c_int, c_int, c_uint32, c_void_p, c_uint32, c_void_p, c_int, c_void_p]
     lib.tp_train_workspace_bytes.restype = c_size_t
     lib.tp_train_workspace_bytes.argtypes = [POINTER(tp_desc)]
     lib.tp_backward_workspace_bytes.restype = c_size_t
@@ -203,6 +221,9 @@ def check(rc: int, what: str) -> None:
 
 
 TP_DESC_TRAIN_PACK = 1
+TP_DESC_MASKED = 2
+TP_IPC_HANDLE_BYTES = 64
+TP_WORKSPACE_STATUS_BYTES = 256
 
 
 def make_desc(batch: int, raw_grid: int, scale_factor: int, hidden_size: int, dtype: int,
@@ -215,21 +236,24 @@ def strides3(st) -> "ctypes.Array":
     return (c_int64 * 3)(int(st[0]), int(st[1]), int(st[2]))
 
 
+# the library's defaults (tests reset the table to these)
 _TUNING_DEFAULTS = {TP_TUNE_GEMM_TILE: 0, TP_TUNE_XCD_SWIZZLE: 1, TP_TUNE_GEMM_KERNEL: 0, TP_TUNE_FOLD_OUT_PROJ: 0,
                     TP_TUNE_DYNAMIC_TILES: 1, TP_TUNE_Q_SIDE_STREAM: 1, TP_TUNE_RESERVE_CUS: 0, TP_TUNE_ABSORB_KV: 0, TP_TUNE_FUSE_KV_LN: 1,
                     TP_TUNE_FUSE_ATTN: 0, TP_TUNE_LN_MERGE: 0, TP_TUNE_SPLIT_K: 0, TP_TUNE_SMALL_GEMM_WAVES: 0}
-_tuning_values = dict(_TUNING_DEFAULTS)
 
 
 def set_tuning(key: int, value: int) -> None:
     """Process-wide tuning table of the library (benchmarks / tests; NOT reentrant: include/tokenpacker.h)."""
     check(load_library().tp_set_tuning(key, value), "tp_set_tuning")
-    _tuning_values[key] = value
 
 
 def get_tuning(key: int) -> int:
-    """Last value set through :func:`set_tuning` in this process (the library's default otherwise)."""
-    return _tuning_values.get(key, 0)
+    """The library's current value of a tuning key (``tp_get_tuning``: the table itself, not a copy kept on this side —
+    another binding or a direct ``tp_set_tuning`` call cannot make it lie)."""
+    v = load_library().tp_get_tuning(key)
+    if v == -1 and not (0 <= key < 16):
+        raise ValueError(f"tp_get_tuning: {last_error()}")
+    return v
 
 
 __all__ = [n for n in dir() if n.startswith(("TP_", "tp_"))] + [

@@ -69,7 +69,7 @@ PackedLayout packed_layout(int D) {
     return L;
 }
 
-WorkspaceLayout workspace_layout(int B, int grid, int s, int D, bool train) {
+WorkspaceLayout workspace_layout(int B, int grid, int s, int D, const SchedulePlan& P) {
     WorkspaceLayout L{};
     const size_t N = (size_t)grid * grid, G = grid / s, M = G * G, E = kEmbed;
     const size_t rows_kv = (size_t)B * N, rows_q = (size_t)B * M;
@@ -77,26 +77,38 @@ WorkspaceLayout workspace_layout(int B, int grid, int s, int D, bool train) {
     L.stats_parts_q = gemm_stats_parts(kEmbed);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
+    auto take_if = [&](bool need, size_t bytes) { return need ? take(bytes) : kNoSlab; };
+    L.status = take(256);                                   // offset 0 whatever the schedule: the caller zeroes it once
     L.q0 = take(rows_q * E * 2);
     L.hkv = take(rows_kv * 2 * E * 2);
-    L.h2 = take(2 * rows_kv * E * 2);
+    {
+        const size_t lg = kHeads * rows_kv * 4, mru = kHeads * rows_q * 2 * 4;
+        L.attn_aux = take(lg > mru ? lg : mru);
+    }
+    L.h2 = take_if(P.need_h2, 2 * rows_kv * E * 2);
     L.stats_kv = take(2 * (size_t)8 * rows_kv * 2 * 4);     // up to 8 slabs (tile 128) per group
     L.mr_kv = take(2 * rows_kv * 2 * 4);                    // per-row (mean, rstd), 2 groups
-    // K | V [2][rows_kv, E]; the absorbed schedule keeps qt | u [2][rows_q, 8, E] there instead
-    L.kv = take(2 * (rows_kv > 8 * rows_q ? rows_kv : 8 * rows_q) * E * 2);
-    L.q1pre = take(rows_q * E * 2);
+    // K | V [2][rows_kv, E] (training, masked / plain schedules); the absorbed schedule keeps qt | u [2][rows_q, 8, E] there
+    L.kv = take_if(P.need_kv, P.absorb ? 2 * 8 * rows_q * E * 2 : 2 * rows_kv * E * 2);
+    L.q1pre = take_if(P.need_q1pre, rows_q * E * 2);
     L.stats_q = take((size_t)8 * rows_q * 2 * 4);
     L.mr_q = take(rows_q * 2 * 4);
     L.q = take(rows_q * E * 2);
     L.o = take(rows_q * E * 2);
-    L.a1 = take(rows_q * E * 2);
+    L.a1 = take_if(P.need_a1, rows_q * E * 2);
     L.a2 = take(rows_q * (size_t)D * 2);
     L.counters = take(4096);
-    L.splitk = take(B <= 8 ? kSplitKBytes : 0);
-    L.z1 = L.z2 = 0;
-    if (train) { L.z1 = take(rows_kv * 2 * E * 2); L.z2 = take(rows_q * (size_t)D * 2); }
+    L.splitk = take_if(P.split_k, kSplitKBytes);
+    L.z1 = L.z2 = kNoSlab;
+    if (P.train) { L.z1 = take(rows_kv * 2 * E * 2); L.z2 = take(rows_q * (size_t)D * 2); }
     L.total = off;
     return L;
+}
+
+WorkspaceLayout workspace_layout(int B, int grid, int s, int D, bool train) {
+    tp_desc d{};
+    d.batch = B; d.raw_grid = grid; d.scale_factor = s; d.hidden_size = D; d.dtype = TP_BF16; d.out_dtype = TP_BF16; d.ln_eps = 1e-6f;
+    return workspace_layout(B, grid, s, D, plan_schedule(&d, train, false));
 }
 
 int validate_desc(const tp_desc* d) {
@@ -127,32 +139,91 @@ int validate_desc(const tp_desc* d) {
         return TP_ERR_INVALID_ARG;
     }
     if (!(d->ln_eps > 0.f)) { set_error("tp_desc: ln_eps must be > 0"); return TP_ERR_INVALID_ARG; }
-    if (d->flags & ~TP_DESC_TRAIN_PACK) { set_error("tp_desc: unknown flags 0x%x", d->flags); return TP_ERR_INVALID_ARG; }
+    if (d->flags & ~(TP_DESC_TRAIN_PACK | TP_DESC_MASKED)) { set_error("tp_desc: unknown flags 0x%x", d->flags); return TP_ERR_INVALID_ARG; }
     return TP_OK;
 }
 
 // The absorbed schedule (region_attention_absorbed_kernel's header): auto = scale_factor >= 3, where the two in-projection
 // GEMMs over the B*576 fine tokens cost far more than the 1/s^2-sized query-side work that replaces them (at s = 2 the
 // [B M, 8, 1024] intermediates cost what the GEMMs save).  Inference only: the backward needs K and V.
-// out_proj folded into mlp[0] (W = Wm0·Wout): TP_TUNE_FOLD_OUT_PROJ 0 = auto, 1 = always, 2 = never.  Auto folds on the
-// absorbed schedule and on the scale_factor-2 schedule with attention in the in-projections' epilogues: the fold removes a
-// 2.25-round launch (-2.3 % of the B = 256 forward) and moves the max-norm parity metric by its own noise — worst golden
-// case on s = 2: 0.68e-3 without, 0.79e-3 with it, rel-L2 unchanged (0.654e-3); on s >= 3: 0.967e-3 / 0.926e-3
-// (tools/fold_parity.py).  Not on the plain schedules (K and V rounded to fp16 before attention): there the worst case sat
-// at 0.984e-3 / 0.992e-3 of a 1e-3 gate.
-bool fold_out_proj(const tp_desc* d, bool train) {
-    if (train) return false;                            // the backward needs A1 and the plain weights
-    const int mode = tuning(TP_TUNE_FOLD_OUT_PROJ);
-    if (mode != 0) return mode == 1;
-    return absorb_kv(d, false) ||
-           (d->scale_factor == 2 && tuning(TP_TUNE_FUSE_KV_LN) != 0 && tuning(TP_TUNE_FUSE_ATTN) == 0);
-}
-
 bool absorb_kv(const tp_desc* d, bool train) {
     if (train) return false;
     const int s2 = d->scale_factor * d->scale_factor, mode = tuning(TP_TUNE_ABSORB_KV);
     if (s2 > 64 || mode == 1) return false;
     return mode == 2 || d->scale_factor >= 3;
+}
+
+// ONE place decides the schedule of a forward (SchedulePlan, tp_internal.h).
+// out_proj folded into mlp[0] (W = Wm0·Wout): TP_TUNE_FOLD_OUT_PROJ 0 = auto, 1 = always, 2 = never.  Auto folds where K and V
+// are not rounded to fp16 in front of attention — the absorbed schedule and attention in the in-projections' epilogues: the
+// fold removes a 2.25-round launch (-2.3 % of the B = 256 forward) and moves the max-norm parity metric by its own noise
+// (worst s = 2 golden case 0.68e-3 without, 0.79e-3 with it, rel-L2 unchanged; tools/fold_parity.py).  It is decided PER
+// FORWARD from what actually runs: a masked forward, or a grid whose rows per image are not a multiple of 8, falls back to
+// the plain schedule (K, V rounded) and therefore does NOT fold — there the worst case sat at 0.984e-3 / 0.992e-3 of the
+// 1e-3 gate.  The folded weight is part of every inference pack, so the choice needs no re-pack.
+SchedulePlan plan_schedule(const tp_desc* d, bool train, bool masked) {
+    SchedulePlan P{};
+    const int s = d->scale_factor, N = d->raw_grid * d->raw_grid;
+    const bool chain = tuning(TP_TUNE_FUSE_KV_LN) != 0;
+    P.train = train;
+    P.absorb = absorb_kv(d, train);
+    P.absorb_raw = P.absorb && chain;
+    P.fuse_ln = !train && !P.absorb && chain;
+    P.fuse_q = !train && chain;
+    P.region_major = P.fuse_ln && s == 2 && (N % 8) == 0 && !masked && tuning(TP_TUNE_FUSE_ATTN) != 1;
+    P.fuse_attn = P.region_major && tuning(TP_TUNE_FUSE_ATTN) == 0;
+    const int fmode = tuning(TP_TUNE_FOLD_OUT_PROJ);
+    P.fold = !train && (fmode == 1 || (fmode == 0 && (P.absorb || P.fuse_attn)));
+    P.split_k = tuning(TP_TUNE_SPLIT_K) == 1 && !train && d->batch <= 8;
+    P.need_h2 = train || !(P.fuse_ln || P.absorb_raw);
+    P.need_kv = train || P.absorb || !P.fuse_attn;
+    P.need_q1pre = !P.fuse_q;
+    P.need_a1 = !P.fold;
+    return P;
+}
+
+bool fold_out_proj(const tp_desc* d, bool train) { return plan_schedule(d, train, false).fold; }
+
+// Host-side record of what tp_pack_weights put into an image (keyed by device + address; the image itself lives in device
+// memory, and a forward must not synchronise to read a header back).  The forward entry points refuse an image that cannot
+// serve them — a TRAIN_PACK image handed to an inference entry point, or an image packed for another hidden size / dtype —
+// instead of multiplying by weights that were never written.  An address the registry has not seen (an image the caller
+// copied elsewhere) is accepted unchecked.  256 entries, least recently packed first out.
+struct PackRec { int dev; const void* ptr; int train_pack, D, dtype; unsigned long long stamp; };
+static std::mutex g_pack_mu;
+static std::vector<PackRec> g_pack_reg;
+static unsigned long long g_pack_clock = 0;
+void pack_registry_put(const void* packed, const tp_desc* d, bool train_pack) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lock(g_pack_mu);
+    for (auto& r : g_pack_reg)
+        if (r.dev == dev && r.ptr == packed) { r.train_pack = train_pack; r.D = d->hidden_size; r.dtype = d->dtype; r.stamp = ++g_pack_clock; return; }
+    if (g_pack_reg.size() >= 256) {
+        size_t lru = 0;
+        for (size_t i = 1; i < g_pack_reg.size(); ++i) if (g_pack_reg[i].stamp < g_pack_reg[lru].stamp) lru = i;
+        g_pack_reg.erase(g_pack_reg.begin() + (long)lru);
+    }
+    g_pack_reg.push_back(PackRec{dev, packed, train_pack ? 1 : 0, d->hidden_size, d->dtype, ++g_pack_clock});
+}
+int pack_registry_check(const void* packed, const tp_desc* d, bool train) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return TP_OK;
+    std::lock_guard<std::mutex> lock(g_pack_mu);
+    for (const auto& r : g_pack_reg)
+        if (r.dev == dev && r.ptr == packed) {
+            if (r.D != d->hidden_size || r.dtype != d->dtype) {
+                set_error("packed weights at %p were packed for hidden_size %d / dtype %d, the forward asks for %d / %d", packed, r.D, r.dtype,
+                          d->hidden_size, d->dtype);
+                return TP_ERR_INVALID_ARG;
+            }
+            if (r.train_pack && !train) {
+                set_error("packed weights at %p are a TP_DESC_TRAIN_PACK image (no inference-only weights): tp_forward_train only", packed);
+                return TP_ERR_INVALID_ARG;
+            }
+            return TP_OK;
+        }
+    return TP_OK;
 }
 
 GemmArgs plain_gemm(const void* A, long long lda_elems, const void* W, void* C, long long ldc,
@@ -180,6 +251,11 @@ int tp_set_tuning(int key, int value) {
     if (key < 0 || key >= TP_TUNE_COUNT_) { set_error("tp_set_tuning: bad key %d", key); return TP_ERR_INVALID_ARG; }
     g_tuning[key].store(value);
     return TP_OK;
+}
+
+int tp_get_tuning(int key) {
+    if (key < 0 || key >= TP_TUNE_COUNT_) { set_error("tp_get_tuning: bad key %d", key); return -1; }
+    return g_tuning[key].load();
 }
 
 }  // extern "C"
@@ -212,7 +288,9 @@ size_t tp_workspace_bytes(const tp_desc* desc) {
     if (validate_desc(desc) != TP_OK) return 0;
     const long long bc = max_images_per_launch(desc);    // larger batches run as chunks of this size through one workspace
     const int b = (bc >= 1 && desc->batch > bc) ? (int)bc : desc->batch;
-    return workspace_layout(b, desc->raw_grid, desc->scale_factor, desc->hidden_size).total;
+    tp_desc d = *desc; d.batch = b;
+    return workspace_layout(b, desc->raw_grid, desc->scale_factor, desc->hidden_size,
+                            plan_schedule(&d, false, (desc->flags & TP_DESC_MASKED) != 0)).total;
 }
 
 int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, size_t packed_bytes,
@@ -280,7 +358,9 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
     //   of H2 — which is then computed for those statistics only and never written (604 MB less written and read per
     //   B = 256 forward, 16 fewer output stores per tile of that GEMM).  W' is the ROUNDED folded weight, so the mean
     //   term still cancels against c = rowsum(W') exactly as in the unfused form.
-    if (tuning(TP_TUNE_FUSE_KV_LN) != 0 && !train_pack) {
+    // Every INFERENCE pack carries every inference-only weight, whatever the tuning table says at pack time: the schedule is
+    // chosen per forward (plan_schedule) and must find its operands whichever knob was turned in between.
+    if (!train_pack) {
         for (int g = 0; g < 2; ++g) {
             TP_TRY(pack_transpose_f16_launch(P + L.w_kv2 + (size_t)g * E * E * 2, P + L.scratch_t, (int)E, stream));   // W2^T [k][j]
             GemmArgs a = plain_gemm(P + L.w_in_kv + (size_t)g * E * E * 2, E, P + L.scratch_t, P + L.scratch_p, E, (int)E, (int)E,
@@ -304,9 +384,9 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
         if (e != hipSuccess) { set_error("tp_pack_weights: hipMemsetD32Async(status): %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
     }
     // out_proj folded into mlp[0]:  W_om = Wm0·Wout (fp32 accumulate on the MFMA kernel, rounded once to fp16),
-    // b_om = Wm0·bout + bm0 — built only when fold_out_proj() says so AT PACK TIME (never for a training pack: a training
-    // step re-packs every step and must not pay for a product it never uses); status[1] records it.
-    if (fold_out_proj(desc, train_pack)) {
+    // b_om = Wm0·bout + bm0 — in every inference pack (never in a training pack: a training step re-packs every step and
+    // must not pay for a product it never uses); status[1] records it.
+    if (!train_pack) {
         TP_TRY(pack_transpose_f16_launch(P + L.w_out, P + L.scratch_t, (int)E, stream));
         {
             GemmArgs a = plain_gemm(P + L.w_m0, E, P + L.scratch_t, P + L.scratch_p, E, D, (int)E, (int)E, nullptr, 0);
@@ -319,6 +399,7 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
         hipError_t e = hipMemsetD32Async((hipDeviceptr_t)(status + 1), 1, 1, stream);
         if (e != hipSuccess) { set_error("tp_pack_weights: hipMemsetD32Async(status): %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
     }
+    pack_registry_put(packed, desc, train_pack);
     return TP_OK;
 }
 
@@ -369,24 +450,24 @@ int tp_debug_count_saturated(const tp_desc* desc, const void* workspace, size_t 
     if (!workspace || !counts) { set_error("tp_debug_count_saturated: NULL argument"); return TP_ERR_INVALID_ARG; }
     const int B = desc->batch, g = desc->raw_grid, s = desc->scale_factor, D = desc->hidden_size;
     if (B > max_images_per_launch(desc)) { set_error("tp_debug_count_saturated: batch was served in chunks; scan a smaller batch"); return TP_ERR_INVALID_ARG; }
-    const WorkspaceLayout W = workspace_layout(B, g, s, D, false);
+    const SchedulePlan plan = plan_schedule(desc, false, (desc->flags & TP_DESC_MASKED) != 0);    // (the schedule of the forward scanned)
+    const WorkspaceLayout W = workspace_layout(B, g, s, D, plan);
     if (workspace_bytes < W.total) { set_error("tp_debug_count_saturated: workspace %zu B < %zu B", workspace_bytes, W.total); return TP_ERR_WORKSPACE; }
     hipStream_t stream = (hipStream_t)stream_;
     const long long rows_kv = (long long)B * g * g, rows_q = (long long)B * (g / s) * (g / s), E = kEmbed;
     const char* ws = (const char*)workspace;
+    auto n_if = [](size_t off, long long n) -> long long { return off == kNoSlab ? 0 : n; };     // a slab the schedule does not have: nothing to scan
     const struct { size_t off; long long n; } bufs[TP_NUM_DEBUG_BUFFERS] = {
-        // (the absorbed schedule keeps qt | u [2][rows_q, 8, E] where K | V would be)
         {W.q0, rows_q * E}, {W.hkv, rows_kv * 2 * E},
-        {W.h2, tuning(TP_TUNE_FUSE_KV_LN) != 0 ? 0 : 2 * rows_kv * E},     // (fused chain, plain or absorbed: H2 is never written)
-        // (attention in the in-projections' epilogues, TP_TUNE_FUSE_ATTN: K | V are never written.  The mask-less forward is assumed.)
-        {W.kv, absorb_kv(desc, false) ? 2 * rows_q * 8 * E
-               : (s == 2 && (g * g) % 8 == 0 && tuning(TP_TUNE_FUSE_KV_LN) != 0 && tuning(TP_TUNE_FUSE_ATTN) == 0) ? 0 : 2 * rows_kv * E},
-        {W.q1pre, tuning(TP_TUNE_FUSE_KV_LN) != 0 ? 0 : rows_q * E},                                  // (fused chain: never written)
-        {W.q, rows_q * E}, {W.o, rows_q * E}, {W.a1, fold_out_proj(desc, false) ? 0 : rows_q * E}, {W.a2, rows_q * (long long)D}};
+        {W.h2, n_if(W.h2, 2 * rows_kv * E)},
+        // (the absorbed schedule keeps qt | u [2][rows_q, 8, E] where K | V would be)
+        {W.kv, n_if(W.kv, plan.absorb ? 2 * rows_q * 8 * E : 2 * rows_kv * E)},
+        {W.q1pre, n_if(W.q1pre, rows_q * E)},
+        {W.q, rows_q * E}, {W.o, rows_q * E}, {W.a1, n_if(W.a1, rows_q * E)}, {W.a2, rows_q * (long long)D}};
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * TP_NUM_DEBUG_BUFFERS, stream);
     if (e != hipSuccess) { set_error("tp_debug_count_saturated: hipMemsetAsync: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
     for (int i = 0; i < TP_NUM_DEBUG_BUFFERS; ++i)
-        TP_TRY(count_saturated_launch(ws + bufs[i].off, bufs[i].n, counts + i, stream));
+        if (bufs[i].n > 0) TP_TRY(count_saturated_launch(ws + bufs[i].off, bufs[i].n, counts + i, stream));
     return TP_OK;
 }
 
@@ -489,23 +570,52 @@ namespace tp {
 // persistent GEMMs instead of running alone at 2.25 CU rounds.  One side stream + event pair per caller stream,
 // created on first use (the only state the library keeps besides the tuning table and the error string).
 struct SideCtx { hipStream_t s; hipEvent_t fork, join; };
-static SideCtx* side_ctx_for(hipStream_t main) {
-    static std::mutex mu;
-    static std::vector<std::pair<std::pair<int, hipStream_t>, SideCtx>> cache;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    for (auto& e : cache)
-        if (e.first.first == dev && e.first.second == main) return &e.second;
-    if (cache.size() >= 64) return nullptr;                 // unbounded stream churn: fall back to one stream
-    SideCtx c{};
-    if (hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-    cache.reserve(64);
-    cache.push_back({{dev, main}, c});
-    return &cache.back().second;
+struct SideEntry { int dev; hipStream_t main; SideCtx ctx; unsigned long long stamp; };
+static std::mutex g_side_mu;
+static std::vector<SideEntry> g_side_cache;
+static unsigned long long g_side_clock = 0;
+static void side_entry_destroy(SideEntry& e) {      // (called with the lock held)
+    (void)hipStreamSynchronize(e.ctx.s);            // whatever was forked onto it has been joined by its forward; be sure anyway
+    (void)hipEventDestroy(e.ctx.fork);
+    (void)hipEventDestroy(e.ctx.join);
+    (void)hipStreamDestroy(e.ctx.s);
 }
+// The side stream of (device, caller stream), created on first use; at most 64 per process, least recently used first out.
+// Returned BY VALUE: an entry evicted or released by another thread does not leave this forward with a dangling pointer
+// (HIP defers the destruction of a stream / event that still has work queued).
+static bool side_ctx_for(hipStream_t main, SideCtx* out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    for (auto& e : g_side_cache)
+        if (e.dev == dev && e.main == main) { e.stamp = ++g_side_clock; *out = e.ctx; return true; }
+    if (g_side_cache.size() >= 64) {
+        size_t lru = 0;
+        for (size_t i = 1; i < g_side_cache.size(); ++i) if (g_side_cache[i].stamp < g_side_cache[lru].stamp) lru = i;
+        side_entry_destroy(g_side_cache[lru]);
+        g_side_cache.erase(g_side_cache.begin() + (long)lru);
+    }
+    SideCtx c{};
+    if (hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(c.s); return false; }
+    if (hipEventCreateWithFlags(&c.join, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(c.fork); (void)hipStreamDestroy(c.s); return false; }
+    g_side_cache.push_back(SideEntry{dev, main, c, ++g_side_clock});
+    *out = c;
+    return true;
+}
+int release_stream_state(hipStream_t main) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { set_error("tp_release_stream: hipGetDevice failed"); return TP_ERR_LAUNCH; }
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    for (size_t i = 0; i < g_side_cache.size(); ++i)
+        if (g_side_cache[i].dev == dev && g_side_cache[i].main == main) {
+            side_entry_destroy(g_side_cache[i]);
+            g_side_cache.erase(g_side_cache.begin() + (long)i);
+            break;
+        }
+    return TP_OK;
+}
+int side_cache_size() { std::lock_guard<std::mutex> lock(g_side_mu); return (int)g_side_cache.size(); }
 
 int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3], const void* x_multi,
                  const int64_t xm_strides[3], const void* packed_weights, void* out, void* workspace,
@@ -553,11 +663,15 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     const int N = g * g, G = g / s, M = G * G, E = kEmbed;
     const int rows_kv = B * N, rows_q = B * M;
     const PackedLayout P = packed_layout(D);
-    const WorkspaceLayout W = workspace_layout(B, g, s, D, train);
+    tp_desc dplan = *desc; dplan.batch = B;
+    const SchedulePlan plan = plan_schedule(&dplan, train, attn_mask != nullptr);
+    const WorkspaceLayout W = workspace_layout(B, g, s, D, plan);
     if (workspace_bytes < W.total) {
-        set_error("tp_forward: workspace %zu B < required %zu B", workspace_bytes, W.total);
+        set_error("tp_forward: workspace %zu B < required %zu B%s", workspace_bytes, W.total,
+                  attn_mask ? " (a masked forward: size it with TP_DESC_MASKED in tp_desc.flags)" : "");
         return TP_ERR_WORKSPACE;
     }
+    TP_TRY(pack_registry_check(packed_weights, desc, train));
     if (((uintptr_t)workspace & 255) || ((uintptr_t)packed_weights & 255) || ((uintptr_t)out & 15)) {
         set_error("tp_forward: workspace/packed buffers must be 256-byte aligned, out 16-byte aligned");
         return TP_ERR_INVALID_ARG;
@@ -565,6 +679,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     hipStream_t stream = (hipStream_t)stream_;
     const char* pw = (const char*)packed_weights;
     char* ws = (char*)workspace;
+    auto slab = [&](size_t off) -> char* { return off == kNoSlab ? nullptr : ws + off; };      // a slab the schedule does not have: NULL
     const long long kvE = (long long)rows_kv * E;      // elements per K/V group slab
     // Hkv: training keeps [rows, 2048] (K half | V half per row: what the backward reads); inference writes a K slab and a V
     // slab [rows, 1024] each (GemmArgs::c_split_cols), so that everything behind the first layer walks contiguous rows
@@ -579,8 +694,10 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         if (e != hipSuccess) { set_error("tp_forward: hipMemsetAsync: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
     }
     int launch_no = 0;
+    int stage_idx = 0;                                  // advanced by mark(): 1 .. TP_NUM_STAGES while stage k - 1 is being enqueued
     auto launch = [&](int in_dt, int out_dt, GemmArgs& a, hipStream_t st) -> int {
         a.tile_counters = counters ? counters + 64 * launch_no++ : nullptr;      // [groups <= 8][8 XCDs] heads per launch
+        a.sat_flag = (int*)(ws + W.status); a.sat_bit = 1 << stage_idx;          // sticky fp16-saturation bits, by stage (bit 0: query side)
         return gemm_launch(in_dt, out_dt, a, st);
     };
     // TP_TUNE_SPLIT_K: a latency-bound K = 4096 GEMM of a small batch as S K-groups of the 128-tile kernel (fp32 partials)
@@ -588,26 +705,27 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     auto launch_maybe_splitk = [&](int in_dt, int out_dt, GemmArgs& a, hipStream_t st) -> int {
         const long long tiles = (long long)((a.M + 127) / 128) * (a.N / 128);
         int S = 1;
-        if (tuning(TP_TUNE_SPLIT_K) == 1 && !train && B <= 8 && !a.A_parts[0] && a.groups == 1 && (a.flags & ~TP_LINEAR_GELU) == 0)
+        if (plan.split_k && !a.A_parts[0] && a.groups == 1 && (a.flags & ~TP_LINEAR_GELU) == 0)
             while (S < 8 && tiles * (S * 2) <= 512 && a.K / (S * 2) >= 4 * BK_ELEMS && a.K % (S * 2 * BK_ELEMS) == 0) S *= 2;
         if (S < 4) return launch(in_dt, out_dt, a, st);    // (two K-groups do not pay for the partials' round trip: measured)
         GemmArgs p = a;
         p.groups = S; p.K = a.K / S;
         p.a_gs = (long long)p.K * 2; p.w_gs = (long long)p.K * 2;
         p.ldw_bytes = a.ldw_bytes ? a.ldw_bytes : (long long)a.K * 2;
-        p.C = ws + W.splitk; p.ldc = a.N; p.c_gs = (long long)a.M * a.N * 4;
+        p.C = slab(W.splitk); p.ldc = a.N; p.c_gs = (long long)a.M * a.N * 4;
         p.bias = nullptr; p.flags = 0; p.tile = 128; p.c_split_cols = 0;
         TP_TRY(launch(in_dt, TP_F32, p, st));
-        return splitk_reduce_launch((const float*)(ws + W.splitk), S, a.M, a.N, a.bias, (a.flags & TP_LINEAR_GELU) ? 1 : 0, a.C, a.ldc,
+        return splitk_reduce_launch((const float*)slab(W.splitk), S, a.M, a.N, a.bias, (a.flags & TP_LINEAR_GELU) ? 1 : 0, a.C, a.ldc,
                                     out_dt, st, a.c_split_cols, a.c_split_stride_bytes / (out_dt == TP_F32 ? 4 : 2));
     };
     // query side on a side stream (not when the caller wants per-stage events: those need one stream)
-    SideCtx* side = (tuning(TP_TUNE_Q_SIDE_STREAM) && !stage_events) ? side_ctx_for(stream) : nullptr;
+    SideCtx side_storage{};
+    SideCtx* side = (tuning(TP_TUNE_Q_SIDE_STREAM) && !stage_events && side_ctx_for(stream, &side_storage)) ? &side_storage : nullptr;
     const int parts_q = gemm_stats_parts(E);
     // (fused LayerNorm chain, inference: Q1pre is computed for its row statistics only; the in-projection reads q0)
-    const bool fuse_q = !train && tuning(TP_TUNE_FUSE_KV_LN) != 0;
+    const bool fuse_q = plan.fuse_q;
     auto q_proj = [&](hipStream_t st) -> int {          // 5. Q1pre = q0 · Wq1^T (no bias), LayerNorm partials
-        GemmArgs a = plain_gemm(ws + W.q0, E, pw + P.w_q1, fuse_q ? nullptr : ws + W.q1pre, E, rows_q, E, E, nullptr,
+        GemmArgs a = plain_gemm(ws + W.q0, E, pw + P.w_q1, slab(W.q1pre), E, rows_q, E, E, nullptr,
                                 TP_LINEAR_ROW_STATS | (fuse_q ? TP_LINEAR_NO_STORE : 0));
         a.stats_out = (float*)(ws + W.stats_q);
         return launch(TP_F16, TP_F16, a, st);
@@ -623,7 +741,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     };
     static_assert(kEmbed / 128 == 8, "ln_merge_slabs<8>");
     auto q_inproj = [&](hipStream_t st) -> int {        // 6. Q = LN(Q1pre) · Winq^T + b
-        GemmArgs a = plain_gemm(fuse_q ? ws + W.q0 : ws + W.q1pre, E, fuse_q ? pw + P.w_c_q : pw + P.w_in_q, ws + W.q, E, rows_q, E, E,
+        GemmArgs a = plain_gemm(fuse_q ? ws + W.q0 : slab(W.q1pre), E, fuse_q ? pw + P.w_c_q : pw + P.w_in_q, ws + W.q, E, rows_q, E, E,
                                 (const float*)(pw + P.b_in_q), TP_LINEAR_LN_FOLD);
         a.stats_in = (const float*)(ws + W.mr_q);
         a.colsum = (const float*)(pw + P.c_in_q);
@@ -632,18 +750,19 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
                                       desc->ln_eps, st));
         return launch(TP_F16, TP_F16, a, st);
     };
-    const bool absorb = absorb_kv(desc, train);
+    const bool absorb = plan.absorb;
     // (fused LayerNorm chain — inference, plain schedule: H2 is needed for its row statistics only and is not written)
-    const bool fuse_ln = !train && !absorb && tuning(TP_TUNE_FUSE_KV_LN) != 0;
+    const bool fuse_ln = plan.fuse_ln;
     // scale_factor 2 on that chain: region-major K/V rows, and region attention inside the in-projections' epilogues
     // (the attention epilogues want 8 | rows per image — region pairs in the query DMA —: every even grid but 6, 10, 14, …;
     // decided per image, not per batch, so that an image's bits do not depend on the batch it travels in)
     // (absorbed schedule on the fused chain: H2 for its statistics only, the attention kernel walks Hkv — RAW form)
-    const bool absorb_raw = absorb && tuning(TP_TUNE_FUSE_KV_LN) != 0;
-    const bool region_major = fuse_ln && s == 2 && (N % 8) == 0 && !attn_mask && tuning(TP_TUNE_FUSE_ATTN) != 1;
-    const bool fuse_attn = region_major && tuning(TP_TUNE_FUSE_ATTN) == 0;
-    char* const qt = ws + W.kv;                                        // [rows_q, 8, E] fp16 (absorbed schedule)
-    char* const uu = ws + W.kv + (size_t)rows_q * 8 * E * 2;           // [rows_q, 8, E] fp16
+    const bool absorb_raw = plan.absorb_raw;
+    const bool region_major = plan.region_major;
+    const bool fuse_attn = plan.fuse_attn;
+    char* const kv_slab = slab(W.kv);                                  // K | V, or qt | u on the absorbed schedule (NULL: neither)
+    char* const qt = kv_slab;                                          // [rows_q, 8, E] fp16 (absorbed schedule)
+    char* const uu = kv_slab ? kv_slab + (size_t)rows_q * 8 * E * 2 : nullptr;   // [rows_q, 8, E] fp16
     auto qt_gemm = [&](hipStream_t st) -> int {         // qt[m, h, :] = Q[m, h*128:(h+1)*128] · W'k[h*128:(h+1)*128, :]
         GemmArgs a = plain_gemm(ws + W.q, E, absorb_raw ? pw + P.w_qt_c : pw + P.w_qt, qt, 8 * E, rows_q, E, kHeadDim, nullptr, 0);
         a.groups = kHeads; a.a_gs = kHeadDim * 2; a.w_gs = (long long)E * kHeadDim * 2; a.c_gs = E * 2;
@@ -660,7 +779,6 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         e = hipEventRecord(side->join, side->s);
         if (e != hipSuccess) { set_error("tp_forward: side stream join: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
     }
-    int stage_idx = 0;
     auto mark = [&]() -> int {
         if (stage_events) {
             hipError_t e = hipEventRecord((hipEvent_t)stage_events[stage_idx], stream);
@@ -695,7 +813,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     const int parts_kv = gemm_stats_parts(E);
     {
         const bool stats_only = fuse_ln || absorb_raw;
-        GemmArgs a = plain_gemm(ws + W.hkv, hkv_ld, pw + P.w_kv2, stats_only ? nullptr : ws + W.h2, E, rows_kv, E, E,
+        GemmArgs a = plain_gemm(ws + W.hkv, hkv_ld, pw + P.w_kv2, stats_only ? nullptr : slab(W.h2), E, rows_kv, E, E,
                                 (const float*)(pw + P.b_kv2), TP_LINEAR_ROW_STATS | (stats_only ? TP_LINEAR_NO_STORE : 0));
         a.groups = 2; a.a_gs = hkv_gs; a.w_gs = (long long)E * E * 2; a.c_gs = kvE * 2; a.bias_gs = E;
         a.stats_out = (float*)(ws + W.stats_kv); a.stats_out_gs = (long long)parts_kv * rows_kv * 2;
@@ -730,7 +848,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         a.colsum = (const float*)(pw + P.c_in_kv) + kv * E;
         a.attn_mode = kv + 1;
         a.attn_q = ws + W.q; a.attn_ldq_bytes = E * 2;
-        a.attn_logits = (float*)(ws + W.h2);            // [8 heads][rows_kv] fp32 (H2 is not written on this chain)
+        a.attn_logits = (float*)(ws + W.attn_aux);      // [8 heads][rows_kv] fp32
         a.attn_scale = 0.08838834764831845f;            // 1/sqrt(128): q scaling of F.multi_head_attention_forward
         if (!merge_in_kernel(a, (const float*)(ws + W.stats_kv) + (size_t)kv * parts_kv * rows_kv * 2, 0)) TP_TRY(kv_finalize());
         return launch(TP_F16, TP_F16, a, stream);
@@ -741,7 +859,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     } else
     if (!absorb) {
         TP_TRY(kv_finalize());
-        GemmArgs a = plain_gemm(ws + W.h2, E, pw + P.w_in_kv, ws + W.kv, E, rows_kv, E, E,
+        GemmArgs a = plain_gemm(slab(W.h2), E, pw + P.w_in_kv, kv_slab, E, rows_kv, E, E,
                                 (const float*)(pw + P.b_in_kv), TP_LINEAR_LN_FOLD);
         a.groups = 2; a.a_gs = kvE * 2; a.w_gs = (long long)E * E * 2; a.c_gs = kvE * 2; a.bias_gs = E;
         if (fuse_ln) {                                  // {K,V} = rstd·(Hkv[:, g]·Wc^T + d − mu·c) + b'
@@ -764,13 +882,13 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         TP_TRY(attn_gemm(1));
     } else if (absorb) {
         TP_TRY(kv_finalize());
-        float* const mr_u = (float*)(ws + W.h2);           // RAW: (e / a, a) per head and query (H2 is not written then)
+        float* const mr_u = (float*)(ws + W.attn_aux);     // RAW: (e / a, a) per head and query
         if (absorb_raw)
             TP_TRY(region_attention_absorbed_launch(qt, ws + W.hkv, ws + W.hkv + (size_t)hkv_gs, (const float*)(ws + W.mr_kv),
                                                     (const float*)(ws + W.mr_kv) + (size_t)rows_kv * 2, uu, B, g, s, stream, attn_mask, mask_mode,
                                                     (int)hkv_ld, ws + W.q, (const float*)(pw + P.d_in_kv), (const float*)(pw + P.c_in_kv), mr_u));
         else
-            TP_TRY(region_attention_absorbed_launch(qt, ws + W.h2, ws + W.h2 + kvE * 2, (const float*)(ws + W.mr_kv),
+            TP_TRY(region_attention_absorbed_launch(qt, slab(W.h2), slab(W.h2) + kvE * 2, (const float*)(ws + W.mr_kv),
                                                     (const float*)(ws + W.mr_kv) + (size_t)rows_kv * 2, uu, B, g, s, stream, attn_mask, mask_mode));
         // O[:, h*128:(h+1)*128] = u[:, h, :] · W'v[h*128:(h+1)*128, :]^T + b'v   (eight N = 128 groups)
         // RAW: a_h (u_h · Wc_v,h^T + d_v,h - (e_h / a_h) c_v,h) + b'v,h — a LayerNorm-fold epilogue with (mean, rstd) := mr_u
@@ -784,20 +902,20 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         }
         TP_TRY(launch(TP_F16, TP_F16, a, stream));
     } else
-    TP_TRY(region_attention_launch(ws + W.q, ws + W.kv, ws + W.kv + kvE * 2, ws + W.o, B, g, s, stream, attn_mask, mask_mode,
+    TP_TRY(region_attention_launch(ws + W.q, kv_slab, kv_slab + kvE * 2, ws + W.o, B, g, s, stream, attn_mask, mask_mode,
                                    region_major ? 1 : 0));
     TP_TRY(mark());
     // 8. out_proj — folded into mlp[0] at pack time where fold_out_proj() says so (TP_TUNE_FOLD_OUT_PROJ)
-    const bool fold = fold_out_proj(desc, train);
+    const bool fold = plan.fold;
     if (!fold) {
-        GemmArgs a = plain_gemm(ws + W.o, E, pw + P.w_out, ws + W.a1, E, rows_q, E, E, (const float*)(pw + P.b_out), 0);
+        GemmArgs a = plain_gemm(ws + W.o, E, pw + P.w_out, slab(W.a1), E, rows_q, E, E, (const float*)(pw + P.b_out), 0);
         TP_TRY(launch(TP_F16, TP_F16, a, stream));
     }
     TP_TRY(mark());
     // 9. mlp[0] + GELU   (on O with W_om = Wm0·Wout when folded)
     {
         GemmArgs a = fold ? plain_gemm(ws + W.o, E, pw + P.w_om, ws + W.a2, D, rows_q, D, E, (const float*)(pw + P.b_om), TP_LINEAR_GELU)
-                          : plain_gemm(ws + W.a1, E, pw + P.w_m0, ws + W.a2, D, rows_q, D, E, (const float*)(pw + P.b_m0), TP_LINEAR_GELU);
+                          : plain_gemm(slab(W.a1), E, pw + P.w_m0, ws + W.a2, D, rows_q, D, E, (const float*)(pw + P.b_m0), TP_LINEAR_GELU);
         if (train) { a.flags |= TP_LINEAR_SAVE_PRE; a.C2 = ws + W.z2; }
         TP_TRY(launch(TP_F16, TP_F16, a, stream));
     }
@@ -850,5 +968,9 @@ int tp_forward_staged(const tp_desc* desc, const void* x, const int64_t x_stride
     return forward_impl(desc, x, x_strides, x_multi, xm_strides, packed_weights, out, workspace, workspace_bytes,
                         stream, stage_events, false);
 }
+
+int tp_release_stream(void* stream) { return release_stream_state((hipStream_t)stream); }
+
+int tp_test_side_cache_size(void) { return side_cache_size(); }
 
 }  // extern "C"

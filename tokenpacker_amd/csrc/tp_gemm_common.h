@@ -111,6 +111,20 @@ __device__ __forceinline__ void block_sync_lds() {
     __builtin_amdgcn_s_barrier();
 }
 
+// Sticky fp16-saturation report (GemmArgs::sat_flag): sat_track folds two values about to be clamped into the lane's running
+// max |v| — one v_max3_f32 with |.| source modifiers per pair; sat_report ORs GemmArgs::sat_bit into the flag when any lane
+// of the wave saw a value the reference's fp16 arithmetic would have turned into inf.
+__device__ __forceinline__ float sat_track(float m, float a, float b) {
+    return __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)));       // -> v_max3_f32 m, |a|, |b|
+}
+__device__ __forceinline__ void sat_report(const GemmArgs& p, float sat_max) {
+    // 65520 = the smallest magnitude IEEE round-to-nearest turns into an fp16 inf (what the reference would have produced)
+    if (p.sat_flag && __builtin_amdgcn_ballot_w64(!(sat_max < 65520.f)) != 0) {
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)
+            __hip_atomic_fetch_or(p.sat_flag, p.sat_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // TRAIN_EPI compiles in the two training-only epilogue features (TP_LINEAR_SAVE_PRE, TP_LINEAR_GELU_BWD); the
 // inference kernels are instantiated without them so that their register budget is not taxed.
 // STATS_ONLY (TP_LINEAR_NO_STORE): the row statistics of the unrounded result are the only output — no conversion, no store.
@@ -164,6 +178,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
     constexpr int FNV = FN / VW;                   // fragments per slice (= 4)
     static_assert(WN % 64 == 0, "wave tile must be a multiple of 64 columns");
     float rs1[FM][VW], rs2[FM][VW];
+    float sat_max = 0.f;                          // largest |value| this lane handed to the fp16 clamp (GemmArgs::sat_flag)
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * WM + i * 16 + (lane & 15);
@@ -232,6 +247,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
                     if constexpr (std::is_same<TO, f16_t>::value) {     // saturate instead of producing inf
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
+                            if constexpr (!TRAIN_EPI) sat_max = sat_track(sat_max, v0[r], v1[r]);
                             // (v_med3_f32 straight: fminf/fmaxf on an MFMA result make hipcc add a canonicalising
                             // v_max_f32 per element — 128 extra VALU instructions per wave and tile)
                             v0[r] = __builtin_amdgcn_fmed3f(v0[r], -65504.f, 65504.f);
@@ -274,6 +290,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
         }
     }
 
+    // (not in the training epilogues: their register budget is exhausted — one more live value spills; a training forward
+    // is scanned with tp_debug_count_saturated instead)
+    if constexpr (std::is_same<TO, f16_t>::value && !STATS_ONLY && !TRAIN_EPI) sat_report(p, sat_max);
     if (flags & TP_LINEAR_ROW_STATS) {
         // reduce over the 4 lane groups that share a row, then over the 64-column slices through LDS
         float* red = (float*)smem;                 // [BN/64][BM][2]
@@ -422,6 +441,7 @@ __device__ __forceinline__ void attn_sum_epilogue(f32x4 (&acc)[WM / 16][WN / 16]
     const int cg = lane >> 4, r16 = lane & 15, kq = lane & 3;
     const int col_base = n0 + wn * WN + cg * 4;
     const int hl = (wn * WN) / 128;                        // head inside the tile
+    float sat_max = 0.f;
     // O has M / 4 rows: the hardware range check drops the stores of rows past the end (uniform store count per tile)
     const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.C + g * p.c_gs), 0, (int)(unsigned)((long long)(p.M >> 2) * p.ldc * 2), 0x00020000);
@@ -476,6 +496,7 @@ __device__ __forceinline__ void attn_sum_epilogue(f32x4 (&acc)[WM / 16][WN / 16]
             }
             if (kq == j) mine = w;
         }
+        sat_max = sat_track(sat_track(sat_max, mine[0], mine[1]), mine[2], mine[3]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) mine[r] = __builtin_amdgcn_fmed3f(mine[r], -65504.f, 65504.f);
         const f16x4 o = __builtin_convertvector(mine, f16x4);
@@ -483,6 +504,7 @@ __device__ __forceinline__ void attn_sum_epilogue(f32x4 (&acc)[WM / 16][WN / 16]
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsrc_o, (int)(unsigned)off, 0, 0);
         __builtin_amdgcn_sched_barrier(0);                 // one fragment row at a time (register budget of the persistent kernels)
     }
+    sat_report(p, sat_max);
 }
 
 }  // namespace tp

@@ -97,6 +97,10 @@ struct GemmArgs {
     int flags;                        // TP_LINEAR_*
     int groups;
     int tile;                         // 0 auto, 128, 256
+    // Sticky fp16-saturation report: every fp16 epilogue clamps to +-65504 instead of producing inf; when sat_flag is given
+    // (a device int32 the caller zeroed at some point), a wave that clamped anything ORs sat_bit into it.  One v_max3 per
+    // two output elements and, for a tile that did saturate, one atomic — nothing otherwise.
+    int* sat_flag; int sat_bit;
 };
 int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream);
 bool gemm_uses_small_kernel(const GemmArgs& a);        // whether gemm_launch would run `a` on the 128-tile kernel (tp_gemm.hip)
@@ -193,15 +197,35 @@ struct PackedLayout {
 };
 PackedLayout packed_layout(int D);
 
+// The schedule tp_forward runs for a descriptor under the tuning table OF THE MOMENT (tp_api.hip plan_schedule): one place
+// decides; forward_impl, the workspace layout and the debug scan read it.  `masked`: the forward carries an attn_mask.
+struct SchedulePlan {
+    bool train;
+    bool absorb, absorb_raw;       // K/V in-projections absorbed into the query side (scale_factor >= 3); on the fused LayerNorm chain
+    bool fuse_ln;                  // plain schedule on the fused LayerNorm chain: H2 for its row statistics only
+    bool fuse_q;                   // query side on the fused chain: Q1pre for its row statistics only
+    bool region_major, fuse_attn;  // scale_factor 2: region-major K/V rows; attention inside the in-projections' epilogues
+    bool fold;                     // out_proj folded into mlp[0]
+    bool split_k;                  // TP_TUNE_SPLIT_K applies to this batch
+    bool need_h2, need_kv, need_q1pre, need_a1;   // workspace slabs the schedule writes
+};
+SchedulePlan plan_schedule(const tp_desc* desc, bool train, bool masked);
+
+constexpr size_t kNoSlab = ~(size_t)0;             // offset of a slab the schedule does not have (never dereferenced)
 struct WorkspaceLayout {
+    size_t status;                // 256 B at offset 0: int32[0] = sticky fp16-saturation bits (bit k: stage k - 1 of tp_forward_staged, bit 0: query side)
     size_t q0, hkv, h2, stats_kv, mr_kv, kv, q1pre, stats_q, mr_q, q, o, a1, a2;
+    size_t attn_aux;              // logits [8][B*N] fp32 (attention in the in-projection epilogues) | (e/a, a) [8][B*M][2] (absorbed, RAW)
     size_t counters;              // zeroed once per forward: tile-queue heads of the persistent GEMM launches
     size_t splitk;                // small batches: fp32 partial results of a K-split GEMM (TP_TUNE_SPLIT_K), kSplitKBytes
     size_t z1, z2;                // training forward only: fp16 pre-GELU activations [B*N, 2048], [B*M, D]
     size_t total;
     int stats_parts_kv, stats_parts_q;
 };
-WorkspaceLayout workspace_layout(int B, int grid, int s, int D, bool train = false);
+// Schedule-aware: a slab the plan does not write takes no space (kNoSlab).  At B = 256, scale_factor 2, D = 4096 the default
+// inference schedule needs 1.24 GB (no H2, no K | V, no Q1pre); the training layout keeps every slab the backward reads.
+WorkspaceLayout workspace_layout(int B, int grid, int s, int D, const SchedulePlan& plan);
+WorkspaceLayout workspace_layout(int B, int grid, int s, int D, bool train = false);    // the plan of (desc-less) defaults: training = every slab
 // K-split of a latency-bound GEMM (TP_TUNE_SPLIT_K): S * tiles <= 512 workgroups of 128 x 128 (two per CU) -> at most
 // 512 * 128 * 128 fp32 partial values
 constexpr size_t kSplitKBytes = (size_t)512 * 128 * 128 * 4;
@@ -242,6 +266,8 @@ int bw_ln_backward_launch(int gdtype, const void* dy, const void* x_f16, const f
 int bw_region_attention_launch(int gdtype, const void* q, const void* k, const void* v, const void* dout, void* dq,
                                void* dk, void* dv, int B, int grid, int s, hipStream_t stream);
 int validate_desc(const tp_desc* d);
+void pack_registry_put(const void* packed, const tp_desc* d, bool train_pack);      // tp_api.hip: what an image was packed for
+int pack_registry_check(const void* packed, const tp_desc* d, bool train);
 GemmArgs plain_gemm(const void* A, long long lda_elems, const void* W, void* C, long long ldc, int M, int N, int K,
                     const float* bias, int flags);
 long long max_images_per_launch(const tp_desc* desc);

@@ -107,10 +107,12 @@ class TokenPacker(nn.Module):
         self._overflow_checked = False
         self._workspaces: Dict[tuple, torch.Tensor] = {}
         self._last_launch = None             # (desc, workspace) of the last inference forward: saturation_report()
+        self._sat_warned, self._sat_pending, self._sat_count = False, None, 0
 
     # ------------------------------------------------------------------------------------------
     _CACHE_DEFAULTS = {"_packed": None, "_packed_key": None, "_packed_event": None, "_packed_stream": None,
-                       "_overflow_checked": False, "_last_launch": None}
+                       "_overflow_checked": False, "_last_launch": None, "_sat_warned": False, "_sat_pending": None,
+                       "_sat_count": 0}
 
     def __getstate__(self):
         """``copy.deepcopy`` / ``pickle`` / ``torch.save(module)`` carry the parameters and settings, never the kernel-side
@@ -160,12 +162,11 @@ class TokenPacker(nn.Module):
 
     def _ensure_packed(self, dtype: torch.dtype, device: torch.device, stream_ptr: int, force: bool = False) -> torch.Tensor:
         """(Re)build the kernel-side weight image: always when ``force`` (training forward), otherwise when any
-        parameter storage / version, the compute dtype or the pack-time tuning changed."""
+        parameter storage / version or the compute dtype changed."""
         weights = self._named_weights()
-        # pack-time tuning: the folded / pre-multiplied weights exist only if their knob was on when packing
-        fold = (_capi.get_tuning(_capi.TP_TUNE_FOLD_OUT_PROJ), _capi.get_tuning(_capi.TP_TUNE_FUSE_KV_LN),
-                _capi.get_tuning(_capi.TP_TUNE_ABSORB_KV), _capi.get_tuning(_capi.TP_TUNE_FUSE_ATTN))
-        key = (dtype, device, fold, tuple((w.data_ptr(), w._version) for w in weights))
+        # (an inference image carries every folded / pre-multiplied weight whatever the tuning table says: the schedule is
+        # chosen per forward, the image never has to follow a knob)
+        key = (dtype, device, tuple((w.data_ptr(), w._version) for w in weights))
         stream = torch.cuda.current_stream(device)
         if not force and self._packed is not None and self._packed_key == key:
             if self._packed_stream != stream_ptr and self._packed_event is not None:
@@ -209,13 +210,29 @@ class TokenPacker(nn.Module):
             self._packed, self._packed_key = packed, key
         return packed
 
+    _MAX_WORKSPACES = 8          # (device, stream) pairs that keep a workspace; least recently used first out
+
     def _workspace(self, nbytes: int, device: torch.device, stream_ptr) -> torch.Tensor:
         key = (device.index if device.index is not None else -1, stream_ptr)
-        ws = self._workspaces.get(key)
+        ws = self._workspaces.pop(key, None)
         if ws is None or ws.numel() < nbytes:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            self._workspaces[key] = ws
+            ws[:_capi.TP_WORKSPACE_STATUS_BYTES].zero_()      # the status block (sticky saturation bits) starts clear
+        self._workspaces[key] = ws                           # (re-inserted: dict order = recency)
+        while len(self._workspaces) > self._MAX_WORKSPACES:
+            self._workspaces.pop(next(iter(self._workspaces)))
         return ws
+
+    def release_stream(self, stream: Optional["torch.cuda.Stream"] = None) -> None:
+        """Drop everything kept for ``stream`` (default: the current one): this module's workspace for it and the
+        library's side stream (``tp_release_stream``).  Call before destroying a stream the module has run on — the
+        runtime may hand the same handle to a new stream."""
+        stream = stream if stream is not None else torch.cuda.current_stream()
+        ptr = stream.cuda_stream
+        for key in [k for k in self._workspaces if k[1] == ptr or k[1] == ("bwd", ptr)]:
+            self._workspaces.pop(key)
+        with torch.cuda.device(stream.device):
+            _capi.check(_capi.load_library().tp_release_stream(ptr), "tp_release_stream")
 
     # ------------------------------------------------------------------------------------------
     def out_like(self, x: torch.Tensor):
@@ -352,6 +369,8 @@ class TokenPacker(nn.Module):
                                                      packed.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
                                                      stream_ptr), "tp_forward_train")
                 return out, ws, desc, packed
+            if mask is not None:                 # a masked forward runs the plain schedule (K | V written): larger workspace
+                desc.flags |= _capi.TP_DESC_MASKED
             ws_bytes = lib.tp_workspace_bytes(ctypes.byref(desc))
             if ws_bytes == 0:
                 raise RuntimeError(f"tp_workspace_bytes: {_capi.last_error()}")
@@ -379,7 +398,47 @@ class TokenPacker(nn.Module):
                                                   packed.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
                                                   stream_ptr, handles, len(_stage_events)), "tp_forward_staged")
             self._last_launch = (desc, ws, stream_ptr)
+            self._poll_saturation(ws, torch.cuda.current_stream(device))
         return out, ws, desc, packed
+
+    def saturated_stages(self, clear: bool = False):
+        """Names of the stages whose fp16 epilogues have CLAMPED a value (where the reference's half-precision arithmetic
+        would have produced inf) in any inference forward on the current stream's workspace since the flag was last
+        cleared — the sticky status word the kernels maintain (include/tokenpacker.h, TP_WORKSPACE_STATUS_BYTES).  Empty
+        tuple = every forward so far stayed inside the fp16 range.  Synchronises (one 4-byte read-back)."""
+        if self._last_launch is None:
+            return ()
+        _, ws, _ = self._last_launch
+        bits = int(ws[:4].view(torch.int32).item())
+        if clear and bits:
+            ws[:4].zero_()
+        names = ("query_side",) + tuple(_capi.STAGE_NAMES)
+        return tuple(n for i, n in enumerate(names) if bits >> i & 1)
+
+    def _poll_saturation(self, ws: torch.Tensor, stream) -> None:
+        """Warn ONCE when a forward clamps: after forwards 1, 2, 4, 8, ... (then every 1024th) the status word is copied
+        to pinned host memory behind the forward (asynchronously); whichever later forward finds the copy finished
+        reads it.  No synchronisation is ever added to the forward."""
+        if self._sat_warned:
+            return
+        pend = self._sat_pending
+        if pend is not None and pend[1].query():
+            if int(pend[0].item()) != 0:
+                self._sat_warned = True
+                import warnings
+                warnings.warn("tokenpacker_amd.TokenPacker: an fp16 epilogue saturated (|value| >= 65520 clamped to 65504 "
+                              "where the reference would have produced inf); module.saturated_stages() names the stage",
+                              RuntimeWarning, stacklevel=3)
+                return
+            self._sat_pending = pend = None
+        self._sat_count += 1
+        n = self._sat_count
+        if pend is None and ((n & (n - 1)) == 0 or n % 1024 == 0):
+            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host.copy_(ws[:4].view(torch.int32), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            self._sat_pending = (host, ev)
 
     def saturation_report(self) -> Dict[str, int]:
         """Debug aid: after an inference forward, how many elements of each fp16 intermediate (``q0, Hkv, H2, KV, Q1pre,
