@@ -98,7 +98,33 @@ def parse_args():
                     help="collective backend for N>1 (nccl = RCCL; gloo only to exercise the N>1 flow on one GPU)")
     ap.add_argument("--single-device", action="store_true",
                     help="test aid: every rank uses cuda:0 (with --backend gloo)")
+    ap.add_argument("--gather", default="rccl", choices=["rccl", "sdma"],
+                    help="N>1: how the projected tokens travel — rccl: all_gather_into_tensor (RCCL kernels over xGMI) | "
+                         "sdma: shard.DirectGather, one hipMemcpyAsync per peer on the copy engines, no compute unit")
+    ap.add_argument("--gather-depth", type=int, default=3, help="--gather sdma: rotating receive buffers")
+    ap.add_argument("--probe-other-gather", action="store_true",
+                    help="N>1: after the timed region also time the transport NOT selected by --gather (multi_gpu.other_gather)")
+    ap.add_argument("--min-seconds", type=float, default=0.6,
+                    help="after the K timed steps, keep stepping until this much time has been measured and report the "
+                         "distribution over blocks of steps (timing.long_run); 0: off")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N=1: skip the eager PyTorch-ROCm baseline and the s=3 / s=4 / B=32 sweep that follow the timed region")
     return ap.parse_args()
+
+
+def self_spawn(args) -> None:
+    """``python bench.py --gpus N`` with no launcher around it: start the N ranks ourselves (torch.distributed.run on
+    127.0.0.1, one process per GPU) and hand their output through — rank 0 prints the one JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: RCCL and tp_gather_* both need it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
 def make_device_inputs(B, dtype, layout, device, seed):
@@ -141,6 +167,51 @@ def cpu_baseline(seconds: float, s: int, D: int, threads: int):
             "sample": f"{n} forwards of B={B}, s={s}, D={D}, fp32, the reference's torch op sequence incl. "
                       f"nn.MultiheadAttention on {cores} host threads of {os.cpu_count()} logical cores, {el:.1f} s "
                       f"(BASELINE config 1 shape)"}
+
+
+def _time_forward(fn, device, warm: int, iters: int) -> float:
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize(device)
+    return 1e3 * (time.perf_counter() - t0) / iters
+
+
+def gpu_extras(args, model, x, xm, dtype, device, images_per_s):
+    """Rank 0 at N=1, AFTER the timed region, driver-verifiable companions of the headline:
+      eager_rocm_baseline — the reference's own op sequence (oracle/reference_ops.eager_forward: nn.Linear / nn.GELU /
+          nn.LayerNorm / F.interpolate / nn.MultiheadAttention, builder.py:107-137) run by PyTorch-ROCm eager on THIS GPU on
+          the same inputs, dtype and batch — the denominator of the north_star's ">= 5x".  A baseline leg like cpu_baseline:
+          it is timed, never shipped.  (``vs_baseline`` stays null: BASELINE.md publishes no number for this metric.)
+      sweep — the other BASELINE configs on one GPU: scale_factor 3 and 4 at the same batch, and the 8-GPU shard (B/8)."""
+    from oracle.reference_ops import eager_forward        # noqa: baseline leg only
+    out = {}
+    B = x.shape[0]
+    with torch.no_grad():
+        try:
+            ms = _time_forward(lambda: eager_forward(model, x, xm), device, 10, 30)
+            out["eager_rocm_baseline"] = {"ms_per_step": round(ms, 3), "value": round(B / ms * 1e3, 1), "unit": "images/s",
+                                          "hip_over_eager": round(images_per_s / (B / ms * 1e3), 3),
+                                          "what": f"the reference's torch op sequence (builder.py:107-137 incl. nn.MultiheadAttention) under "
+                                                  f"PyTorch-ROCm {torch.__version__} eager, {args.dtype}, B={B}, same inputs and weights, "
+                                                  f"10 warm-up + 30 timed forwards"}
+        except Exception as exc:         # noqa: an OOM of the eager path must not cost the line
+            out["eager_rocm_baseline"] = {"error": repr(exc)[:200]}
+        sweep = {}
+        for s2 in (3, 4):
+            m2 = build_model(args.hidden_size, s2, dtype, device)
+            ms = _time_forward(lambda: m2((x, xm)), device, 5, 30)
+            sweep[f"s{s2}_B{B}"] = {"ms_per_step": round(ms, 4), "images_per_s": round(B / ms * 1e3, 1)}
+            del m2
+        for b2 in sorted({max(B // 8, 1), 1}, reverse=True):
+            if b2 < B:
+                ms = _time_forward(lambda: model((x[:b2], xm[:b2])), device, 10, 100)
+                sweep[f"s{args.scale_factor}_B{b2}"] = {"ms_per_step": round(ms, 4), "images_per_s": round(b2 / ms * 1e3, 1)}
+        out["sweep"] = sweep
+    return out
 
 
 def kernel_source_digest() -> str:
@@ -291,8 +362,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs a torch.distributed.run launch (WORLD_SIZE={world})")
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            self_spawn(args)                                     # never returns
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an AMD GPU (no CPU fallback for the product path)")
@@ -345,7 +416,9 @@ def main():
     x, xm = make_device_inputs(max(B, 1), dtype, args.layout, device, seed=1234 + rank)
     x, xm = x[:B], xm[:B]
     gather = world > 1 and not args.no_gather
-    pipe = shard.TokenGatherPipeline(total, depth=2) if (gather and not args.sync_gather and not ragged and not args.hd) else None
+    use_sdma = gather and args.gather == "sdma" and not args.hd
+    pipe = shard.TokenGatherPipeline(total, depth=2) if (gather and not use_sdma and not args.sync_gather and not ragged and not args.hd) else None
+    dgather = shard.DirectGather(total, (M, D), dtype, device, depth=args.gather_depth) if use_sdma else None
     if args.hd:
         gsep = torch.Generator(device=device).manual_seed(5)
         sep = torch.randn(D, generator=gsep, device=device, dtype=torch.float32).to(dtype)
@@ -361,6 +434,12 @@ def main():
                 return hd.assemble_hd_tokens(g_tok, hb, wb, sep, ret)
             y_loc = model((x, xm))
             return hd.assemble_hd_tokens(y_loc, hb, wb, sep, ret) if world == 1 else y_loc
+        if dgather is not None:              # the shard is written straight into its rows of the receive buffer, then pushed
+            view = dgather.begin()
+            if B:
+                model((x, xm), _out=view)
+            ticket = dgather.submit()
+            return dgather.result(ticket) if args.sync_gather else dgather.bufs[ticket[1]]
         if pipe is not None:                 # forward of this step overlaps the gather of the previous one
             slot = pipe.submit(model((x, xm)))
             return pipe._bufs[slot]
@@ -371,6 +450,8 @@ def main():
     def fence():
         if pipe is not None:
             pipe.drain()                     # every gather issued so far is complete inside the timed region
+        if dgather is not None:
+            dgather.drain()
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
@@ -385,6 +466,34 @@ def main():
             y = step()
         fence()
         elapsed = time.perf_counter() - t0
+
+        # The K steps above are the driver's; at 4 ms per step they are < 0.1 s of clock.  Keep stepping (same loop, same
+        # fences) until --min-seconds have been measured, in blocks, so that the line also carries a distribution.
+        long_run = None
+        if args.min_seconds > 0 and args.steps > 0 and not args.hd:
+            per = max(elapsed / args.steps, 1e-6)
+            blk = max(1, min(args.steps, int(0.05 / per) + 1))
+            n_blk = int(min(200, max(5, args.min_seconds / (per * blk))))
+            if world > 1:                    # every rank must run the same number of steps
+                nb = torch.tensor([blk, n_blk], dtype=torch.int64, device=device)
+                dist.broadcast(nb, src=0)
+                blk, n_blk = int(nb[0].item()), int(nb[1].item())
+            blocks = []
+            for _ in range(n_blk):
+                tb = time.perf_counter()
+                for _ in range(blk):
+                    y = step()
+                fence()
+                blocks.append((time.perf_counter() - tb) / blk * 1e3)
+            tb_all = torch.tensor(blocks, dtype=torch.float64, device=device)
+            if world > 1:
+                dist.all_reduce(tb_all, op=dist.ReduceOp.MAX)
+            bl = sorted(tb_all.tolist())
+            long_run = {"blocks": n_blk, "steps_per_block": blk, "seconds": round(sum(bl) * blk * 1e-3, 3),
+                        "ms_per_step_mean": round(sum(bl) / len(bl), 4), "ms_per_step_p10": round(bl[len(bl) // 10], 4),
+                        "ms_per_step_median": round(bl[len(bl) // 2], 4), "ms_per_step_p90": round(bl[(len(bl) * 9) // 10], 4),
+                        "note": "each block is fenced (synchronize [+ barrier]) like the timed region, so short blocks carry "
+                                "the fence's own cost; the K-step region above stays the metric"}
 
         # per-kernel timing inside the real forward: HIP events recorded by the library on the
         # launch stream (tp_forward_staged).  A few extra forwards after the timed region.
@@ -408,7 +517,7 @@ def main():
                 y_loc = model((x, xm))
             fence()
             extra["forward_only_ms"] = 1e3 * (time.perf_counter() - t1) / n_x
-            if not ragged:
+            def probe_rccl():
                 gp = pipe if pipe is not None else shard.TokenGatherPipeline(total, depth=2)
                 gp.submit(y_loc)
                 fence()
@@ -417,14 +526,48 @@ def main():
                     gp.submit(y_loc)
                 gp.drain()
                 fence()
-                extra["gather_only_ms"] = 1e3 * (time.perf_counter() - t1) / n_x
-            else:
+                return 1e3 * (time.perf_counter() - t1) / n_x
+
+            def probe_sdma(g):
+                for _ in range(g.depth):                 # the shard sits in every buffer's own rows: submit() moves nothing locally
+                    g.submit(y_loc)
+                g.drain()
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(n_x):
+                    g.submit()
+                g.drain()
+                fence()
+                return 1e3 * (time.perf_counter() - t1) / n_x
+
+            if args.hd or ragged and dgather is None:
                 fence()
                 t1 = time.perf_counter()
                 for _ in range(n_x):
                     shard.all_gather_tokens(y_loc, total, dense=False)
                 fence()
                 extra["gather_only_ms"] = 1e3 * (time.perf_counter() - t1) / n_x
+            elif dgather is not None:
+                extra["gather_only_ms"] = probe_sdma(dgather)
+            else:
+                extra["gather_only_ms"] = probe_rccl()
+            if args.probe_other_gather and not args.hd and not ragged:
+                # the OTHER transport on the same shard, outside the timed region (opt-in: it opens IPC mappings / a second
+                # set of buffers, and an asymmetric failure there must not cost the line its main numbers)
+                if dgather is not None:
+                    extra["other_gather"] = {"mode": "rccl", "gather_only_ms": probe_rccl()}
+                else:
+                    g2 = shard.DirectGather(total, (M, D), dtype, device, depth=args.gather_depth, timeout_ms=5000)
+                    extra["other_gather"] = {"mode": "sdma", "gather_only_ms": probe_sdma(g2)}
+                    for _ in range(2):                   # pipelined steps on it: forward into the buffer, push, next forward
+                        model((x, xm), _out=g2.begin()); g2.submit()
+                    g2.drain(); fence()
+                    t1 = time.perf_counter()
+                    for _ in range(n_x):
+                        model((x, xm), _out=g2.begin()); g2.submit()
+                    g2.drain(); fence()
+                    extra["other_gather"]["pipelined_ms_per_step"] = 1e3 * (time.perf_counter() - t1) / n_x
+                    g2.close()
 
     if args.hd:
         rows_img = hd.hd_token_rows(2, 4, M)
@@ -433,10 +576,18 @@ def main():
     else:
         assert y.shape == ((total if gather else B), M, D) and torch.isfinite(y[:2].float()).all(), y.shape
 
-    t = torch.tensor([elapsed, extra.get("forward_only_ms", 0.0), extra.get("gather_only_ms", 0.0)],
-                     dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed, extra.get("forward_only_ms", 0.0), extra.get("gather_only_ms", 0.0),
+                      extra.get("other_gather", {}).get("gather_only_ms", 0.0),
+                      extra.get("other_gather", {}).get("pipelined_ms_per_step", 0.0)], dtype=torch.float64, device=device)
+    rank_info = None
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # what the collective library itself saw: ranks, and the device each one drives
+        props = torch.cuda.get_device_properties(device)
+        mine = {"rank": dist.get_rank(), "local_rank": local_rank, "device_index": device.index, "name": props.name,
+                "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None), "pid": os.getpid()}
+        rank_info = [None] * world
+        dist.all_gather_object(rank_info, mine)
     elapsed = float(t[0].item())
     ms_per_step = 1e3 * elapsed / args.steps
     images_per_s = total * args.steps / elapsed
@@ -468,7 +619,7 @@ def main():
                        "global_batch": total, "per_gpu_batch": B, "scale_factor": s, "hidden_size": D,
                        "input_layout": args.layout,
                        "parallelism": f"batch-shard x{world}" + ((" + all_gather(tokens)" + (
-                           ", gather of step i overlapped with forward of step i+1" if pipe is not None else "")) if gather else ""),
+                           ", gather of step i overlapped with forward of step i+1" if (pipe is not None or (dgather is not None and not args.sync_gather)) else "")) if gather else ""),
                        "weights": "random init (reference distribution), synthetic unit-normal CLIP features",
                        "tuning": {k: _capi.get_tuning(getattr(_capi, k)) for k in dir(_capi) if k.startswith("TP_TUNE_")}},
             "whole_path": {"achieved_tflops": round(fl_img * total / (ms_per_step * 1e-3) / 1e12, 1),
@@ -490,11 +641,30 @@ def main():
             out["multi_gpu"] = {"forward_only_ms": round(float(t[1].item()), 4),
                                 "forward_only_images_per_s": round(total / (float(t[1].item()) * 1e-3), 1),
                                 "gather_only_ms": round(float(t[2].item()), 4),
-                                "collective": f"{args.backend} all_gather_into_tensor over {world} ranks" + (" (ragged: b_max-row slots)" if ragged else ""),
-                                "gather_bytes_received_per_rank": int((total - B) * M * D * 2)}
+                                "collective": (f"DirectGather: {world - 1} hipMemcpyAsync (copy engines, no CU) per rank and step + sequence flags, "
+                                               f"depth {args.gather_depth}" if dgather is not None else
+                                               f"{args.backend} all_gather_into_tensor over {world} ranks") + (" (ragged: b_max-row slots)" if ragged and dgather is None else ""),
+                                "gather": "sdma" if dgather is not None else "rccl",
+                                "pipelined": bool(pipe is not None or (dgather is not None and not args.sync_gather)),
+                                "gather_bytes_received_per_rank": int((total - B) * M * D * 2),
+                                "ranks": dist.get_world_size(), "backend": dist.get_backend(), "rank_devices": rank_info,
+                                "env": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS",
+                                                                        "RCCL_MSCCL_ENABLE", "HSA_ENABLE_IPC_MODE_LEGACY", "HSA_ENABLE_SDMA")
+                                        if os.environ.get(k) is not None}}
+            if "other_gather" in extra:
+                out["multi_gpu"]["other_gather"] = {"mode": extra["other_gather"]["mode"], "gather_only_ms": round(float(t[3].item()), 4)}
+                if float(t[4].item()) > 0:
+                    out["multi_gpu"]["other_gather"]["pipelined_ms_per_step"] = round(float(t[4].item()), 4)
+        if long_run is not None:
+            out["timing"] = {"timed_region_s": round(elapsed, 4), "long_run": long_run}
+        if world == 1 and not args.no_extras and not args.hd:
+            out.update(gpu_extras(args, model, x, xm, dtype, device, images_per_s))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, s, D, args.cpu_threads)
         print(json.dumps(out), flush=True)
+
+    if dgather is not None:
+        dgather.close()
 
     if world > 1:
         dist.destroy_process_group()

@@ -114,9 +114,19 @@ def assemble_hd_tokens(image_features: torch.Tensor, h_block: Sequence[int], w_b
 
     ``crop_map`` (int32 device tensor, one entry per crop): crop c is row block ``crop_map[c]`` of ``image_features``
     — the b_max-strided buffer of a ragged all-gather (``shard.GatheredTokens.buf`` / ``.crop_map()``) is read in
-    place instead of being compacted first."""
+    place instead of being compacted first.
+
+    INFERENCE ONLY: the blocks are written by a raw-pointer HIP kernel autograd never sees — with a gradient live on
+    ``image_features`` (or on the separator embeddings) the call raises instead of silently cutting the graph between
+    the projector and the LLM (the reference's slice branch also runs in training; use its torch.cat form there)."""
     if not image_features.is_cuda:
         raise RuntimeError("assemble_hd_tokens runs only on an AMD GPU (HIP kernel); there is no CPU fallback")
+    if torch.is_grad_enabled() and (image_features.requires_grad or sep_embed.requires_grad or ret_embed.requires_grad
+                                    or (out is not None and out.requires_grad)):
+        raise NotImplementedError(
+            "assemble_hd_tokens / build_inputs_embeds write the visual tokens with a HIP kernel outside autograd: with a "
+            "gradient live on the projector output (or the separator embeddings / the destination buffer) the graph would "
+            "be cut silently.  Call it under torch.no_grad() (inference), or assemble with torch ops when training.")
     if image_features.dim() != 3:
         raise ValueError("image_features must be [n_crops, M, D]")
     if len(h_block) != len(w_block):
@@ -226,7 +236,8 @@ def build_inputs_embeds(input_ids: torch.Tensor, embed_tokens, image_features: t
     b_max-strided buffer of a ragged all-gather, read through ``crop_map`` (``shard.GatheredTokens``).
     Every image token of sample b uses the grid ``h_block[b] x w_block[b]``; a sample without an image token still
     consumes one crop index, as in the reference (:124-134).  Labels / attention masks stay host-side list logic
-    (out of scope)."""
+    (out of scope).  INFERENCE ONLY (see ``assemble_hd_tokens``): raises when a gradient is live on
+    ``image_features`` or on the embedding table."""
     if not image_features.is_cuda:
         raise RuntimeError("build_inputs_embeds runs only on an AMD GPU (HIP kernel); there is no CPU fallback")
     ids_cpu = input_ids.detach().cpu()

@@ -238,7 +238,14 @@ class TokenPacker(nn.Module):
     def out_like(self, x: torch.Tensor):
         """``(tensor carrying the result's dtype / device, (M, D))`` for inputs like ``x`` — lets a caller allocate the
         buffer it passes as ``_out``."""
-        dt = torch.float32 if self.output_fp32 else x.dtype
+        dt = x.dtype                                         # forward()'s own resolution of the compute / output dtype
+        if torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in _DTYPES \
+                and x.dtype in (torch.float32, torch.bfloat16, torch.float16):
+            dt = torch.get_autocast_dtype("cuda")
+        elif x.dtype == torch.float32 and self.fp32_compute_dtype is not None:
+            dt = torch.float32
+        if self.output_fp32:
+            dt = torch.float32
         return torch.empty(0, dtype=dt, device=x.device), (self.num_queries, self.hidden_size)
 
     def forward(self, x, attn_mask=None, _stage_events=None, _out=None):

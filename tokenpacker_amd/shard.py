@@ -177,6 +177,170 @@ class TokenGatherPipeline:
             self.result(slot)
 
 
+class DirectGather:
+    """The all-gather of projected tokens WITHOUT a collective kernel: every rank's shard travels to every peer as one
+    ``hipMemcpyAsync`` per peer (SDMA engines over that peer's xGMI link — no compute unit), into rows ``[lo, hi)`` of
+    the peer's receive buffer, which the peer exported once through HIP IPC (``tp_gather_*`` in include/tokenpacker.h).
+
+    Why: RCCL's all-gather runs as kernels, and the next forward's persistent GEMMs own every CU (one 512-thread
+    workgroup with the whole register file per CU) — a collective that overlaps the next forward either waits for CUs or
+    takes them from the GEMMs (16 busy CUs: +19 % per forward, profiles/r02y_hog_bench_B256.json).  Copy engines need none.
+
+    Protocol (one instance per rank, same arguments everywhere; ``depth`` rotating receive buffers ``[total, M, D]``)::
+
+        view = g.begin()                      # rows [lo, hi) of this step's buffer: where the projector writes
+        model((x, x_multi), _out=view)        # (or g.submit(local) copies a shard that lives elsewhere)
+        t = g.submit()                        # sync kernel (1 wave) + one copy and one 4-byte flag per peer, all enqueued
+        ...                                   # next forward(s): the copies ride the SDMA engines meanwhile
+        tokens = g.result(t)                  # [total, M, D]; the current stream waits for every peer's flag of that step
+
+    Sequence numbers instead of acknowledgements: peer p's flag of step i lands here behind p's shard of step i.  ``submit``
+    of step i first waits (on the current stream) until every peer's flag of step i-1 is here — which also proves that each
+    peer has passed ITS submit of step i-1, i.e. has finished with the buffer step ``i - 1 + 1 - depth`` lived in.  Hence
+    the CONTRACT: the reads of a step's tokens are enqueued (on the stream ``submit`` is called on) before
+    ``submit`` number ``depth - 1`` after it — with the default depth 3, "before the second-next submit".
+    Ragged shards are fine (every rank writes its own row range).  ``use_cus=True`` lets the runtime pick blit kernels
+    instead of SDMA (A/B)."""
+
+    def __init__(self, total: int, tail: Sequence[int], dtype: torch.dtype, device: torch.device,
+                 group: Optional[dist.ProcessGroup] = None, depth: int = 3, use_cus: bool = False, timeout_ms: int = 30000):
+        import ctypes
+        from . import _capi
+        if depth < 2:
+            raise ValueError("DirectGather needs depth >= 2 (a buffer is being filled while the previous one is read)")
+        self._capi, self._ct = _capi, ctypes
+        self.lib = _capi.load_library()
+        self.group, self.depth, self.use_cus, self.timeout_ms = group, depth, int(bool(use_cus)), int(timeout_ms)
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        if self.world > 64:
+            raise ValueError("DirectGather: at most 64 ranks (one wave polls the flags)")
+        self.device = torch.device(device)
+        self.sizes = shard_sizes(total, self.world)
+        self.lo, self.hi = shard_bounds(total, self.world, self.rank)
+        self.total, self.tail = total, tuple(tail)
+        with torch.cuda.device(self.device):
+            self.bufs = [torch.empty((total,) + self.tail, dtype=dtype, device=self.device) for _ in range(depth)]
+            self.flags = torch.zeros(64, dtype=torch.int32, device=self.device)
+            self.cells = torch.zeros(8, dtype=torch.int32, device=self.device)
+            self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+            torch.cuda.synchronize(self.device)               # the zeros are in place before any peer can write a flag
+            row_bytes = self.bufs[0][0].numel() * self.bufs[0].element_size() if total else 0
+            self._nbytes = (self.hi - self.lo) * row_bytes
+            mine = {"bufs": [self._export(b) for b in self.bufs], "flags": self._export(self.flags)}
+            everyone = [None] * self.world
+            dist.all_gather_object(everyone, mine, group=group)
+            self.peers = [p for p in range(self.world) if p != self.rank]
+            self._opened = []                                 # mapped allocation bases (tp_gather_close at close())
+            self._dst = [[0] * len(self.peers) for _ in range(depth)]     # [buffer][peer] -> address of MY rows in the peer's buffer
+            self._dst_flag = [0] * len(self.peers)                        # address of flags[self.rank] in the peer's flag array
+            for j, p in enumerate(self.peers):
+                bases = {}
+                def mapped(rec, bases=bases):
+                    handle, off = rec
+                    if handle not in bases:
+                        base = ctypes.c_void_p()
+                        hb = (ctypes.c_char * _capi.TP_IPC_HANDLE_BYTES).from_buffer_copy(handle)
+                        _capi.check(self.lib.tp_gather_open(hb, ctypes.byref(base)), "tp_gather_open")
+                        bases[handle] = base.value
+                        self._opened.append(base.value)
+                    return bases[handle] + off
+                for k in range(depth):
+                    self._dst[k][j] = mapped(everyone[p]["bufs"][k]) + self.lo * row_bytes
+                self._dst_flag[j] = mapped(everyone[p]["flags"]) + 4 * self.rank
+            self.streams = [torch.cuda.Stream(device=self.device) for _ in self.peers]
+        self._push_done = [[None] * len(self.peers) for _ in range(depth)]
+        self._step = 0
+        self._waited = 0                                      # highest sequence number a sync on the current stream has covered
+        self._closed = False
+        dist.barrier(group=group)                             # every rank has mapped every peer before anyone pushes
+
+    def _export(self, t: torch.Tensor):
+        ct, _capi = self._ct, self._capi
+        handle = (ct.c_char * _capi.TP_IPC_HANDLE_BYTES)()
+        off = ct.c_uint64(0)
+        _capi.check(self.lib.tp_gather_export(t.data_ptr(), handle, ct.byref(off)), "tp_gather_export")
+        return bytes(handle), int(off.value)
+
+    def _sync(self, wait_seq: int, cell: Optional[int], publish: int) -> None:
+        cur = torch.cuda.current_stream(self.device)
+        self._capi.check(self.lib.tp_gather_sync(self.flags.data_ptr(), self.world, self.rank, wait_seq & 0xFFFFFFFF,
+                                                 cell, publish & 0xFFFFFFFF, self.status.data_ptr(), self.timeout_ms,
+                                                 cur.cuda_stream), "tp_gather_sync")
+
+    def begin(self) -> torch.Tensor:
+        """Rows ``[lo, hi)`` of the buffer the NEXT ``submit`` sends: the projector's ``_out``.  (The current stream first
+        waits for this rank's own copies out of that buffer, ``depth`` steps ago.)"""
+        k = self._step % self.depth
+        cur = torch.cuda.current_stream(self.device)
+        for ev in self._push_done[k]:
+            if ev is not None:
+                cur.wait_event(ev)
+        return self.bufs[k][self.lo:self.hi]
+
+    def submit(self, local: Optional[torch.Tensor] = None):
+        """Send this step's shard to every peer; returns the ticket ``result`` takes.  ``local``: a shard that is not
+        already in ``begin()``'s view is copied there first."""
+        ct = self._ct
+        with torch.cuda.device(self.device):
+            view = self.begin()
+            if local is not None and (local.data_ptr() != view.data_ptr() or tuple(local.shape) != tuple(view.shape)):
+                if tuple(local.shape) != tuple(view.shape) or local.dtype != view.dtype:
+                    raise ValueError(f"local shard {tuple(local.shape)} {local.dtype} != expected {tuple(view.shape)} {view.dtype}")
+                view.copy_(local)
+            k, seq = self._step % self.depth, self._step + 1
+            cell = self.cells.data_ptr() + 4 * (seq % 8)
+            cur = torch.cuda.current_stream(self.device)
+            self._sync(seq - 1, cell, seq)                    # every peer's previous shard is here; publish this step's number
+            self._waited = max(self._waited, seq - 1)
+            n = len(self.peers)
+            if n:
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                for st in self.streams:
+                    st.wait_event(ev)
+                arr = ct.c_void_p * n
+                self._capi.check(self.lib.tp_gather_push(n, arr(*self._dst[k]), view.data_ptr(), self._nbytes, arr(*self._dst_flag),
+                                                         cell, arr(*[st.cuda_stream for st in self.streams]), self.use_cus),
+                                 "tp_gather_push")
+                for j, st in enumerate(self.streams):
+                    e = torch.cuda.Event()
+                    e.record(st)
+                    self._push_done[k][j] = e
+            self._step += 1
+            return (seq, k)
+
+    def result(self, ticket) -> torch.Tensor:
+        """``[total, M, D]`` of the step ``ticket`` names; the current stream waits until every peer's shard has landed."""
+        seq, k = ticket
+        if seq > self._waited:
+            with torch.cuda.device(self.device):
+                self._sync(seq, None, 0)
+            self._waited = seq
+        return self.bufs[k]
+
+    def drain(self) -> None:
+        if self._step:
+            self.result((self._step, (self._step - 1) % self.depth))
+
+    def check(self) -> None:
+        """Raise if a wait ran into its timeout (a peer died or never submitted).  Synchronises."""
+        if int(self.status.item()) != 0:
+            raise TimeoutError(f"DirectGather rank {self.rank}: a peer's shard did not arrive within {self.timeout_ms} ms")
+
+    def close(self) -> None:
+        if self._closed:
+            return
+        self._closed = True
+        self.drain()
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=self.group)                        # nobody is still writing into anybody
+        with torch.cuda.device(self.device):
+            for base in self._opened:
+                self._capi.check(self.lib.tp_gather_close(base), "tp_gather_close")
+        self._opened = []
+        self.check()
+
+
 def project_sharded(project: Callable[[Tuple[torch.Tensor, torch.Tensor]], torch.Tensor],
                     x_local: torch.Tensor, xm_local: torch.Tensor, total: int,
                     group: Optional[dist.ProcessGroup] = None, gather: bool = True,
@@ -196,7 +360,10 @@ def project_sharded(project: Callable[[Tuple[torch.Tensor, torch.Tensor]], torch
     b = x_local.shape[0]
     equal = min(sizes) == max(sizes)
     if not equal:
-        if getattr(project, "supports_out", False):
+        # (the _out fast path is inference-only: TokenPacker refuses _out while a gradient is live — then the shard goes
+        # through the plain forward and the pad copy, as it did before the fast path existed)
+        grad_live = torch.is_grad_enabled() and any(p.requires_grad for p in getattr(project, "parameters", lambda: [])())
+        if getattr(project, "supports_out", False) and not grad_live:
             probe = project.out_like(x_local)                              # (dtype, device, tail) of the result
             slot, b_r = ragged_local_buffer(total, probe[0], probe[1], group)
             y = project((x_local, xm_local), _out=slot[:b_r]) if b_r else slot[:0]
