@@ -192,7 +192,7 @@ def test_out_proj_fold_is_equivalent():
         _capi.set_tuning(_capi.TP_TUNE_FOLD_OUT_PROJ, 0)
     print(f"\n[parity] out_proj fold off/on: rel_err {errs[0][0]:.3e} / {errs[1][0]:.3e}, rel_l2 {errs[0][1]:.3e} / {errs[1][1]:.3e}")
     assert not torch.equal(errs[0][2], errs[1][2])             # the knob really switches the path
-    assert errs[1][1] <= 1.1 * errs[0][1] and errs[1][0] <= 1.5e-3
+    assert errs[1][1] <= 1.1 * errs[0][1] and errs[1][0] <= 1.0e-3 and errs[0][0] <= 1.0e-3      # the shipped s = 2 schedule: the 1e-3 gate
 
 
 def test_errors_on_gpu_inputs():
@@ -450,6 +450,9 @@ def test_attn_mask_is_honoured(s, dtype):
             y_exact = orc.forward(p_lp, x, xm, scale_factor=s, compute_dtype=torch.float64, io_dtype=dtype,
                                   attn_mask=mask.cpu().float() if mask.dtype != torch.bool else mask.cpu())
             e = orc.rel_err(y, y_exact)
+            # (a masked forward runs a FALLBACK schedule — K | V rounded to fp16 in front of the attention kernel, or the
+            # absorbed one: one fp16 rounding more in series than the shipped s = 2 path, whose gate is 1e-3; the reference
+            # never passes a mask, llava_arch.py:97)
             assert e <= 1.2e-3, (tuple(mask.shape), mask.dtype, e)
             assert float((y - y0).abs().max()) > 0.05          # the mask changes the result
     if s == 2:
@@ -483,7 +486,8 @@ def test_whole_path_other_scale_factors_and_grids(grid, s):
     assert y.shape == (B, (grid // s) ** 2, D)
     e = orc.rel_err(y, y_exact)
     print(f"\n[parity] grid={grid} s={s}: rel_err {e:.3e}")
-    assert e <= 1.2e-3, e
+    shipped = s == 2 and (grid * grid) % 8 == 0             # attention inside the in-projection epilogues: the 1e-3 gate
+    assert e <= (1.0e-3 if shipped else 1.2e-3), e
     assert sum(m.saturation_report().values()) == 0
 
 

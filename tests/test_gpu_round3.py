@@ -1,0 +1,192 @@
+"""Round-3 additions, on a real MI355X: the parity claim as a DISTRIBUTION over seeds, every legal combination of the
+schedule knobs against the oracle, the sticky fp16-saturation word, the pack registry, per-stream state release."""
+import ctypes
+import itertools
+import json
+import os
+import statistics
+import warnings
+
+import pytest
+import torch
+
+from oracle import tokenpacker_oracle as orc
+from tokenpacker_amd import TokenPacker, _capi, build_vision_projector, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _module(params, s, D, dtype, grid=24):
+    m = TokenPacker(raw_grid=grid, hidden_size=D, scale_factor=s)
+    m.load_state_dict(params, strict=True)
+    return m.to(device="cuda", dtype=dtype).eval().requires_grad_(False)
+
+
+# Stated claim (README / DESIGN §3), measured on MI355X over 16 seeds x s in {2, 3, 4} x {bf16 with fp32 output, fp16}
+# (profiles/r03_parity_seed_sweep.json); metric max|y - y_ref| / max|y_ref| against the fp64 oracle on the SAME rounded
+# operands:
+#   scale_factor 2 — the north_star's gated configuration, attention inside the in-projection epilogues, 5 fp16 roundings in
+#     series on the value path: EVERY seed <= 1e-3 (measured: median 6.5e-4 / 7.3e-4, worst seed 8.2e-4 / 8.5e-4);
+#   scale_factor 3, 4 — the absorbed schedule carries one rounding more (u between the attention kernel and the per-head V
+#     GEMM): median <= 8.5e-4, worst seed <= 1.1e-3 (measured: medians 7.2e-4 .. 8.1e-4, worst seed 1.016e-3), rel-L2 <= 8.5e-4.
+GATES = {2: dict(median=8.0e-4, max=1.0e-3, l2=7.5e-4), 3: dict(median=8.5e-4, max=1.1e-3, l2=8.5e-4),
+         4: dict(median=8.5e-4, max=1.1e-3, l2=8.5e-4)}
+
+
+def test_parity_seed_sweep():
+    D, B, seeds = 256, 4, 16
+    rows, summary = [], {}
+    for s, (dtype, tag) in itertools.product((2, 3, 4), ((torch.bfloat16, "bf16_fp32out"), (torch.float16, "fp16"))):
+        errs, l2s = [], []
+        for seed in range(seeds):
+            params = synth.make_params(9000 + 17 * seed + s, D)
+            x, xm = synth.make_inputs(9500 + 31 * seed + s, B, dtype)
+            m = _module(params, s, D, dtype)
+            m.output_fp32 = dtype == torch.bfloat16
+            with torch.no_grad():
+                y = m((x.cuda(), xm.cuda()))
+            p_lp = {k: v.to(dtype) for k, v in params.items()}
+            y_exact = orc.forward(p_lp, x, xm, scale_factor=s, compute_dtype=torch.float64, io_dtype=dtype)
+            errs.append(orc.rel_err(y, y_exact))
+            l2s.append(orc.rel_l2(y, y_exact))
+        key = f"s{s}_{tag}"
+        summary[key] = {"median": statistics.median(errs), "max": max(errs), "min": min(errs),
+                        "l2_median": statistics.median(l2s), "l2_max": max(l2s), "seeds": seeds}
+        rows.append((s, key, summary[key]))
+        print(f"\n[parity-sweep] {key}: rel-max median {summary[key]['median']:.3e} max {summary[key]['max']:.3e} "
+              f"min {summary[key]['min']:.3e} | rel-L2 median {summary[key]['l2_median']:.3e} max {summary[key]['l2_max']:.3e}")
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_seed_sweep.json", "w") as f:
+        json.dump(summary, f, indent=1)
+    for s, key, r in rows:
+        assert r["median"] <= GATES[s]["median"], (key, r)
+        assert r["max"] <= GATES[s]["max"], (key, r)
+        assert r["l2_max"] <= GATES[s]["l2"], (key, r)
+
+
+def _legal_tunings(s):
+    """Every combination of the schedule knobs plan_schedule reads, for scale factor s (values outside a knob's documented
+    range are not enumerated)."""
+    keys = (_capi.TP_TUNE_FUSE_KV_LN, _capi.TP_TUNE_FUSE_ATTN, _capi.TP_TUNE_ABSORB_KV, _capi.TP_TUNE_FOLD_OUT_PROJ,
+            _capi.TP_TUNE_Q_SIDE_STREAM, _capi.TP_TUNE_LN_MERGE)
+    ranges = ((0, 1), (0, 1, 2) if s == 2 else (0,), (0, 1, 2), (0, 1, 2), (0, 1), (0, 1))
+    for combo in itertools.product(*ranges):
+        yield dict(zip(keys, combo))
+
+
+@pytest.mark.parametrize("s,grid,masked", [(2, 24, False), (2, 24, True), (3, 24, False), (2, 6, False), (4, 24, True)])
+def test_every_schedule_the_tuning_table_can_select(s, grid, masked):
+    """forward_impl runs whatever plan_schedule() derives from the tuning table of the moment; the inference image carries
+    every folded weight, so ANY combination must give the oracle's result — one pack, no re-pack between combinations (the
+    C-ABI caller's situation: a knob turned after tp_pack_weights)."""
+    dtype, D, B = torch.float16, 256, 2
+    params = synth.make_params(640 + s, D)
+    g = torch.Generator().manual_seed(641 + s + grid)
+    x = torch.randn(B, grid * grid, 1024, generator=g).to(dtype)
+    xm = torch.randn(B, grid * grid, 4096, generator=g).to(dtype)
+    mask = synth.make_attn_masks(642, B, s)[0] if masked else None
+    m = _module(params, s, D, dtype, grid)
+    m.output_fp32 = True
+    p_lp = {k: v.to(dtype) for k, v in params.items()}
+    y_exact = orc.forward(p_lp, x, xm, scale_factor=s, raw_grid=grid, compute_dtype=torch.float64, io_dtype=dtype,
+                          attn_mask=mask)
+    worst, n, packs = 0.0, 0, set()
+    try:
+        for tun in _legal_tunings(s):
+            for k, v in tun.items():
+                _capi.set_tuning(k, v)
+            with torch.no_grad():
+                y = m((x.cuda(), xm.cuda()), attn_mask=mask)
+            packs.add(m._packed.data_ptr())
+            e = orc.rel_err(y, y_exact)
+            worst, n = max(worst, e), n + 1
+            assert e <= 1.5e-3, (tun, e)
+    finally:
+        for k, v in _capi._TUNING_DEFAULTS.items():
+            _capi.set_tuning(k, v)
+    print(f"\n[schedules] s={s} grid={grid} masked={masked}: {n} tuning combinations, worst rel_err {worst:.3e}, packs {len(packs)}")
+    assert len(packs) == 1
+
+
+def test_sticky_saturation_word_and_warning():
+    """An activation beyond the fp16 range is CLAMPED where the reference's half-precision arithmetic would have produced
+    inf; the forward ORs the stage's bit into the workspace's status word (no scan, no synchronisation) and the module
+    warns once."""
+    dtype, D, B, s = torch.bfloat16, 256, 2, 2
+    params = synth.make_params(77, D)
+    x, xm = synth.make_inputs(78, B, dtype)
+    m = _module(params, s, D, dtype)
+    with torch.no_grad():
+        m((x.cuda(), xm.cuda()))
+        assert m.saturated_stages() == ()
+        params["k_proj_1.0.bias"] = params["k_proj_1.0.bias"] + 3.0e5      # GELU(x W^T + b) >> 65504 in every K-side column
+        m2 = _module(params, s, D, dtype)
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            for _ in range(6):
+                m2((x.cuda(), xm.cuda()))
+                torch.cuda.synchronize()
+        stages = m2.saturated_stages()
+        assert "kv_layer0_gelu" in stages, stages
+        assert sum("saturated" in str(w.message) for w in rec) == 1
+        assert m2.saturation_report()["Hkv"] > 0                            # the scan agrees
+        assert m2.saturated_stages(clear=True) == stages and m2.saturated_stages() == ()      # cleared ...
+        m2((x.cuda(), xm.cuda()))
+        assert "kv_layer0_gelu" in m2.saturated_stages()                                         # ... and set again by the next forward
+
+
+def test_pack_registry_refuses_the_wrong_image():
+    """tp_forward on a TRAIN_PACK image (no inference-only weights), or on an image packed for another hidden size, is an
+    error — not a multiplication by weights that were never written."""
+    lib = _capi.load_library()
+    dtype, s = torch.bfloat16, 2
+    m = _module(synth.make_params(5, 256), s, 256, dtype)
+    stream = torch.cuda.current_stream().cuda_stream
+    img = m._ensure_packed(dtype, torch.device("cuda", 0), stream, force=True)          # what a training step packs
+    x, xm = synth.make_inputs(6, 1, dtype)
+    x, xm = x.cuda(), xm.cuda()
+    out = torch.empty(1, 144, 256, dtype=dtype, device="cuda")
+    d = _capi.make_desc(1, 24, s, 256, _capi.TP_BF16)
+    ws = torch.zeros(lib.tp_workspace_bytes(ctypes.byref(d)), dtype=torch.uint8, device="cuda")
+    args = (x.data_ptr(), _capi.strides3(x.stride()), xm.data_ptr(), _capi.strides3(xm.stride()))
+    rc = lib.tp_forward(ctypes.byref(d), *args, img.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+    assert rc == _capi.TP_ERR_INVALID_ARG and "TRAIN_PACK" in _capi.last_error()
+    img2 = m._ensure_packed(dtype, torch.device("cuda", 0), stream)                     # an inference image
+    assert lib.tp_forward(ctypes.byref(d), *args, img2.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), stream) == _capi.TP_OK
+    d512 = _capi.make_desc(1, 24, s, 512, _capi.TP_BF16)
+    ws512 = torch.zeros(lib.tp_workspace_bytes(ctypes.byref(d512)), dtype=torch.uint8, device="cuda")
+    out512 = torch.empty(1, 144, 512, dtype=dtype, device="cuda")
+    rc = lib.tp_forward(ctypes.byref(d512), *args, img2.data_ptr(), out512.data_ptr(), ws512.data_ptr(), ws512.numel(), stream)
+    assert rc == _capi.TP_ERR_INVALID_ARG and "hidden_size" in _capi.last_error()
+    # a masked forward needs the workspace sized WITH the flag
+    mask = torch.zeros(1, 4, dtype=torch.float32, device="cuda")
+    rc = lib.tp_forward_masked(ctypes.byref(d), *args, img2.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), mask.data_ptr(), 1, stream)
+    assert rc == _capi.TP_ERR_WORKSPACE and "TP_DESC_MASKED" in _capi.last_error()
+    torch.cuda.synchronize()
+
+
+def test_release_stream_and_lru_of_the_side_stream_cache():
+    lib = _capi.load_library()
+    dtype = torch.bfloat16
+    m = _module(synth.make_params(8, 256), 2, 256, dtype)
+    x, xm = synth.make_inputs(9, 1, dtype)
+    x, xm = x.cuda(), xm.cuda()
+    with torch.no_grad():
+        y0 = m((x, xm))
+        base = lib.tp_test_side_cache_size()
+        streams = [torch.cuda.Stream() for _ in range(70)]                 # more caller streams than the cache holds
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                assert torch.equal(m((x, xm)), y0)
+        torch.cuda.synchronize()
+        assert lib.tp_test_side_cache_size() <= 64 and len(m._workspaces) <= m._MAX_WORKSPACES
+        n = lib.tp_test_side_cache_size()
+        m.release_stream(streams[-1])
+        assert lib.tp_test_side_cache_size() == n - 1
+        m.release_stream(streams[-1])                                      # unknown to the library now: not an error
+        assert lib.tp_release_stream(None) == _capi.TP_OK
+        with torch.cuda.stream(streams[-1]):
+            assert torch.equal(m((x, xm)), y0)                             # and the stream still works afterwards
+        torch.cuda.synchronize()
+    assert base >= 1
