@@ -276,8 +276,11 @@ typedef struct tp_linear_args {
     int32_t tile;              /* 0 = auto, 128 or 256: force the block tile                       */
     int32_t reserved1;
     float*  row_stats_out;     /* ROW_STATS                                                        */
+    void*   sk_workspace;      /* optional: tp_linear_sk_workspace_bytes() of scratch — lets the launch run as stream-K     */
+                               /* (TP_TUNE_STREAM_K; tp_linear zeroes the flag words itself).  NULL: never stream-K        */
 } tp_linear_args;
 int tp_linear(const tp_linear_args* args, void* stream);
+size_t tp_linear_sk_workspace_bytes(void);
 /* (mean, M2) slabs [parts][M][2] written by a TP_LINEAR_ROW_STATS call -> per-row (mean, rstd)
  * [M][2] of nn.LayerNorm(ln_dim, eps) (biased variance), for a TP_LINEAR_LN_FOLD call.  ln_dim == parts * 128. */
 int tp_ln_finalize(const float* row_stats, int parts, int64_t M, int ln_dim, float eps,
@@ -426,6 +429,14 @@ enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all hal
                                      same images inside a large batch (the default keeps them bit-identical). */
        TP_TUNE_SMALL_GEMM_WAVES = 12, /* the 128 x 128-tile kernel as 4 waves of 64 x 64 or 8 waves of 32 x 64 (bit-identical): 0 (default)
                                      auto by the number of workgroups of the launch | 4 | 8 */
+       TP_TUNE_STREAM_K = 13,     /* stream-K decomposition of a persistent GEMM launch whose tile count is not a multiple of the CU
+                                     count (tp_gemm8.hip SK): the launch's K-tiles are shared evenly, a tile cut in two hands one fp32
+                                     partial over between neighbouring workgroups.  0 (default) auto by a cost model — at the shipped
+                                     shapes the first K/V layer and mlp[2] of batches of ~15 .. 200 images, e.g. the 32-image shard of
+                                     an 8-GPU batch: 2.25 / 1.125 tiles per CU cost that, not 3 / 1.5 | 1 never | 2 whenever eligible.
+                                     Deterministic for a given batch size, but a split tile's summation order is not the unsplit
+                                     kernels': with 0 / 2 an image's low bits depend on the batch it travels in (1 keeps them
+                                     independent of it, as rounds 1-2 shipped) */
        TP_TUNE_COUNT_ = 16 };
 int tp_set_tuning(int key, int value);
 int tp_get_tuning(int key);                  /* the library's current value (not a binding's shadow copy); -1: bad key */

@@ -15,7 +15,7 @@ def stream_ptr():
 
 
 def linear(A, W, bias=None, flags=0, tile=0, rows_per_batch=0, a_batch_stride=0, lda=None, M=None,
-           mean_rstd=None, colsum=None, want_stats=False, out_dtype=None, kern=0, sync=True):
+           mean_rstd=None, colsum=None, want_stats=False, out_dtype=None, kern=0, sync=True, sk_workspace=None):
     """C = epilogue(A · W^T) through tp_linear.  A may be a 2-D tensor or a raw (ptr-bearing) tensor
     with explicit M / lda / batch strides.  tile: 0 auto | 128 | 256; a NEGATIVE tile (-256) or kern=1
     selects the two-phase 256-tile main loop instead of the default ping-pong kernel (tp_gemm8.hip)."""
@@ -42,6 +42,7 @@ def linear(A, W, bias=None, flags=0, tile=0, rows_per_batch=0, a_batch_stride=0,
     args.row_mean_rstd = mean_rstd.data_ptr() if mean_rstd is not None else None
     args.colsum = colsum.data_ptr() if colsum is not None else None
     args.tile = tile
+    args.sk_workspace = sk_workspace.data_ptr() if sk_workspace is not None else None
     stats = None
     if want_stats:
         parts = lib.tp_linear_stats_parts(ctypes.byref(args))
@@ -120,8 +121,22 @@ def training_schedule_for_inference():
     two bit-identical."""
     _capi.set_tuning(_capi.TP_TUNE_ABSORB_KV, 1)
     _capi.set_tuning(_capi.TP_TUNE_FUSE_KV_LN, 0)
+    _capi.set_tuning(_capi.TP_TUNE_STREAM_K, 1)        # the training forward never runs stream-K
     try:
         yield
     finally:
         _capi.set_tuning(_capi.TP_TUNE_ABSORB_KV, 0)
         _capi.set_tuning(_capi.TP_TUNE_FUSE_KV_LN, 1)
+        _capi.set_tuning(_capi.TP_TUNE_STREAM_K, 0)
+
+
+@contextlib.contextmanager
+def batch_invariant():
+    """TP_TUNE_STREAM_K = 1: no launch is decomposed stream-K, so a row's bits depend on nothing but the row — not on the
+    batch it travels in, nor on the order of the rows (the default trades that for the idle last round of a launch whose
+    tile count is not a multiple of the CU count; results stay deterministic for a given batch size either way)."""
+    _capi.set_tuning(_capi.TP_TUNE_STREAM_K, 1)
+    try:
+        yield
+    finally:
+        _capi.set_tuning(_capi.TP_TUNE_STREAM_K, 0)

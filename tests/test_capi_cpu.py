@@ -31,7 +31,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_capi.tp_desc) == 32
     assert ctypes.sizeof(_capi.tp_weights) == 23 * ctypes.sizeof(ctypes.c_void_p)
     assert len(_capi.WEIGHT_FIELDS) == 23
-    assert ctypes.sizeof(_capi.tp_linear_args) == 8 * 4 + 3 * 8 + 6 * 8 + 2 * 4 + 8
+    assert ctypes.sizeof(_capi.tp_linear_args) == 8 * 4 + 3 * 8 + 6 * 8 + 2 * 4 + 8 + 8
 
 
 def test_sizes_and_descriptor_validation():

@@ -23,6 +23,7 @@ TP_TUNE_FUSE_ATTN = 10
 TP_TUNE_LN_MERGE = 9
 TP_TUNE_SPLIT_K = 11
 TP_TUNE_SMALL_GEMM_WAVES = 12
+TP_TUNE_STREAM_K = 13
 TP_WGRAD_X_TRANSPOSED = 1
 TP_NUM_STAGES = 10
 TP_NUM_DEBUG_BUFFERS = 9
@@ -43,7 +44,7 @@ EXPORTED_SYMBOLS = (
     "tp_wgrad", "tp_wgrad_workspace_bytes", "tp_packed_status_offset", "tp_debug_count_saturated",
     "tp_region_attention_absorbed", "tp_forward_masked",
     "tp_get_tuning", "tp_release_stream", "tp_test_side_cache_size",
-    "tp_gather_export", "tp_gather_open", "tp_gather_close", "tp_gather_push", "tp_gather_sync",
+    "tp_linear_sk_workspace_bytes", "tp_gather_export", "tp_gather_open", "tp_gather_close", "tp_gather_push", "tp_gather_sync",
 )
 
 # state-dict name -> tp_weights field order (include/tokenpacker.h)
@@ -83,7 +84,7 @@ class tp_linear_args(Structure):
                 ("a_batch_stride", c_int64), ("lda", c_int64), ("ldc", c_int64),
                 ("A", c_void_p), ("W", c_void_p), ("bias", c_void_p), ("C", c_void_p),
                 ("row_mean_rstd", c_void_p), ("colsum", c_void_p),
-                ("tile", c_int32), ("reserved1", c_int32), ("row_stats_out", c_void_p)]
+                ("tile", c_int32), ("reserved1", c_int32), ("row_stats_out", c_void_p), ("sk_workspace", c_void_p)]
 
 
 class tp_hd_image(Structure):
@@ -146,6 +147,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.tp_linear.argtypes = [POINTER(tp_linear_args), c_void_p]
     lib.tp_ln_finalize.restype = c_int
     lib.tp_ln_finalize.argtypes = [c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_void_p]
+    lib.tp_linear_sk_workspace_bytes.restype = c_size_t
+    lib.tp_linear_sk_workspace_bytes.argtypes = []
     lib.tp_linear_stats_parts.restype = c_int
     lib.tp_linear_stats_parts.argtypes = [POINTER(tp_linear_args)]
     lib.tp_set_tuning.restype = c_int
@@ -239,7 +242,7 @@ def strides3(st) -> "ctypes.Array":
 # the library's defaults (tests reset the table to these)
 _TUNING_DEFAULTS = {TP_TUNE_GEMM_TILE: 0, TP_TUNE_XCD_SWIZZLE: 1, TP_TUNE_GEMM_KERNEL: 0, TP_TUNE_FOLD_OUT_PROJ: 0,
                     TP_TUNE_DYNAMIC_TILES: 1, TP_TUNE_Q_SIDE_STREAM: 1, TP_TUNE_RESERVE_CUS: 0, TP_TUNE_ABSORB_KV: 0, TP_TUNE_FUSE_KV_LN: 1,
-                    TP_TUNE_FUSE_ATTN: 0, TP_TUNE_LN_MERGE: 0, TP_TUNE_SPLIT_K: 0, TP_TUNE_SMALL_GEMM_WAVES: 0}
+                    TP_TUNE_FUSE_ATTN: 0, TP_TUNE_LN_MERGE: 0, TP_TUNE_SPLIT_K: 0, TP_TUNE_SMALL_GEMM_WAVES: 0, TP_TUNE_STREAM_K: 0}
 
 
 def set_tuning(key: int, value: int) -> None:

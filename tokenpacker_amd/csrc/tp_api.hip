@@ -97,7 +97,8 @@ WorkspaceLayout workspace_layout(int B, int grid, int s, int D, const SchedulePl
     L.o = take(rows_q * E * 2);
     L.a1 = take_if(P.need_a1, rows_q * E * 2);
     L.a2 = take(rows_q * (size_t)D * 2);
-    L.counters = take(4096);
+    L.counters = take(kCounterBytes);                       // tile-queue heads + stream-K flags of every launch, zeroed per forward
+    L.sk_slabs = take(kStreamKSlabBytes);                   // stream-K partial accumulators (one 256 KiB slab per workgroup)
     L.splitk = take_if(P.split_k, kSplitKBytes);
     L.z1 = L.z2 = kNoSlab;
     if (P.train) { L.z1 = take(rows_kv * 2 * E * 2); L.z2 = take(rows_q * (size_t)D * 2); }
@@ -557,8 +558,17 @@ int tp_linear(const tp_linear_args* a, void* stream) {
     g.M = a->M; g.N = a->N; g.K = a->K; g.flags = a->flags;
     g.groups = 1; g.tile = a->tile;
     if (a->flags & TP_LINEAR_OUT_F32) { set_error("tp_linear: TP_LINEAR_OUT_F32 was replaced by out_dtype = TP_F32"); return TP_ERR_INVALID_ARG; }
+    if (a->sk_workspace) {                              // [flags: one int per workgroup][slabs]
+        if ((uintptr_t)a->sk_workspace & 255) { set_error("tp_linear: sk_workspace must be 256-byte aligned"); return TP_ERR_INVALID_ARG; }
+        hipError_t e = hipMemsetAsync(a->sk_workspace, 0, kStreamKMaxWorkgroups * 4, (hipStream_t)stream);
+        if (e != hipSuccess) { set_error("tp_linear: hipMemsetAsync: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
+        g.sk_flags = (int*)a->sk_workspace;
+        g.sk_slabs = (float*)((char*)a->sk_workspace + kStreamKMaxWorkgroups * 4);
+    }
     return gemm_launch(a->dtype, a->out_dtype, g, (hipStream_t)stream);
 }
+
+size_t tp_linear_sk_workspace_bytes(void) { return kStreamKSlabBytes + kStreamKMaxWorkgroups * 4; }
 
 }  // extern "C"  (forward_impl has C++ linkage: tp_train.hip calls it too)
 
@@ -690,13 +700,21 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     // tile-queue heads of the persistent GEMM launches: 64 ints per launch (<= 16 launches), zeroed once per forward
     int* counters = tuning(TP_TUNE_DYNAMIC_TILES) ? (int*)(ws + W.counters) : nullptr;
     if (counters) {
-        hipError_t e = hipMemsetAsync(counters, 0, 4096, stream);
+        hipError_t e = hipMemsetAsync(counters, 0, kCounterBytes, stream);
         if (e != hipSuccess) { set_error("tp_forward: hipMemsetAsync: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
     }
     int launch_no = 0;
     int stage_idx = 0;                                  // advanced by mark(): 1 .. TP_NUM_STAGES while stage k - 1 is being enqueued
     auto launch = [&](int in_dt, int out_dt, GemmArgs& a, hipStream_t st) -> int {
-        a.tile_counters = counters ? counters + 64 * launch_no++ : nullptr;      // [groups <= 8][8 XCDs] heads per launch
+        if (counters && launch_no < kMaxLaunches) {
+            a.tile_counters = counters + 64 * launch_no;                         // [groups <= 8][8 XCDs] heads per launch
+            a.sk_flags = counters + 64 * kMaxLaunches + kStreamKMaxWorkgroups * launch_no;     // stream-K: one flag per workgroup
+            a.sk_slabs = (float*)(ws + W.sk_slabs);                              // (launches of one stream run one after the other)
+            ++launch_no;
+        } else { a.tile_counters = nullptr; a.sk_flags = nullptr; a.sk_slabs = nullptr; }
+        // stream-K (GemmArgs::stream_k = 1: never): not for the training forward (its SAVE_PRE kernels cannot, and the whole
+        // forward must be the inference forward of the same schedule bit for bit); the query side's launches opt out themselves
+        if (train) a.stream_k = 1;
         a.sat_flag = (int*)(ws + W.status); a.sat_bit = 1 << stage_idx;          // sticky fp16-saturation bits, by stage (bit 0: query side)
         return gemm_launch(in_dt, out_dt, a, st);
     };
@@ -728,6 +746,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         GemmArgs a = plain_gemm(ws + W.q0, E, pw + P.w_q1, slab(W.q1pre), E, rows_q, E, E, nullptr,
                                 TP_LINEAR_ROW_STATS | (fuse_q ? TP_LINEAR_NO_STORE : 0));
         a.stats_out = (float*)(ws + W.stats_q);
+        a.stream_k = 1;                                 // (the query side may run beside the K/V side: one set of stream-K slabs)
         return launch(TP_F16, TP_F16, a, st);
     };
     // Small M (the 128-tile kernel): the consumer of a LayerNorm merges the producer's (mean, M2) slabs itself — one launch
@@ -748,6 +767,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         if (!merge_in_kernel(a, (const float*)(ws + W.stats_q), 0))
             TP_TRY(ln_finalize_launch((const float*)(ws + W.stats_q), (float*)(ws + W.mr_q), rows_q, parts_q, 1, E,
                                       desc->ln_eps, st));
+        a.stream_k = 1;
         return launch(TP_F16, TP_F16, a, st);
     };
     const bool absorb = plan.absorb;

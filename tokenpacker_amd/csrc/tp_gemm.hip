@@ -278,7 +278,22 @@ static int launch_types(const GemmArgs& a, hipStream_t stream) {
 // with a half tile at 0.75 of a full tile's time (0.63 at K <= 1024; a one-round tail also pays its first tile's
 // un-hidden DMA latency) and a second launch at ~8 us (dependent-launch gap) relative to a full tile's
 // 8.4 + 1.47 K/64 us (profiles/README.md).  Same epilogue, bit-identical results whatever the shape.
-enum { ROUTE_SMALL = 0, ROUTE_G8 = 1, ROUTE_G8_HALF = 2, ROUTE_G8_SPLIT = 3 };
+// (d) stream-K (tp_gemm8.hip SK, TP_TUNE_STREAM_K): the launch's K-tiles shared evenly by the workgroups — U K-tiles each at the
+//   main loop's 1.47 us, one epilogue per tile started, and ~14 us for the one partial a workgroup hands over and the one it
+//   takes in (256 KiB each way).  It wins where the tile count is a non-integer multiple of the CU count and K is long:
+//   the first K/V layer and mlp[2] of a 32-image shard (2.25 and 1.125 tiles per CU).
+enum { ROUTE_SMALL = 0, ROUTE_G8 = 1, ROUTE_G8_HALF = 2, ROUTE_G8_SPLIT = 3, ROUTE_G8_SK = 4 };
+// `best_other`: the cheapest alternative in units of a full tile's time
+static bool stream_k_pays(const GemmArgs& a, double best_other) {
+    double u = 0;
+    const int skmode = tuning(TP_TUNE_STREAM_K);
+    if (skmode == 1 || a.stream_k == 1 || !gemm8_stream_k_eligible(a, &u)) return false;
+    if (skmode == 2) return true;
+    const long long per = gemm8_persistent_cus(), T = (long long)((a.M + 255) / 256) * (a.N / 256);
+    const double t_tile = 8.4 + 1.47 * (a.K / BK);
+    const double cost_d = (u * 1.47 + (double)(T / per + 1) * 8.4 + 14.0) / t_tile;
+    return cost_d < best_other - 0.05;
+}
 static int gemm_route(const GemmArgs& a, long long* head_rows_out) {
     const bool free_choice = a.tile == 0 && tuning(TP_TUNE_GEMM_TILE) == 0 && tuning(TP_TUNE_GEMM_KERNEL) == 0 &&
                              a.m_begin == 0 && a.m_end == 0 && !a.half_tiles && !a.A_parts[0] && a.N % 256 == 0 && a.K >= 2 * BK;
@@ -302,13 +317,23 @@ static int gemm_route(const GemmArgs& a, long long* head_rows_out) {
                 const long long tail_half = (long long)((a.M - head_rows + 127) / 128) * tiles_n;
                 if (head_rows < a.M) cost_b = (double)full + half * (double)rounds(tail_half) + launch;
             }
+            if (stream_k_pays(a, cost_a < cost_b ? (cost_a < cost_c ? cost_a : cost_c) : (cost_b < cost_c ? cost_b : cost_c))) return ROUTE_G8_SK;
             if (TH >= 64 && cost_c < cost_a - 0.05 && cost_c <= cost_b) return ROUTE_G8_HALF;
             if (cost_b < cost_a - 0.05) { *head_rows_out = head_rows; return ROUTE_G8_SPLIT; }
         }
     }
     if ((a.half_tiles && a.N % 256 == 0) ||
-        (gemm_pick_tile(a.M, a.N, a.tile, a.groups) == 256 && tuning(TP_TUNE_GEMM_KERNEL) != 1))
+        (gemm_pick_tile(a.M, a.N, a.tile, a.groups) == 256 && tuning(TP_TUNE_GEMM_KERNEL) != 1)) {
+        // (a four-part A operand takes none of the tile-shape alternatives above, but its launch must make the SAME stream-K
+        // decision as the concatenated operand's — the two forms are bit-identical, tests/test_gpu_parts.py)
+        if (a.A_parts[0] && a.tile == 0 && tuning(TP_TUNE_GEMM_TILE) == 0 && tuning(TP_TUNE_GEMM_KERNEL) == 0 && !a.half_tiles) {
+            GemmArgs cat = a;
+            for (int i = 0; i < 4; ++i) cat.A_parts[i] = nullptr;
+            long long h = 0;
+            if (gemm_route(cat, &h) == ROUTE_G8_SK) return ROUTE_G8_SK;
+        }
         return ROUTE_G8;
+    }
     return ROUTE_SMALL;
 }
 
@@ -372,6 +397,10 @@ int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stre
             rest.m_begin = (int)head_rows; rest.half_tiles = 1; rest.tile_counters = nullptr;
             if (int rc = gemm8_launch(in_dtype, out_dtype, head, stream)) return rc;
             return gemm8_launch(in_dtype, out_dtype, rest, stream);
+        }
+        if (route == ROUTE_G8_SK) {
+            GemmArgs sk = a; sk.stream_k = 2;
+            return gemm8_launch(in_dtype, out_dtype, sk, stream);
         }
         if (route == ROUTE_G8) return gemm8_launch(in_dtype, out_dtype, a, stream);
     }

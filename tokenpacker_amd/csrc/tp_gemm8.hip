@@ -111,9 +111,22 @@ constexpr int G8_DEPTH = 3;                        // DMA groups left in flight 
 //   Both take their epilogue parameters by LDS-DMA (one 1-KiB instruction per wave, issued with the prologue, two buffers)
 //   instead of the register-carried prefetch of the other modes: nothing rides through the epilogue in registers a
 //   compiler-inserted s_waitcnt could trip over, and the count of instructions behind the queries is the same in every wave.
-template <typename TI, typename TO, int AMODE, bool PERSIST, bool TRAIN_EPI, bool HALF = false, int XMODE = 0>
+// SK (stream-K, GemmArgs::stream_k): instead of whole tiles, the nwg workgroups share the launch's K-tiles EVENLY — the linearised
+//   (tile, K-tile) space is cut into nwg contiguous ranges (cuts closer than SK_MINSEG K-tiles to a tile boundary snap onto it), so
+//   a launch of 2.25 tiles per CU costs 2.25 tile times instead of 3 (or 2 + a half-tile tail launch).  A range covers at least one
+//   whole tile (checked on the host), hence a tile is shared by at most TWO workgroups, neighbours c and c + 1:
+//     c + 1 starts with the tile's TAIL K-range: its very first item; the fp32 accumulators go to slab c + 1 (256 KiB, write-through
+//           16-byte stores, every wave drains, ONE flag store) — at the START of the launch;
+//     c     ends with the tile's HEAD K-range: its last item; it polls flag c + 1 (long set by then), one agent-scope acquire, adds
+//           the slab to its accumulators and runs the ordinary epilogue.  Nobody waits for anybody who waits: no deadlock whatever
+//           the dispatch order; a neighbour that starts late only delays its one consumer.
+//   Summation order = head K-range, then + tail partial: fixed by the decomposition, i.e. deterministic for a given (M, N, K, CUs) —
+//   but NOT the order of the unsplit kernels: a split tile's low bits differ from the same rows computed inside another batch size.
+constexpr int SK_MINSEG = 4;
+template <typename TI, typename TO, int AMODE, bool PERSIST, bool TRAIN_EPI, bool HALF = false, int XMODE = 0, bool SK = false>
 __global__ void __launch_bounds__(512, 2)
 gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int xcd_swizzle) {
+    static_assert(!SK || (PERSIST && !HALF && XMODE == 0 && !TRAIN_EPI && (AMODE == 0 || AMODE == 1 || AMODE == 2)), "stream-K: plain persistent full-tile kernels");
     using X8 = typename Vec<TI>::x8;
     constexpr int BM = HALF ? G8_BM / 2 : G8_BM, BN = G8_BN, WM = BM / 2, WN = G8_WN;
     constexpr bool A_KMAJOR = (AMODE == 3 || AMODE == 4), W_KMAJOR = (AMODE == 3);
@@ -142,7 +155,9 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int g = blockIdx.y;
-    const int nk = p.K / BK;
+    const int nk_full = p.K / BK;
+    int nk = nk_full;                                   // K-tiles of the item being set up / computed (SK: a K-range of a tile)
+    int kt_base = 0;                                    // SK: first K-tile of that range
     const long long ldw = p.ldw_bytes ? p.ldw_bytes : (long long)p.K * 2;
 
     // ---- this workgroup's tile list: L, L + L_step, ... < L_end (indices into the tile_m-major tile order) ----
@@ -150,6 +165,20 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
     int L, L_end, L_step;
     int* queue = nullptr;                               // per-XCD queue head (tiles beyond the first round), or static
     int queue_base = 0;
+    int sk_u = 0, sk_end = 0, sk_c = 0;                // SK: this workgroup's range of K-tile units and its linear index
+    if constexpr (SK) {
+        // XCD-contiguous linear index: neighbours (which share a tile) sit on one XCD — their slab travels through one L2
+        sk_c = (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3);
+        const long long total = (long long)ntiles * nk_full;
+        auto bound = [&](const int c) -> int {
+            int b = (int)((long long)c * total / nwg);
+            const int r = b % nk_full;
+            if (r < SK_MINSEG) b -= r; else if (r > nk_full - SK_MINSEG) b += nk_full - r;
+            return b;
+        };
+        sk_u = bound(sk_c); sk_end = bound(sk_c + 1);
+        L = sk_u / nk_full; L_end = ntiles; L_step = 1;
+    } else
     if (ntiles <= nwg) {                               // one tile per workgroup
         L = xcd_swizzle ? xcd_remap(blockIdx.x, nwg) : (int)blockIdx.x;
         L_end = L + 1; L_step = 1;
@@ -291,12 +320,13 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
                                                          is_a ? voff_a[sub][q] : voff_w[sub][q], 0, 0, 0);
             return;
         }
-        const int soff = kt * ROW_BYTES;
+        const int soff = (SK ? kt_base + kt : kt) * ROW_BYTES;
         if constexpr (is_a && AMODE == 2) {
             // K-tile kt lives in source kt / tpp: pick that source's base with scalar selects and rebuild the
             // descriptor (words 2, 3 are constants) — four resident descriptors cost 12 more SGPRs, which pushed
             // hipcc into VGPR-held descriptors and waterfall loops around every DMA instruction
-            const int tpp = p.k_part / BK, part = kt / tpp, so = (kt - part * tpp) * ROW_BYTES;   // wave-uniform
+            const int ktg = SK ? kt_base + kt : kt;
+            const int tpp = p.k_part / BK, part = ktg / tpp, so = (ktg - part * tpp) * ROW_BYTES;   // wave-uniform
             const char* b = part == 0 ? p.A_parts[0] : part == 1 ? p.A_parts[1] : part == 2 ? p.A_parts[2] : p.A_parts[3];
             const unsigned long long addr = (unsigned long long)(b + a_tile_off_cur);
             const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)addr);
@@ -620,6 +650,10 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
             else *(float2*)(par + 2 * BN + 2 * (tid - 256)) = pf_mr;
         };
 
+        if constexpr (SK) {                             // the first item may start inside a tile (the tile's tail K-range)
+            kt_base = sk_u - L * nk_full;
+            nk = nk_full - kt_base < sk_end - sk_u ? nk_full - kt_base : sk_end - sk_u;
+        }
         setup_tile(L);
         prefetch_params();
         if constexpr (DMA_PAR) issue_params(0);
@@ -641,9 +675,20 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
             const int m0c = m0, n0c = n0, tile_nc = tile_n;
             int Ln = L + L_step;
             if (queue) Ln = queue_base + __builtin_amdgcn_readfirstlane(*(const int*)(smem + L_NEXT));
+            bool sk_tail = false, sk_need = false;          // SK: this item was a tile's tail K-range / a head that lacks its tail
+            if constexpr (SK) {
+                sk_tail = kt_base > 0;
+                sk_need = !sk_tail && nk < nk_full;
+                sk_u += nk;
+                Ln = sk_u < sk_end ? sk_u / nk_full : L_end;
+            }
             const bool has_next = Ln < L_end;               // wave-uniform
             const char* lds_q = smem + ring_of(nk - 2) * KBUF + (HALF ? 0 : 2 * G8_GROUP);     // XMODE 3: where the queries are
             if (has_next) {
+                if constexpr (SK) {
+                    kt_base = sk_u - Ln * nk_full;
+                    nk = nk_full - kt_base < sk_end - sk_u ? nk_full - kt_base : sk_end - sk_u;
+                }
                 setup_tile(Ln);
                 if constexpr (XMODE == 3 && !HALF) ring_base ^= 1;
                 prefetch_params();
@@ -672,6 +717,57 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
             else if constexpr (XMODE == 4)
                 attn_sum_epilogue<BM, BN, WM, WN, true, PAR_LG>(acc, p, g, m0c, n0c, wm, wn, lane, mean_rstd,
                                                                 smem + L_PAR + par_buf * PAR_SZ);
+            else if constexpr (SK) {
+                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                // slab c: [wave][fragment i * FN + j][lane] x 16 B — every wave instruction moves 1 KiB contiguous, and the
+                // consumer's lanes hold the same elements (same kernel, same layout)
+                // (the lane's offset is recomputed here from a laundered lane id: hoisted out of the tile loop it would cost the
+                // K loop a register it does not have)
+                int l_ = lane;
+                asm volatile("" : "+v"(l_));
+                const int voff = ((wave * (FM * FN)) * 64 + l_) * 16;
+                if (sk_tail) {
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                        (void*)(p.sk_slabs + (long long)sk_c * (BM * BN)), 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[i][j]), rs, voff + (i * FN + j) * 1024, 0,
+                                                                   /* sc1: write-through */ 16);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave drains (and the next item's DMA prologue lands)
+                    __builtin_amdgcn_s_barrier();
+                    if (tid == 0) __hip_atomic_store(p.sk_flags + sk_c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    if (sk_need) {
+                        if (tid == 0) {                     // ONE lane polls ONE word, relaxed; then ONE agent-scope acquire
+                            int spins = 0;
+                            while (__hip_atomic_load(p.sk_flags + sk_c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                                __builtin_amdgcn_s_sleep(8);
+                                if (++spins > (1 << 24)) {  // (a neighbour that never ran: give up loudly instead of hanging the stream)
+                                    if (p.sat_flag) __hip_atomic_fetch_or(p.sat_flag, 1 << 30, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    break;
+                                }
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                            (void*)(p.sk_slabs + (long long)(sk_c + 1) * (BM * BN)), 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+                        for (int i = 0; i < FM; ++i) {
+                            u32x4_t t[FN];
+#pragma unroll
+                            for (int j = 0; j < FN; ++j) t[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (i * FN + j) * 1024, 0, 16);
+#pragma unroll
+                            for (int j = 0; j < FN; ++j) acc[i][j] += __builtin_bit_cast(f32x4, t[j]);
+                        }
+                    }
+                    gemm_epilogue<TO, BM, BN, WM, WN, true, TRAIN_EPI, false>(acc, p, g, m0c, n0c, tile_nc, wm, wn, lane, tid,
+                                                                              mean_rstd, smem + L_RED, smem + L_PAR);
+                }
+            }
             else
             gemm_epilogue<TO, BM, BN, WM, WN, true, TRAIN_EPI, XMODE == 1>(acc, p, g, m0c, n0c, tile_nc, wm, wn, lane, tid,
                                                                            mean_rstd, smem + L_RED, smem + L_PAR);
@@ -704,9 +800,26 @@ int gemm8_persistent_cus() {
     return (per_xcd < 1 ? 1 : per_xcd) * 8;
 }
 
-template <typename TI, typename TO, int AMODE, bool PERSIST, bool TRAIN_EPI, bool HALF = false, int XMODE = 0>
+// Whether a launch can run as stream-K (the SK form of gemm8_kernel), and its K-tile units per workgroup.
+bool gemm8_stream_k_eligible(const GemmArgs& a, double* units_per_wg) {
+    if (!a.sk_slabs || !a.sk_flags || a.groups > 1 || a.half_tiles || a.tt_rows > 0 || a.acc_init || a.attn_mode ||
+        (a.flags & (TP_LINEAR_NO_STORE | TP_LINEAR_SAVE_PRE | TP_LINEAR_GELU_BWD)) || a.N % G8_BN != 0 || a.m_begin != 0 || a.m_end != 0)
+        return false;
+    const int nwg = gemm8_persistent_cus(), nk = a.K / BK;
+    if (nwg % 8 != 0 || nwg > kStreamKMaxWorkgroups) return false;
+    const long long ntiles = (long long)((a.M + G8_BM - 1) / G8_BM) * (a.N / G8_BN);
+    if (ntiles <= nwg || ntiles * nk >= (1ll << 30)) return false;
+    const double u = (double)ntiles * nk / nwg;
+    // A tile is shared by at most TWO workgroups iff no range lies strictly inside a tile, i.e. every range is at least nk
+    // long: raw lengths are floor(u) or ceil(u), and snapping moves each cut by at most SK_MINSEG - 1.
+    if ((long long)u < nk + 2 * (SK_MINSEG - 1) || nk < 2 * SK_MINSEG) return false;
+    if (units_per_wg) *units_per_wg = u;
+    return true;
+}
+
+template <typename TI, typename TO, int AMODE, bool PERSIST, bool TRAIN_EPI, bool HALF = false, int XMODE = 0, bool SK = false>
 static int launch8_cfg(const GemmArgs& a, hipStream_t stream) {
-    auto kern = gemm8_kernel<TI, TO, AMODE, PERSIST, TRAIN_EPI, HALF, XMODE>;
+    auto kern = gemm8_kernel<TI, TO, AMODE, PERSIST, TRAIN_EPI, HALF, XMODE, SK>;
     constexpr int lds = g8_lds_bytes(HALF, PERSIST, XMODE);
     static_assert(lds <= 160 * 1024, "LDS budget of a CU");
     constexpr int TBM = HALF ? G8_BM / 2 : G8_BM;
@@ -728,6 +841,10 @@ static int launch8_cfg(const GemmArgs& a, hipStream_t stream) {
         const int cap = gemm8_persistent_cus();
         if (nwg > cap && cap > 0) nwg = cap;
     }
+    if constexpr (SK) {
+        if (!gemm8_stream_k_eligible(a, nullptr)) { set_error("tp gemm8: launch is not eligible for stream-K"); return TP_ERR_INVALID_ARG; }
+        nwg = gemm8_persistent_cus();
+    }
     dim3 grid((unsigned)nwg, (unsigned)a.groups, 1);
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, a, tiles_m, tiles_n, tuning(TP_TUNE_XCD_SWIZZLE));
     return check_launch("gemm8_kernel");
@@ -746,8 +863,10 @@ static int launch8_var(const GemmArgs& a, hipStream_t stream) {
     const bool strided_a = a.rows_per_batch < a.M || a.a_region_s > 0;     // (region-major rows: the strided-A kernels)
     if (a.A_parts[0]) {                                // K split over four sources: the forward's first layer only
         if (a.half_tiles) { set_error("tp gemm8: half tiles do not take a multi-part A operand"); return TP_ERR_INVALID_ARG; }
-        if constexpr (std::is_same<TO, f16_t>::value && PERSIST)
+        if constexpr (std::is_same<TO, f16_t>::value && PERSIST) {
+            if (a.stream_k == 2 && !train_epi) return launch8_cfg<TI, TO, 2, PERSIST, false, false, 0, true>(a, stream);
             return train_epi ? launch8_cfg<TI, TO, 2, PERSIST, true>(a, stream) : launch8_cfg<TI, TO, 2, PERSIST, false>(a, stream);
+        }
         set_error("tp gemm8: a multi-part A operand is supported for fp16 output on the persistent kernel only");
         return TP_ERR_INVALID_ARG;
     }
@@ -786,6 +905,9 @@ static int launch8_var(const GemmArgs& a, hipStream_t stream) {
     if constexpr (PERSIST) {
         if (half) return strided_a ? launch8_cfg<TI, TO, 1, PERSIST, false, true>(a, stream)
                                                 : launch8_cfg<TI, TO, 0, PERSIST, false, true>(a, stream);
+        if (a.stream_k == 2)                            // gemm_launch's decision (gemm8_stream_k_eligible + its cost model)
+            return strided_a ? launch8_cfg<TI, TO, 1, PERSIST, false, false, 0, true>(a, stream)
+                             : launch8_cfg<TI, TO, 0, PERSIST, false, false, 0, true>(a, stream);
     }
     return strided_a ? launch8_cfg<TI, TO, 1, PERSIST, false>(a, stream)
                                   : launch8_cfg<TI, TO, 0, PERSIST, false>(a, stream);

@@ -101,6 +101,10 @@ struct GemmArgs {
     // (a device int32 the caller zeroed at some point), a wave that clamped anything ORs sat_bit into it.  One v_max3 per
     // two output elements and, for a tile that did saturate, one atomic — nothing otherwise.
     int* sat_flag; int sat_bit;
+    // Stream-K (tp_gemm8.hip SK): the launch's K-tiles are shared evenly by the persistent workgroups; a tile cut in two hands
+    // its tail partial over through sk_slabs [workgroups][256 x 256] fp32 and sk_flags [workgroups] (zeroed ints).
+    // stream_k: 0 = gemm_launch decides (cost model, TP_TUNE_STREAM_K), 1 = never for this launch.
+    float* sk_slabs; int* sk_flags; int stream_k;
 };
 int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream);
 bool gemm_uses_small_kernel(const GemmArgs& a);        // whether gemm_launch would run `a` on the 128-tile kernel (tp_gemm.hip)
@@ -132,6 +136,11 @@ int gemm_pick_tile(int M, int N, int forced, int groups = 1);     // -> 128 or 2
 // 256x256x64 ping-pong kernel (tp_gemm8.hip); gemm_launch routes tile-256 problems to it
 int gemm8_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream);
 int gemm8_persistent_cus();                            // workgroups of a persistent launch (CUs rounded down to 8)
+constexpr int kStreamKMaxWorkgroups = 256;             // slabs / flags of the stream-K hand-over are sized for this many workgroups
+constexpr size_t kStreamKSlabBytes = (size_t)kStreamKMaxWorkgroups * 256 * 256 * 4;     // 64 MiB
+bool gemm8_stream_k_eligible(const GemmArgs& a, double* units_per_wg);
+constexpr int kMaxLaunches = 16;                       // GEMM launches of one forward that get queue heads / stream-K flags
+constexpr size_t kCounterBytes = (size_t)kMaxLaunches * (64 + kStreamKMaxWorkgroups) * 4;
 inline int gemm_stats_parts(int N) { return N / 128; }   // one (sum, sumsq) slab per 128 output columns
 
 // ---- small kernels (tp_kernels.hip) -----------------------------------------------------------
@@ -216,7 +225,8 @@ struct WorkspaceLayout {
     size_t status;                // 256 B at offset 0: int32[0] = sticky fp16-saturation bits (bit k: stage k - 1 of tp_forward_staged, bit 0: query side)
     size_t q0, hkv, h2, stats_kv, mr_kv, kv, q1pre, stats_q, mr_q, q, o, a1, a2;
     size_t attn_aux;              // logits [8][B*N] fp32 (attention in the in-projection epilogues) | (e/a, a) [8][B*M][2] (absorbed, RAW)
-    size_t counters;              // zeroed once per forward: tile-queue heads of the persistent GEMM launches
+    size_t counters;              // zeroed once per forward: tile-queue heads of the persistent GEMM launches + stream-K flags
+    size_t sk_slabs;              // stream-K partial accumulators, kStreamKSlabBytes
     size_t splitk;                // small batches: fp32 partial results of a K-split GEMM (TP_TUNE_SPLIT_K), kSplitKBytes
     size_t z1, z2;                // training forward only: fp16 pre-GELU activations [B*N, 2048], [B*M, D]
     size_t total;
