@@ -431,12 +431,11 @@ enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all hal
                                      auto by the number of workgroups of the launch | 4 | 8 */
        TP_TUNE_STREAM_K = 13,     /* stream-K decomposition of a persistent GEMM launch whose tile count is not a multiple of the CU
                                      count (tp_gemm8.hip SK): the launch's K-tiles are shared evenly, a tile cut in two hands one fp32
-                                     partial over between neighbouring workgroups.  0 (default) auto by a cost model — at the shipped
-                                     shapes the first K/V layer and mlp[2] of batches of ~15 .. 200 images, e.g. the 32-image shard of
-                                     an 8-GPU batch: 2.25 / 1.125 tiles per CU cost that, not 3 / 1.5 | 1 never | 2 whenever eligible.
-                                     Deterministic for a given batch size, but a split tile's summation order is not the unsplit
-                                     kernels': with 0 / 2 an image's low bits depend on the batch it travels in (1 keeps them
-                                     independent of it, as rounds 1-2 shipped) */
+                                     partial over between neighbouring workgroups (write-through slab + flag, fixed summation order).
+                                     0 / 1 (default) off | 2 on for every eligible launch.  OPT-IN: correct and deterministic, but
+                                     measured SLOWER than full rounds + a half-tile tail at every batch (B = 32: +22 % per forward) —
+                                     de-phased K ranges lose the L2 sharing of operands between a tile row's workgroups
+                                     (profiles/r03_stream_k_ab.txt).  With 2 an image's low bits depend on the batch it travels in. */
        TP_TUNE_COUNT_ = 16 };
 int tp_set_tuning(int key, int value);
 int tp_get_tuning(int key);                  /* the library's current value (not a binding's shadow copy); -1: bad key */

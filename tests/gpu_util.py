@@ -121,22 +121,8 @@ def training_schedule_for_inference():
     two bit-identical."""
     _capi.set_tuning(_capi.TP_TUNE_ABSORB_KV, 1)
     _capi.set_tuning(_capi.TP_TUNE_FUSE_KV_LN, 0)
-    _capi.set_tuning(_capi.TP_TUNE_STREAM_K, 1)        # the training forward never runs stream-K
     try:
         yield
     finally:
         _capi.set_tuning(_capi.TP_TUNE_ABSORB_KV, 0)
         _capi.set_tuning(_capi.TP_TUNE_FUSE_KV_LN, 1)
-        _capi.set_tuning(_capi.TP_TUNE_STREAM_K, 0)
-
-
-@contextlib.contextmanager
-def batch_invariant():
-    """TP_TUNE_STREAM_K = 1: no launch is decomposed stream-K, so a row's bits depend on nothing but the row — not on the
-    batch it travels in, nor on the order of the rows (the default trades that for the idle last round of a launch whose
-    tile count is not a multiple of the CU count; results stay deterministic for a given batch size either way)."""
-    _capi.set_tuning(_capi.TP_TUNE_STREAM_K, 1)
-    try:
-        yield
-    finally:
-        _capi.set_tuning(_capi.TP_TUNE_STREAM_K, 0)

@@ -24,21 +24,6 @@ GATE = {(torch.float16, False): 1e-3, (torch.float16, True): 1e-3,
         (torch.bfloat16, True): 1e-3, (torch.bfloat16, False): 2.0 ** -8}
 
 
-# Tests that compare BITS across row orders, tile shapes or batch sizes run with stream-K off (TP_TUNE_STREAM_K = 1): the
-# default decomposes a launch whose tile count is not a multiple of the CU count, and a tile cut in two sums in another order.
-_BIT_COMPARISONS = {"test_attention_in_the_inprojection_epilogues_is_the_same_function"}
-
-
-@pytest.fixture(autouse=True)
-def _stream_k_off_for_bit_comparisons(request):
-    from tests.gpu_util import batch_invariant
-    if getattr(request.node, "originalname", request.node.name) in _BIT_COMPARISONS:
-        with batch_invariant():
-            yield
-    else:
-        yield
-
-
 def _module(params, s, D, dtype):
     cfg = type("Cfg", (), {"hidden_size": D, "scale_factor": s})()
     m = build_vision_projector(cfg)
@@ -519,8 +504,7 @@ def test_batch_invariance_across_tile_shapes_and_kernels(s):
     xb = torch.randn(Bmax, 577, 1024, generator=g, device="cuda").to(dtype)
     xmb = torch.randn(Bmax, 577, 4096, generator=g, device="cuda").to(dtype)
     x, xm = xb[:, 1:], xmb[:, 1:]                                   # tower layout
-    from tests.gpu_util import batch_invariant
-    with torch.no_grad(), batch_invariant():                        # (the stream-K default gives this property up: TP_TUNE_STREAM_K)
+    with torch.no_grad():
         alone = {k: m((x[k:k + 1], xm[k:k + 1])) for k in (0, 2, 16, 32, 35, 46, 63, 99)}
         for B in (3, 17, 33, 36, 47, 64, 100):
             y = m((x[:B], xm[:B]))

@@ -1,6 +1,6 @@
-"""Stream-K decomposition of the persistent 256-tile GEMM (tp_gemm8.hip SK, TP_TUNE_STREAM_K): a launch whose tile count
-is not a multiple of the CU count shares its K-tiles evenly; a tile cut in two hands one fp32 partial over between
-neighbouring workgroups.  Checked: against a torch fp32 reference of the same op and against the unsplit kernel (same
+"""Stream-K decomposition of the persistent 256-tile GEMM (tp_gemm8.hip SK; OPT-IN, TP_TUNE_STREAM_K = 2 — measured slower
+than the default tail policy, profiles/r03_stream_k_ab.txt): a launch whose tile count is not a multiple of the CU count
+shares its K-tiles evenly; a tile cut in two hands one fp32 partial over between neighbouring workgroups.  Checked: against a torch fp32 reference of the same op and against the unsplit kernel (same
 value up to the summation order of the fp32 accumulation), determinism under uneven load (another stream holding CUs,
 repeated launches: every word identical — the hand-over must never read a stale slab), the whole path at the 8-GPU
 shard's batch against the oracle, and the shapes that must NOT take the route."""
@@ -57,7 +57,8 @@ def test_stream_k_matches_reference_and_unsplit_kernel(M, N, K, dtype, out_dtype
     frac = (y_sk != y_plain).float().mean().item()
     print(f"\n[stream-K] {M}x{N}x{K} {out_dtype}: max diff vs unsplit {d:.2e} of max|ref|, {100 * frac:.3f} % of elements differ")
     assert d <= {torch.float32: 2e-6, torch.float16: 1.1e-3, torch.bfloat16: 8.5e-3}[out_dtype]
-    assert 0 < frac < 0.2, "stream-K must have run (some split tile rounds differently) and only the split tiles may differ"
+    # (fp32 output shows every re-ordered sum; a 16-bit output only where the rounding flips)
+    assert 0 < frac < (0.9 if out_dtype == torch.float32 else 0.2), "stream-K must have run, and only the cut tiles may differ"
 
 
 def test_stream_k_is_deterministic_under_uneven_load():
@@ -94,15 +95,15 @@ def test_stream_k_is_deterministic_under_uneven_load():
                                    (147456, 2048, 4096),    # B = 256: 18 tiles per CU exactly — nothing to gain
                                    (2304, 2048, 4096)])     # fewer tiles than CUs
 def test_shapes_that_do_not_take_the_route_are_untouched(M, N, K):
-    """Forced on (TP_TUNE_STREAM_K = 2) or decided by the cost model, an ineligible or exactly divisible launch runs the
-    unsplit kernels: bit-identical to stream-K off."""
+    """Off (the default) nothing is decomposed, whatever scratch the caller passes; forced on (TP_TUNE_STREAM_K = 2), an
+    ineligible launch runs the unsplit kernels: bit-identical to stream-K off."""
     g = torch.Generator(device="cuda").manual_seed(M)
     A = (torch.randn(min(M, 20000), K, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
     if M > A.shape[0]:
         A = A.repeat((M + A.shape[0] - 1) // A.shape[0], 1)[:M].contiguous()
     W = (torch.randn(N, K, generator=g, device="cuda") * 0.05).to(torch.bfloat16)
     ws = _skws()
-    _capi.set_tuning(_capi.TP_TUNE_STREAM_K, 0)                 # the cost model
+    _capi.set_tuning(_capi.TP_TUNE_STREAM_K, 0)                 # the default
     y_auto = gu.linear(A, W, out_dtype=torch.float16, sk_workspace=ws)
     y_off = _run(A, W, None, 0, torch.float16, False, ws)
     assert torch.equal(y_auto, y_off)
@@ -112,8 +113,8 @@ def test_shapes_that_do_not_take_the_route_are_untouched(M, N, K):
 
 @pytest.mark.parametrize("s,B", [(2, 32), (2, 36), (3, 32), (2, 100)])
 def test_whole_path_with_stream_k_against_the_oracle(s, B):
-    """The 8-GPU shard (B = 32), the HD shard (36 crops) and a mid-size batch, D = 4096, default tuning (stream-K by the
-    cost model): parity against the fp64 oracle at the shipped gate, run-to-run determinism, and what turning it off changes."""
+    """The 8-GPU shard (B = 32), the HD shard (36 crops) and a mid-size batch, D = 4096, stream-K on for every eligible launch:
+    parity against the fp64 oracle at the shipped gate, run-to-run determinism, and what the default (off) gives."""
     dtype, D = torch.bfloat16, 4096
     params = synth.make_params(400 + s, D)
     x, xm = synth.make_inputs(401 + B, B, dtype)
@@ -123,10 +124,13 @@ def test_whole_path_with_stream_k_against_the_oracle(s, B):
     m.output_fp32 = True
     xg, xmg = x.cuda(), xm.cuda()
     with torch.no_grad():
-        y = m((xg, xmg))
-        y_again = m((xg, xmg))
-        with gu.batch_invariant():
-            y_off = m((xg, xmg))
+        y_off = m((xg, xmg))
+        _capi.set_tuning(_capi.TP_TUNE_STREAM_K, 2)
+        try:
+            y = m((xg, xmg))
+            y_again = m((xg, xmg))
+        finally:
+            _capi.set_tuning(_capi.TP_TUNE_STREAM_K, 0)
     torch.cuda.synchronize()
     assert torch.equal(y, y_again)
     p_lp = {k: v.to(dtype) for k, v in params.items()}
@@ -137,4 +141,4 @@ def test_whole_path_with_stream_k_against_the_oracle(s, B):
     changed = (y != y_off).float().mean().item()
     print(f"\n[stream-K] whole path s={s} B={B}: rel_err {e:.3e} (off: {e_off:.3e}), {100 * changed:.2f} % of output elements differ from stream-K off")
     assert e <= (1.0e-3 if s == 2 else 1.1e-3) and e_off <= (1.0e-3 if s == 2 else 1.1e-3)
-    assert changed > 0, "the cost model was expected to pick stream-K for some launch of this batch"
+    assert changed > 0, "some launch of this batch was expected to be eligible for stream-K"

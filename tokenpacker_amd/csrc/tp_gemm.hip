@@ -278,21 +278,17 @@ static int launch_types(const GemmArgs& a, hipStream_t stream) {
 // with a half tile at 0.75 of a full tile's time (0.63 at K <= 1024; a one-round tail also pays its first tile's
 // un-hidden DMA latency) and a second launch at ~8 us (dependent-launch gap) relative to a full tile's
 // 8.4 + 1.47 K/64 us (profiles/README.md).  Same epilogue, bit-identical results whatever the shape.
-// (d) stream-K (tp_gemm8.hip SK, TP_TUNE_STREAM_K): the launch's K-tiles shared evenly by the workgroups — U K-tiles each at the
-//   main loop's 1.47 us, one epilogue per tile started, and ~14 us for the one partial a workgroup hands over and the one it
-//   takes in (256 KiB each way).  It wins where the tile count is a non-integer multiple of the CU count and K is long:
-//   the first K/V layer and mlp[2] of a 32-image shard (2.25 and 1.125 tiles per CU).
+// (d) stream-K (tp_gemm8.hip SK, TP_TUNE_STREAM_K = 2, opt-in): the launch's K-tiles shared evenly by the workgroups; measured
+//   slower than (b) at every batch (stream_k_pays below).
 enum { ROUTE_SMALL = 0, ROUTE_G8 = 1, ROUTE_G8_HALF = 2, ROUTE_G8_SPLIT = 3, ROUTE_G8_SK = 4 };
-// `best_other`: the cheapest alternative in units of a full tile's time
-static bool stream_k_pays(const GemmArgs& a, double best_other) {
+// Opt-in only (TP_TUNE_STREAM_K = 2).  The cost model this started with — U K-tiles at the main loop's 1.47 us + one epilogue per
+// tile started + ~14 us for the partial handed over and the one taken in, against the round count of the alternatives —
+// predicted -8 % on the first K/V layer of a 32-image shard; MEASURED: +39 % (0.265 -> 0.369 ms), +25 % per forward at B = 100
+// (profiles/r03_stream_k_ab.txt): contiguous K-tile ranges put the workgroups that share an A row-panel / a W column-slice at
+// DIFFERENT K positions, the XCD's L2 stops serving 3 of 4 / 7 of 8 operand fetches and the launch becomes fabric-bound.
+static bool stream_k_pays(const GemmArgs& a, double /*best_other*/) {
     double u = 0;
-    const int skmode = tuning(TP_TUNE_STREAM_K);
-    if (skmode == 1 || a.stream_k == 1 || !gemm8_stream_k_eligible(a, &u)) return false;
-    if (skmode == 2) return true;
-    const long long per = gemm8_persistent_cus(), T = (long long)((a.M + 255) / 256) * (a.N / 256);
-    const double t_tile = 8.4 + 1.47 * (a.K / BK);
-    const double cost_d = (u * 1.47 + (double)(T / per + 1) * 8.4 + 14.0) / t_tile;
-    return cost_d < best_other - 0.05;
+    return tuning(TP_TUNE_STREAM_K) == 2 && a.stream_k != 1 && gemm8_stream_k_eligible(a, &u);
 }
 static int gemm_route(const GemmArgs& a, long long* head_rows_out) {
     const bool free_choice = a.tile == 0 && tuning(TP_TUNE_GEMM_TILE) == 0 && tuning(TP_TUNE_GEMM_KERNEL) == 0 &&
