@@ -27,9 +27,15 @@ struct BwLayout {
     size_t wt_m2, wt_m0, wt_out, wt_in, wt_2;        // wt_in: [3][E,E] (q,k,v);  wt_2: [2][E,E] (k,v)
     size_t ln_g, ln_b;                                // [3][E] fp32 each (q,k,v)
     // coarse-token side
-    size_t dyT, a2T, dz2, dz2T, a1T, da1, oT, dO, dQ, q1T, dq1, dQ1pre, q0T;
+    size_t dz2, da1, dO, dQ, dq1, dQ1pre;
     // fine-token side ([2] = k, v)
-    size_t dKV, kv1T, dkv1, dH2, hkvT, dZ1, dZ1T, xmT;
+    size_t dKV, dkv1, dH2, dZ1;
+    // ONE transposed-operand scratch: every weight gradient whose activation operand must be rewritten (fp16 activation of a
+    // bf16 model cast, LayerNorm input normalised) transposes it here and consumes it in the next launch — never two at once
+    size_t xt;
+    // fallback paths only (hidden_size not a multiple of 256 / a grid whose images are not whole 64-row K-tiles): transposed
+    // copies of dy, dZ2, dZ1 and x_multi; kNoSlab when the in-place (K-major operand) paths serve the shape
+    size_t dyT, dz2T, dZ1T, xmT;
     size_t counters;                                  // tile-queue heads of the persistent GEMM launches (zeroed once)
     size_t part, colpart, lnpart;                     // fp32 partials: split-K wgrad, column sums, LN affine grads
     size_t redscratch;                                // stage-1 output of the many-parts reduction
@@ -37,6 +43,10 @@ struct BwLayout {
     size_t total;
     int Rp, Rqp;
 };
+
+// Whether the first-layer weight gradient reads x_multi in place (wgrad_tt_supported's shape conditions; strides are
+// multiples of 8 by tp_forward's own argument check): images must be whole 64-row K-tiles.
+static bool xm_inplace(int grid) { const int N = grid * grid; return N % 64 == 0 && N >= 128; }
 
 static BwLayout bw_layout(int B, int grid, int s, int D) {
     BwLayout L{};
@@ -46,16 +56,23 @@ static BwLayout bw_layout(int B, int grid, int s, int D) {
     const size_t Rp = L.Rp, Rqp = L.Rqp;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = up(off + bytes); return o; };
+    auto take_if = [&](bool need, size_t bytes) { return need ? take(bytes) : kNoSlab; };
     L.wt_m2 = take((size_t)D * D * 2); L.wt_m0 = take(E * D * 2); L.wt_out = take(E * E * 2);
     L.wt_in = take(3 * E * E * 2); L.wt_2 = take(2 * E * E * 2);
     L.ln_g = take(3 * E * 4); L.ln_b = take(3 * E * 4);
-    L.dyT = take(D * Rqp * 2); L.a2T = take(D * Rqp * 2); L.dz2 = take(Rq * D * 2); L.dz2T = take(D * Rqp * 2);
-    L.a1T = take(E * Rqp * 2); L.da1 = take(Rq * E * 2); L.oT = take(E * Rqp * 2);
-    L.dO = take(Rq * E * 2); L.dQ = take(Rq * E * 2); L.q1T = take(E * Rqp * 2);
-    L.dq1 = take(Rq * E * 2); L.dQ1pre = take(Rq * E * 2); L.q0T = take(E * Rqp * 2);
-    L.dKV = take(2 * R * E * 2); L.kv1T = take(2 * E * Rp * 2); L.dkv1 = take(2 * R * E * 2);
-    L.dH2 = take(2 * R * E * 2); L.hkvT = take(2 * E * Rp * 2);
-    L.dZ1 = take(R * 2 * E * 2); L.dZ1T = take(2 * E * Rp * 2); L.xmT = take((size_t)kMulti * Rp * 2);
+    L.dz2 = take(Rq * D * 2); L.da1 = take(Rq * E * 2);
+    L.dO = take(Rq * E * 2); L.dQ = take(Rq * E * 2);
+    L.dq1 = take(Rq * E * 2); L.dQ1pre = take(Rq * E * 2);
+    L.dKV = take(2 * R * E * 2); L.dkv1 = take(2 * R * E * 2);
+    L.dH2 = take(2 * R * E * 2);
+    L.dZ1 = take(R * 2 * E * 2);
+    {
+        const size_t a = (size_t)D * Rqp * 2, b = E * Rp * 2;        // the largest operands: A2^T [D, Rq], H2^T / Hkv^T [E, R]
+        L.xt = take(a > b ? a : b);
+    }
+    const bool inplace_d = D % 256 == 0, inplace_xm = xm_inplace(grid);
+    L.dyT = take_if(!inplace_d, D * Rqp * 2); L.dz2T = take_if(!inplace_d, D * Rqp * 2);
+    L.dZ1T = take_if(!inplace_xm, 2 * E * Rp * 2); L.xmT = take_if(!inplace_xm, (size_t)kMulti * Rp * 2);
     // split-K partials: S splits of an [Nout, Kin] weight with S * tiles(256^2) <= ~512
     size_t wmax = (size_t)D * D;
     if ((size_t)2 * E * kMulti > wmax) wmax = (size_t)2 * E * kMulti;
@@ -326,28 +343,28 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
     // ---- mlp[2] ---------------------------------------------------------------------------------------------
     if (inplace) {
         TP_TRY(bias_grad_rows(dy, D, Rq, D, grads->mlp_2_bias));
-        TP_TRY(wgrad_rows(dy, D, Rq, Rqp, D, D, fw + W.a2, D, TP_F16, bw + L.a2T, grads->mlp_2_weight));
+        TP_TRY(wgrad_rows(dy, D, Rq, Rqp, D, D, fw + W.a2, D, TP_F16, bw + L.xt, grads->mlp_2_weight));
     } else {
         TP_TRY(T(GT, dy, D, Rq, D, bw + L.dyT, Rqp, nullptr, nullptr, nullptr, colpart));
         TP_TRY(bias_grad(Rqp, D, grads->mlp_2_bias));
-        TP_TRY(T(TP_F16, fw + W.a2, D, Rq, D, bw + L.a2T, Rqp));
-        TP_TRY(wgrad(bw + L.dyT, bw + L.a2T, D, D, Rqp, grads->mlp_2_weight));
+        TP_TRY(T(TP_F16, fw + W.a2, D, Rq, D, bw + L.xt, Rqp));
+        TP_TRY(wgrad(bw + L.dyT, bw + L.xt, D, D, Rqp, grads->mlp_2_weight));
     }
     TP_TRY(dgrad(dy, D, Rq, D, bw + L.wt_m2, D, bw + L.dz2, D, TP_LINEAR_GELU_BWD, fw + W.z2, D));
     // ---- mlp[0] ---------------------------------------------------------------------------------------------
     if (inplace) {
         TP_TRY(bias_grad_rows(bw + L.dz2, D, Rq, D, grads->mlp_0_bias));
-        TP_TRY(wgrad_rows(bw + L.dz2, D, Rq, Rqp, D, E, fw + W.a1, E, TP_F16, bw + L.a1T, grads->mlp_0_weight));
+        TP_TRY(wgrad_rows(bw + L.dz2, D, Rq, Rqp, D, E, fw + W.a1, E, TP_F16, bw + L.xt, grads->mlp_0_weight));
     } else {
         TP_TRY(T(GT, bw + L.dz2, D, Rq, D, bw + L.dz2T, Rqp, nullptr, nullptr, nullptr, colpart));
         TP_TRY(bias_grad(Rqp, D, grads->mlp_0_bias));
-        TP_TRY(T(TP_F16, fw + W.a1, E, Rq, E, bw + L.a1T, Rqp));
-        TP_TRY(wgrad(bw + L.dz2T, bw + L.a1T, D, E, Rqp, grads->mlp_0_weight));
+        TP_TRY(T(TP_F16, fw + W.a1, E, Rq, E, bw + L.xt, Rqp));
+        TP_TRY(wgrad(bw + L.dz2T, bw + L.xt, D, E, Rqp, grads->mlp_0_weight));
     }
     TP_TRY(dgrad(bw + L.dz2, D, Rq, D, bw + L.wt_m0, E, bw + L.da1, E));
     // ---- out_proj ---------------------------------------------------------------------------------------------
     TP_TRY(bias_grad_rows(bw + L.da1, E, Rq, E, grads->clip_attn_out_proj_bias));
-    TP_TRY(wgrad_rows(bw + L.da1, E, Rq, Rqp, E, E, fw + W.o, E, TP_F16, bw + L.oT, grads->clip_attn_out_proj_weight));
+    TP_TRY(wgrad_rows(bw + L.da1, E, Rq, Rqp, E, E, fw + W.o, E, TP_F16, bw + L.xt, grads->clip_attn_out_proj_weight));
     TP_TRY(dgrad(bw + L.da1, E, Rq, E, bw + L.wt_out, E, bw + L.dO, E));
     // ---- region attention ---------------------------------------------------------------------------------------
     TP_TRY(bw_region_attention_launch(GT, fw + W.q, fw + W.kv, fw + W.kv + kvE * 2, bw + L.dO, bw + L.dQ, bw + L.dKV,
@@ -357,12 +374,12 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
     char* g_inb = (char*)grads->clip_attn_in_proj_bias;
     //   q
     TP_TRY(bias_grad_rows(bw + L.dQ, E, Rq, E, g_inb));
-    TP_TRY(wgrad_rows(bw + L.dQ, E, Rq, Rqp, E, E, fw + W.q1pre, E, TP_F16, bw + L.q1T, g_inw, (const float*)(fw + W.mr_q), ln_g, ln_b));
+    TP_TRY(wgrad_rows(bw + L.dQ, E, Rq, Rqp, E, E, fw + W.q1pre, E, TP_F16, bw + L.xt, g_inw, (const float*)(fw + W.mr_q), ln_g, ln_b));
     TP_TRY(dgrad(bw + L.dQ, E, Rq, E, bw + L.wt_in, E, bw + L.dq1, E));
     //   k, v
     for (int t = 0; t < 2; ++t) {
         const char* dX = bw + L.dKV + (size_t)t * kvE * 2;
-        char* x1T = bw + L.kv1T + (size_t)t * E * Rp * 2;
+        char* x1T = bw + L.xt;
         const float* mr = (const float*)(fw + W.mr_kv) + (size_t)t * R * 2;
         TP_TRY(bias_grad_rows(dX, E, R, E, g_inb + (size_t)(1 + t) * E * 2));
         TP_TRY(wgrad_rows(dX, E, R, Rp, E, E, fw + W.h2 + (size_t)t * kvE * 2, E, TP_F16, x1T, g_inw + (size_t)(1 + t) * E * E * 2,
@@ -387,14 +404,14 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
         }
     }
     // ---- q_proj_1 (no bias) ---------------------------------------------------------------------------------------
-    TP_TRY(wgrad_rows(bw + L.dQ1pre, E, Rq, Rqp, E, E, fw + W.q0, E, TP_F16, bw + L.q0T, grads->q_proj_1_weight));
+    TP_TRY(wgrad_rows(bw + L.dQ1pre, E, Rq, Rqp, E, E, fw + W.q0, E, TP_F16, bw + L.xt, grads->q_proj_1_weight));
     // ---- k/v_proj_1[2] -----------------------------------------------------------------------------------------------
     {
         void* gw[2] = {grads->k_proj_1_2_weight, grads->v_proj_1_2_weight};
         void* gb[2] = {grads->k_proj_1_2_bias, grads->v_proj_1_2_bias};
         for (int t = 0; t < 2; ++t) {
             const char* dH = bw + L.dH2 + (size_t)t * kvE * 2;
-            char* hT = bw + L.hkvT + (size_t)t * E * Rp * 2;
+            char* hT = bw + L.xt;
             TP_TRY(bias_grad_rows(dH, E, R, E, gb[t]));
             TP_TRY(wgrad_rows(dH, E, R, Rp, E, E, fw + W.hkv + (size_t)t * E * 2, 2 * E, TP_F16, hT, gw[t]));
             TP_TRY(dgrad(dH, E, R, E, bw + L.wt_2 + (size_t)t * E * E * 2, E, bw + L.dZ1 + (size_t)t * E * 2, 2 * E,
@@ -405,7 +422,12 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
     // dW0 [2E, 4096] = dZ1^T · x_multi (rows 0..E-1: k_proj_1[0], E..2E-1: v_proj_1[0]).  Both operands are in the model
     // dtype and row-major, so the contraction reads them in place (K-major GEMM operands): no dZ1^T, no x_multi^T.
     const WgradX XM{x_multi, xm_strides[1], N, xm_strides[0], xm_parts, kMulti / 4};
-    if (wgrad_tt_supported(R, 2 * E, kMulti, XM, 2 * E)) {
+    const bool xm_tt = wgrad_tt_supported(R, 2 * E, kMulti, XM, 2 * E);
+    if (!xm_tt && L.xmT == kNoSlab) {                   // (cannot happen for arguments tp_forward_train accepted)
+        set_error("tp_backward: x_multi strides rule out the in-place weight gradient this workspace was sized for");
+        return TP_ERR_INVALID_ARG;
+    }
+    if (xm_tt) {
         const int slices = bw_colsum_rows_launch(GT, bw + L.dZ1, 2 * E, R, 2 * E, colpart, stream);
         if (slices < 0) return slices;
         TP_TRY(bw_reduce_many_parts_launch(GT, colpart, 2 * E, slices, E, grads->k_proj_1_0_bias, redscratch, stream));
