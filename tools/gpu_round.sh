@@ -50,13 +50,13 @@ if has bench; then
 fi
 if has sweep; then
   echo "== sweep (scale_factor 3, 4; HD 36 crops/GPU; fp16) =="
-  for sf in 3 4; do timeout 300 python bench.py --scale-factor $sf --no-cpu-baseline > $OUT/bench_s$sf.json 2>> $OUT/bench.err; cat $OUT/bench_s$sf.json; done
-  timeout 300 python bench.py --batch 36 --no-cpu-baseline > $OUT/bench_hd36.json 2>> $OUT/bench.err; cat $OUT/bench_hd36.json
-  timeout 300 python bench.py --dtype fp16 --no-cpu-baseline > $OUT/bench_fp16.json 2>> $OUT/bench.err; cat $OUT/bench_fp16.json
+  for sf in 3 4; do timeout 300 python bench.py --scale-factor $sf --no-cpu-baseline --no-extras > $OUT/bench_s$sf.json 2>> $OUT/bench.err; cat $OUT/bench_s$sf.json; done
+  timeout 300 python bench.py --batch 36 --no-cpu-baseline --no-extras > $OUT/bench_hd36.json 2>> $OUT/bench.err; cat $OUT/bench_hd36.json
+  timeout 300 python bench.py --dtype fp16 --no-cpu-baseline --no-extras > $OUT/bench_fp16.json 2>> $OUT/bench.err; cat $OUT/bench_fp16.json
 fi
 if has small; then
   echo "== small batches (strong-scaling shards: 256/8 = 32 images, B = 1, 8, 64, 128) and the HD workload on one GPU =="
-  for b in 1 8 32 64 128; do timeout 300 python bench.py --batch $b --no-cpu-baseline > $OUT/bench_b$b.json 2>> $OUT/bench.err; python - "$OUT/bench_b$b.json" <<'PY'
+  for b in 1 8 10 32 64 128; do timeout 300 python bench.py --batch $b --no-cpu-baseline --no-extras --steps 100 --warmup 20 > $OUT/bench_b$b.json 2>> $OUT/bench.err; python - "$OUT/bench_b$b.json" <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1])); print("B=%d: %.1f img/s  %.4f ms/step  whole-path %.0f TFLOP/s" % (d["config"]["global_batch"], d["value"], d["ms_per_step"], d["whole_path"]["achieved_tflops"]))
 PY
@@ -74,17 +74,17 @@ if has e2e; then
 fi
 if has prof; then
   echo "== rocprof kernel trace =="
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/rocprof -o bench -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/$OUT/rocprof_bench.log 2>&1 ); echo "rocprof exit $?"
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/rocprof -o bench -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --min-seconds 0 > $R/$OUT/rocprof_bench.log 2>&1 ); echo "rocprof exit $?"
   F=$(find $OUT/rocprof -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && head -16 "$F"
   find $OUT/rocprof -name "*kernel_trace.csv" -size +20M -delete
 fi
 if has prof3; then
   echo "== rocprof kernel trace, scale_factor 3 (absorbed K/V schedule) =="
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/rocprof_s3 -o bench -- python $R/bench.py --scale-factor 3 --steps 10 --warmup 3 --no-cpu-baseline > $R/$OUT/rocprof_bench_s3.log 2>&1 ); echo "rocprof exit $?"
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/rocprof_s3 -o bench -- python $R/bench.py --scale-factor 3 --steps 10 --warmup 3 --no-cpu-baseline --no-extras --min-seconds 0 > $R/$OUT/rocprof_bench_s3.log 2>&1 ); echo "rocprof exit $?"
   F=$(find $OUT/rocprof_s3 -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && head -16 "$F" | cut -c1-220
   find $OUT/rocprof_s3 -name "*kernel_trace.csv" -size +20M -delete
   for C in "FETCH_SIZE" "WRITE_SIZE"; do
-    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/pmc3_$C -o pmc -- python $R/bench.py --scale-factor 3 --steps 3 --warmup 2 --no-cpu-baseline > $R/$OUT/pmc3_$C.log 2>&1 ); echo "pmc3 $C exit $?"
+    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/pmc3_$C -o pmc -- python $R/bench.py --scale-factor 3 --steps 3 --warmup 2 --no-cpu-baseline --no-extras --min-seconds 0 > $R/$OUT/pmc3_$C.log 2>&1 ); echo "pmc3 $C exit $?"
   done
   mkdir -p $OUT/s3 && for C in FETCH_SIZE WRITE_SIZE; do mv $OUT/pmc3_$C $OUT/s3/pmc_$C; done
   python tools/pmc_summary.py $OUT/s3 > $OUT/pmc_summary_s3.json 2> $OUT/pmc_summary.err; python - "$OUT/pmc_summary_s3.json" <<'PY'
@@ -99,7 +99,7 @@ if has pmc; then
   echo "== rocprof PMC passes (own runs, kernel-trace only) =="
   for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
     N=$(echo $C | tr ' ' '_' | cut -c1-24)
-    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/pmc_$N -o pmc -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $R/$OUT/pmc_$N.log 2>&1 ); echo "pmc $N exit $?"
+    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/pmc_$N -o pmc -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras --min-seconds 0 > $R/$OUT/pmc_$N.log 2>&1 ); echo "pmc $N exit $?"
   done
   python tools/pmc_summary.py $OUT > $OUT/pmc_summary.json 2> $OUT/pmc_summary.err; cat $OUT/pmc_summary.json | head -60; tail -3 $OUT/pmc_summary.err
   python tools/make_traffic.py $OUT/pmc_summary.json $TAG && cp profiles/traffic.json $OUT/traffic.json
