@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — TokenPacker projector throughput on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N --steps K --warmup W]          # N=1
+    python bench.py [--gpus N --steps K --warmup W]          # N=1; N>1 with no launcher around it: bench.py starts its own
+                                                             # N ranks (torch.distributed.run on 127.0.0.1) and rank 0 prints
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -11,8 +12,11 @@ batch of 256 images ``[256, 576, 1024]`` + ``[256, 576, 4096]`` bf16 -> ``[256, 
 scale_factor=2, CLIP-L 336 px, bf16).  With N > 1 the batch is SHARDED (``--scaling strong``, the default: 256/N
 images per GPU, weights replicated — SURVEY.md §8e) and every step ends with the ONE all-gather of projected tokens
 the north_star prescribes, so each rank holds ``[256, 144, 4096]``; the gather of step i overlaps the forward of
-step i+1 (two rotating output buffers, all gathers drained inside the timed region).  ``--scaling weak`` keeps 256
-images per GPU instead; ``--no-gather`` drops the collective (DDP-style: the LLM consumes the local shard).
+step i+1 (rotating output buffers, all gathers drained inside the timed region).  ``--gather rccl`` (default) is
+``all_gather_into_tensor`` (RCCL kernels over xGMI); ``--gather sdma`` is ``shard.DirectGather``: the shard is written
+straight into its rows of the receive buffer and travels as one copy-engine transfer per peer + a sequence flag — no
+compute unit.  ``--scaling weak`` keeps 256 images per GPU instead; ``--no-gather`` drops the gather
+(DDP-style: the LLM consumes the local shard).
 
 Other workloads (each prints the same one-line JSON):
   --hd    BASELINE configs[3], TokenPacker-HD: 32 images x 9 crops = 288 crops sharded over the ranks (ragged when
@@ -31,6 +35,16 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
                  (stamped with the git tree of the kernel sources they were measured on; a stale file is refused).
   cpu_baseline — the reference's op sequence (nn.Linear / F.interpolate / nn.MultiheadAttention ..., fp32) on the host
                  cores, BASELINE config 1 (B=4), a bounded ~12 s sample, rank 0 at N=1 only.
+  eager_rocm_baseline — the same op sequence under PyTorch-ROCm eager on THIS GPU, same inputs / dtype / batch: the
+                 denominator of the north_star's ">= 5x" (``hip_over_eager``).  ``vs_baseline`` stays null: BASELINE.md
+                 publishes no number for the metric.  (Both baseline legs run AFTER the timed region; they are the only
+                 code that reaches into oracle/, through one import site.)
+  sweep        — N=1: scale_factor 3 and 4 at the same batch; the 8-GPU shard (B/8), B=10 and B=1 at this scale factor.
+  timing       — ``long_run``: the same step loop continued in fenced blocks until >= --min-seconds have been measured
+                 (mean / p10 / median / p90 ms per step); the K-step region stays the metric.
+  multi_gpu    — N>1: ranks and backend as torch.distributed reports them, every rank's device (index, uuid, PCI id,
+                 pid), the NCCL_* / HSA_* variables that are set, the gather mode, forward-only / gather-only times,
+                 and with --probe-other-gather the transport not selected.
   stages_ms    — per-kernel breakdown of one forward.
 """
 from __future__ import annotations

@@ -69,6 +69,7 @@ int main(int argc, char** argv) {
     void *packed, *ws, *out, *out2;
     CHECK_HIP(hipMalloc(&packed, pbytes));  CHECK_HIP(hipMalloc(&ws, wbytes));
     CHECK_HIP(hipMalloc(&out, obytes));     CHECK_HIP(hipMalloc(&out2, obytes));
+    CHECK_HIP(hipMemsetAsync(ws, 0, TP_WORKSPACE_STATUS_BYTES, stream));   /* the status block: zeroed ONCE by the caller */
     CHECK_TP(tp_pack_weights(&d, &w, packed, pbytes, stream));
     int32_t status[3] = {-1, -1, -1};
     CHECK_HIP(hipStreamSynchronize(stream));
@@ -84,7 +85,9 @@ int main(int argc, char** argv) {
     CHECK_HIP(hipStreamSynchronize(stream));
 
     uint16_t* h1 = (uint16_t*)malloc(obytes); uint16_t* h2 = (uint16_t*)malloc(obytes);
-    int32_t hs[TP_NUM_DEBUG_BUFFERS];
+    int32_t hs[TP_NUM_DEBUG_BUFFERS], sticky = -1;
+    CHECK_HIP(hipMemcpy(&sticky, ws, sizeof sticky, hipMemcpyDeviceToHost));   /* sticky fp16-saturation bits of the two forwards */
+    if (sticky != 0) { fprintf(stderr, "an epilogue clamped (stage bits 0x%x)\n", sticky); return 8; }
     CHECK_HIP(hipMemcpy(h1, out, obytes, hipMemcpyDeviceToHost));
     CHECK_HIP(hipMemcpy(h2, out2, obytes, hipMemcpyDeviceToHost));
     CHECK_HIP(hipMemcpy(hs, sat, sizeof hs, hipMemcpyDeviceToHost));
