@@ -112,9 +112,12 @@ def parse_args():
                     help="collective backend for N>1 (nccl = RCCL; gloo only to exercise the N>1 flow on one GPU)")
     ap.add_argument("--single-device", action="store_true",
                     help="test aid: every rank uses cuda:0 (with --backend gloo)")
-    ap.add_argument("--gather", default="rccl", choices=["rccl", "sdma"],
+    ap.add_argument("--gather", default="auto", choices=["auto", "rccl", "sdma"],
                     help="N>1: how the projected tokens travel — rccl: all_gather_into_tensor (RCCL kernels over xGMI) | "
-                         "sdma: shard.DirectGather, one hipMemcpyAsync per peer on the copy engines, no compute unit")
+                         "sdma: shard.DirectGather, one hipMemcpyAsync per peer on the copy engines, no compute unit | "
+                         "auto (default): a two-step self-test of the sdma transport (every rank checks every peer's rows); if it "
+                         "passes on every rank BOTH transports are timed over the K steps and the faster one is the line's value "
+                         "(both are reported), otherwise rccl alone")
     ap.add_argument("--gather-depth", type=int, default=3, help="--gather sdma: rotating receive buffers")
     ap.add_argument("--probe-other-gather", action="store_true",
                     help="N>1: after the timed region also time the transport NOT selected by --gather (multi_gpu.other_gather)")
@@ -343,15 +346,34 @@ def run_e2e(args, world, rank, device, dtype, dist):
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    with torch.no_grad():
+    def timed_region():
+        """W warm-up steps, then EXACTLY K timed steps between two fences; max over the ranks."""
         for _ in range(max(args.warmup, 1)):
-            y = step()
+            out = step()
         fence()
-        t0 = time.perf_counter()
+        t_start = time.perf_counter()
         for _ in range(args.steps):
-            y = step()
+            out = step()
         fence()
-        elapsed = time.perf_counter() - t0
+        el = torch.tensor([time.perf_counter() - t_start], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return out, float(el.item())
+
+    with torch.no_grad():
+        per_transport = {}
+        if len(transports) > 1:              # auto: the same protocol once per transport; the faster one is the job's
+            for t_name in transports:
+                cur["t"] = t_name
+                y, el = timed_region()
+                per_transport[t_name] = el
+            cur["t"] = min(per_transport, key=per_transport.get)     # (max-reduced times: every rank picks the same)
+            elapsed = per_transport[cur["t"]]
+        else:
+            y, elapsed = timed_region()
+            if transports:
+                per_transport[cur["t"]] = elapsed
+        chosen = cur["t"]
         step(timed=True)
         torch.cuda.synchronize(device)
     assert y.shape == (b, T, D) and torch.isfinite(y[:1].float()).all()
@@ -376,6 +398,42 @@ def run_e2e(args, world, rank, device, dtype, dist):
            "note": "tower and prefill are PyTorch-ROCm library code around the path (producer / consumer), timed to place the "
                    "projector inside encode_images(); only projector_hip is this repository's kernels"}
     print(json.dumps(out), flush=True)
+
+
+def sdma_self_test(total, M, D, dtype, device, depth, world, rank, dist, shard):
+    """Build the copy-engine gather and prove it on this node before anything is timed with it: two steps, every rank fills
+    its rows with a value only it would write and checks EVERY rank's rows after the gather.  The verdict is reduced over the
+    ranks (MIN), so every rank takes the same branch afterwards; waits are bounded (5 s), set-up errors are raised on every
+    rank together (shard.DirectGather).  Returns (gather object or None, reason)."""
+    try:
+        g = shard.DirectGather(total, (M, D), dtype, device, depth=depth, timeout_ms=5000)
+    except Exception as exc:             # noqa: raised on every rank alike
+        return None, repr(exc)[:300]
+    ok, err = True, None
+    try:
+        for it in range(2):
+            g.begin().fill_(float(rank + 1 + 16 * it))
+            buf = g.result(g.submit())
+            torch.cuda.synchronize(device)
+            for r in range(world):
+                lo, hi = shard.shard_bounds(total, world, r)
+                if hi > lo and not bool((buf[lo:hi] == float(r + 1 + 16 * it)).all()):
+                    ok, err = False, f"rank {rank}: rows of rank {r} wrong after step {it}"
+        if int(g.status.item()) != 0:
+            ok, err = False, f"rank {rank}: a peer's shard did not arrive within 5 s"
+    except Exception as exc:             # noqa
+        ok, err = False, f"rank {rank}: {exc!r}"[:300]
+    verdict = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+    if int(verdict.item()) == 0:
+        try:
+            g.status.zero_()
+            g.close()
+        except Exception:                # noqa
+            pass
+        return None, err or "a peer failed the self-test"
+    g.timeout_ms = 30000
+    return g, None
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -439,9 +497,21 @@ def main():
     x, xm = make_device_inputs(max(B, 1), dtype, args.layout, device, seed=1234 + rank)
     x, xm = x[:B], xm[:B]
     gather = world > 1 and not args.no_gather
-    use_sdma = gather and args.gather == "sdma" and not args.hd
-    pipe = shard.TokenGatherPipeline(total, depth=2) if (gather and not use_sdma and not args.sync_gather and not ragged and not args.hd) else None
-    dgather = shard.DirectGather(total, (M, D), dtype, device, depth=args.gather_depth) if use_sdma else None
+    # ---- the gather's transport (N > 1): rccl | sdma | auto = both, after the sdma self-test ------------------------
+    pipe = dgather = None
+    transports, sdma_note = [], None
+    if gather and not args.hd:
+        if args.gather == "sdma":
+            dgather = shard.DirectGather(total, (M, D), dtype, device, depth=args.gather_depth)
+            transports = ["sdma"]
+        elif args.gather == "auto":
+            dgather, sdma_note = sdma_self_test(total, M, D, dtype, device, args.gather_depth, world, rank, dist, shard)
+            transports = ["rccl", "sdma"] if dgather is not None else ["rccl"]
+        else:
+            transports = ["rccl"]
+        if "rccl" in transports and not args.sync_gather and not ragged:
+            pipe = shard.TokenGatherPipeline(total, depth=2)
+    cur = {"t": transports[0] if transports else None}      # the transport step() uses
     if args.hd:
         gsep = torch.Generator(device=device).manual_seed(5)
         sep = torch.randn(D, generator=gsep, device=device, dtype=torch.float32).to(dtype)
@@ -457,13 +527,13 @@ def main():
                 return hd.assemble_hd_tokens(g_tok, hb, wb, sep, ret)
             y_loc = model((x, xm))
             return hd.assemble_hd_tokens(y_loc, hb, wb, sep, ret) if world == 1 else y_loc
-        if dgather is not None:              # the shard is written straight into its rows of the receive buffer, then pushed
+        if cur["t"] == "sdma":               # the shard is written straight into its rows of the receive buffer, then pushed
             view = dgather.begin()
             if B:
                 model((x, xm), _out=view)
             ticket = dgather.submit()
             return dgather.result(ticket) if args.sync_gather else dgather.bufs[ticket[1]]
-        if pipe is not None:                 # forward of this step overlaps the gather of the previous one
+        if cur["t"] == "rccl" and pipe is not None:       # forward of this step overlaps the gather of the previous one
             slot = pipe.submit(model((x, xm)))
             return pipe._bufs[slot]
         if gather:
@@ -480,15 +550,34 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    with torch.no_grad():
+    def timed_region():
+        """W warm-up steps, then EXACTLY K timed steps between two fences; max over the ranks."""
         for _ in range(max(args.warmup, 1)):
-            y = step()
+            out = step()
         fence()
-        t0 = time.perf_counter()
+        t_start = time.perf_counter()
         for _ in range(args.steps):
-            y = step()
+            out = step()
         fence()
-        elapsed = time.perf_counter() - t0
+        el = torch.tensor([time.perf_counter() - t_start], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return out, float(el.item())
+
+    with torch.no_grad():
+        per_transport = {}
+        if len(transports) > 1:              # auto: the same protocol once per transport; the faster one is the job's
+            for t_name in transports:
+                cur["t"] = t_name
+                y, el = timed_region()
+                per_transport[t_name] = el
+            cur["t"] = min(per_transport, key=per_transport.get)     # (max-reduced times: every rank picks the same)
+            elapsed = per_transport[cur["t"]]
+        else:
+            y, elapsed = timed_region()
+            if transports:
+                per_transport[cur["t"]] = elapsed
+        chosen = cur["t"]
 
         # The K steps above are the driver's; at 4 ms per step they are < 0.1 s of clock.  Keep stepping (same loop, same
         # fences) until --min-seconds have been measured, in blocks, so that the line also carries a distribution.
@@ -563,34 +652,28 @@ def main():
                 fence()
                 return 1e3 * (time.perf_counter() - t1) / n_x
 
-            if args.hd or ragged and dgather is None:
+            if args.hd or (ragged and chosen != "sdma"):
                 fence()
                 t1 = time.perf_counter()
                 for _ in range(n_x):
                     shard.all_gather_tokens(y_loc, total, dense=False)
                 fence()
                 extra["gather_only_ms"] = 1e3 * (time.perf_counter() - t1) / n_x
-            elif dgather is not None:
+            elif chosen == "sdma":
                 extra["gather_only_ms"] = probe_sdma(dgather)
             else:
                 extra["gather_only_ms"] = probe_rccl()
-            if args.probe_other_gather and not args.hd and not ragged:
-                # the OTHER transport on the same shard, outside the timed region (opt-in: it opens IPC mappings / a second
-                # set of buffers, and an asymmetric failure there must not cost the line its main numbers)
-                if dgather is not None:
+            # the transport NOT chosen, on the same shard: in auto mode it has been set up and proven already; on request
+            # (--probe-other-gather) it is set up here
+            if not args.hd and not ragged:
+                if chosen == "sdma" and ("rccl" in transports or args.probe_other_gather):
                     extra["other_gather"] = {"mode": "rccl", "gather_only_ms": probe_rccl()}
-                else:
-                    g2 = shard.DirectGather(total, (M, D), dtype, device, depth=args.gather_depth, timeout_ms=5000)
+                elif chosen == "rccl" and (dgather is not None or args.probe_other_gather):
+                    g2 = dgather if dgather is not None else shard.DirectGather(total, (M, D), dtype, device, depth=args.gather_depth,
+                                                                                 timeout_ms=5000)
                     extra["other_gather"] = {"mode": "sdma", "gather_only_ms": probe_sdma(g2)}
-                    for _ in range(2):                   # pipelined steps on it: forward into the buffer, push, next forward
-                        model((x, xm), _out=g2.begin()); g2.submit()
-                    g2.drain(); fence()
-                    t1 = time.perf_counter()
-                    for _ in range(n_x):
-                        model((x, xm), _out=g2.begin()); g2.submit()
-                    g2.drain(); fence()
-                    extra["other_gather"]["pipelined_ms_per_step"] = 1e3 * (time.perf_counter() - t1) / n_x
-                    g2.close()
+                    if g2 is not dgather:
+                        g2.close()
 
     if args.hd:
         rows_img = hd.hd_token_rows(2, 4, M)
@@ -642,7 +725,7 @@ def main():
                        "global_batch": total, "per_gpu_batch": B, "scale_factor": s, "hidden_size": D,
                        "input_layout": args.layout,
                        "parallelism": f"batch-shard x{world}" + ((" + all_gather(tokens)" + (
-                           ", gather of step i overlapped with forward of step i+1" if (pipe is not None or (dgather is not None and not args.sync_gather)) else "")) if gather else ""),
+                           ", gather of step i overlapped with forward of step i+1" if ((chosen == "rccl" and pipe is not None) or (chosen == "sdma" and not args.sync_gather)) else "")) if gather else ""),
                        "weights": "random init (reference distribution), synthetic unit-normal CLIP features",
                        "tuning": {k: _capi.get_tuning(getattr(_capi, k)) for k in dir(_capi) if k.startswith("TP_TUNE_")}},
             "whole_path": {"achieved_tflops": round(fl_img * total / (ms_per_step * 1e-3) / 1e12, 1),
@@ -665,10 +748,13 @@ def main():
                                 "forward_only_images_per_s": round(total / (float(t[1].item()) * 1e-3), 1),
                                 "gather_only_ms": round(float(t[2].item()), 4),
                                 "collective": (f"DirectGather: {world - 1} hipMemcpyAsync (copy engines, no CU) per rank and step + sequence flags, "
-                                               f"depth {args.gather_depth}" if dgather is not None else
-                                               f"{args.backend} all_gather_into_tensor over {world} ranks") + (" (ragged: b_max-row slots)" if ragged and dgather is None else ""),
-                                "gather": "sdma" if dgather is not None else "rccl",
-                                "pipelined": bool(pipe is not None or (dgather is not None and not args.sync_gather)),
+                                               f"depth {args.gather_depth}" if chosen == "sdma" else
+                                               f"{args.backend} all_gather_into_tensor over {world} ranks") + (" (ragged: b_max-row slots)" if ragged and chosen != "sdma" else ""),
+                                "gather": chosen if chosen else "rccl",
+                                "gather_requested": args.gather,
+                                "transports_timed_ms_per_step": {k: round(1e3 * v / args.steps, 4) for k, v in per_transport.items()},
+                                "sdma_self_test": ("passed" if dgather is not None else f"not used: {sdma_note}") if args.gather == "auto" and not args.hd else None,
+                                "pipelined": bool((chosen == "rccl" and pipe is not None) or (chosen == "sdma" and not args.sync_gather)),
                                 "gather_bytes_received_per_rank": int((total - B) * M * D * 2),
                                 "ranks": dist.get_world_size(), "backend": dist.get_backend(), "rank_devices": rank_info,
                                 "env": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS",

@@ -62,6 +62,18 @@ def test_bench_spawns_its_own_ranks(mode):
     assert d["timing"]["long_run"]["blocks"] >= 5
 
 
+def test_bench_auto_proves_the_sdma_transport_then_times_both():
+    """The default (--gather auto): the copy-engine transport is self-tested (every rank checks every peer's rows), both
+    transports are timed over the K steps with the same protocol, the faster one is the line's value, both are reported."""
+    d = _bench_no_launcher([])
+    mg = d["multi_gpu"]
+    assert mg["gather_requested"] == "auto" and mg["sdma_self_test"] == "passed"
+    assert set(mg["transports_timed_ms_per_step"]) == {"rccl", "sdma"}
+    best = min(mg["transports_timed_ms_per_step"], key=mg["transports_timed_ms_per_step"].get)
+    assert mg["gather"] == best and abs(d["ms_per_step"] - mg["transports_timed_ms_per_step"][best]) < 1e-3
+    assert mg["other_gather"]["mode"] == ("sdma" if best == "rccl" else "rccl") and mg["other_gather"]["gather_only_ms"] > 0
+
+
 def test_bench_sdma_sync_gather_and_ragged():
     d = _bench_no_launcher(["--gather", "sdma", "--sync-gather", "--batch", "7"])
     assert d["config"]["global_batch"] == 7 and d["config"]["per_gpu_batch"] == 4 and d["multi_gpu"]["gather"] == "sdma"

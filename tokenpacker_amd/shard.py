@@ -218,41 +218,65 @@ class DirectGather:
         self.sizes = shard_sizes(total, self.world)
         self.lo, self.hi = shard_bounds(total, self.world, self.rank)
         self.total, self.tail = total, tuple(tail)
-        with torch.cuda.device(self.device):
-            self.bufs = [torch.empty((total,) + self.tail, dtype=dtype, device=self.device) for _ in range(depth)]
-            self.flags = torch.zeros(64, dtype=torch.int32, device=self.device)
-            self.cells = torch.zeros(8, dtype=torch.int32, device=self.device)
-            self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
-            torch.cuda.synchronize(self.device)               # the zeros are in place before any peer can write a flag
-            row_bytes = self.bufs[0][0].numel() * self.bufs[0].element_size() if total else 0
-            self._nbytes = (self.hi - self.lo) * row_bytes
-            mine = {"bufs": [self._export(b) for b in self.bufs], "flags": self._export(self.flags)}
-            everyone = [None] * self.world
-            dist.all_gather_object(everyone, mine, group=group)
-            self.peers = [p for p in range(self.world) if p != self.rank]
-            self._opened = []                                 # mapped allocation bases (tp_gather_close at close())
-            self._dst = [[0] * len(self.peers) for _ in range(depth)]     # [buffer][peer] -> address of MY rows in the peer's buffer
-            self._dst_flag = [0] * len(self.peers)                        # address of flags[self.rank] in the peer's flag array
-            for j, p in enumerate(self.peers):
-                bases = {}
-                def mapped(rec, bases=bases):
-                    handle, off = rec
-                    if handle not in bases:
-                        base = ctypes.c_void_p()
-                        hb = (ctypes.c_char * _capi.TP_IPC_HANDLE_BYTES).from_buffer_copy(handle)
-                        _capi.check(self.lib.tp_gather_open(hb, ctypes.byref(base)), "tp_gather_open")
-                        bases[handle] = base.value
-                        self._opened.append(base.value)
-                    return bases[handle] + off
-                for k in range(depth):
-                    self._dst[k][j] = mapped(everyone[p]["bufs"][k]) + self.lo * row_bytes
-                self._dst_flag[j] = mapped(everyone[p]["flags"]) + 4 * self.rank
-            self.streams = [torch.cuda.Stream(device=self.device) for _ in self.peers]
+        # Set-up is COLLECTIVE-SAFE: a rank whose local step fails (an IPC export / mapping the driver refuses) still takes part
+        # in the exchanges below, and then EVERY rank raises — nobody is left waiting in a barrier for a rank that has gone.
+        self._opened = []                                     # mapped allocation bases (tp_gather_close at close())
+        self.peers = [p for p in range(self.world) if p != self.rank]
+        err, mine = None, None
+        try:
+            with torch.cuda.device(self.device):
+                self.bufs = [torch.empty((total,) + self.tail, dtype=dtype, device=self.device) for _ in range(depth)]
+                self.flags = torch.zeros(64, dtype=torch.int32, device=self.device)
+                self.cells = torch.zeros(8, dtype=torch.int32, device=self.device)
+                self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+                torch.cuda.synchronize(self.device)           # the zeros are in place before any peer can write a flag
+                row_bytes = self.bufs[0][0].numel() * self.bufs[0].element_size() if total else 0
+                self._nbytes = (self.hi - self.lo) * row_bytes
+                mine = {"bufs": [self._export(b) for b in self.bufs], "flags": self._export(self.flags)}
+        except Exception as exc:                              # noqa: reported to every rank below
+            err = f"rank {self.rank}: {exc!r}"
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, {"err": err, "handles": mine}, group=group)
+        errs = [e["err"] for e in everyone if e["err"]]
+        if errs:
+            raise RuntimeError("DirectGather: exporting the receive buffers failed: " + "; ".join(errs))
+        try:
+            with torch.cuda.device(self.device):
+                self._dst = [[0] * len(self.peers) for _ in range(depth)]     # [buffer][peer] -> address of MY rows in the peer's buffer
+                self._dst_flag = [0] * len(self.peers)                        # address of flags[self.rank] in the peer's flag array
+                for j, p in enumerate(self.peers):
+                    bases = {}
+
+                    def mapped(rec, bases=bases):
+                        handle, off = rec
+                        if handle not in bases:
+                            base = ctypes.c_void_p()
+                            hb = (ctypes.c_char * _capi.TP_IPC_HANDLE_BYTES).from_buffer_copy(handle)
+                            _capi.check(self.lib.tp_gather_open(hb, ctypes.byref(base)), "tp_gather_open")
+                            bases[handle] = base.value
+                            self._opened.append(base.value)
+                        return bases[handle] + off
+                    for k in range(depth):
+                        self._dst[k][j] = mapped(everyone[p]["handles"]["bufs"][k]) + self.lo * row_bytes
+                    self._dst_flag[j] = mapped(everyone[p]["handles"]["flags"]) + 4 * self.rank
+                self.streams = [torch.cuda.Stream(device=self.device) for _ in self.peers]
+        except Exception as exc:                              # noqa
+            err = f"rank {self.rank}: {exc!r}"
+        oks = [None] * self.world
+        dist.all_gather_object(oks, err, group=group)          # (also the barrier: every rank has mapped every peer before anyone pushes)
+        if any(oks):
+            self._unmap()
+            raise RuntimeError("DirectGather: mapping the peers' buffers failed: " + "; ".join(e for e in oks if e))
         self._push_done = [[None] * len(self.peers) for _ in range(depth)]
         self._step = 0
         self._waited = 0                                      # highest sequence number a sync on the current stream has covered
         self._closed = False
-        dist.barrier(group=group)                             # every rank has mapped every peer before anyone pushes
+
+    def _unmap(self) -> None:
+        with torch.cuda.device(self.device):
+            for base in self._opened:
+                self.lib.tp_gather_close(base)
+        self._opened = []
 
     def _export(self, t: torch.Tensor):
         ct, _capi = self._ct, self._capi
@@ -334,10 +358,7 @@ class DirectGather:
         self.drain()
         torch.cuda.synchronize(self.device)
         dist.barrier(group=self.group)                        # nobody is still writing into anybody
-        with torch.cuda.device(self.device):
-            for base in self._opened:
-                self._capi.check(self.lib.tp_gather_close(base), "tp_gather_close")
-        self._opened = []
+        self._unmap()
         self.check()
 
 
