@@ -12,10 +12,11 @@ batch of 256 images ``[256, 576, 1024]`` + ``[256, 576, 4096]`` bf16 -> ``[256, 
 scale_factor=2, CLIP-L 336 px, bf16).  With N > 1 the batch is SHARDED (``--scaling strong``, the default: 256/N
 images per GPU, weights replicated — SURVEY.md §8e) and every step ends with the ONE all-gather of projected tokens
 the north_star prescribes, so each rank holds ``[256, 144, 4096]``; the gather of step i overlaps the forward of
-step i+1 (rotating output buffers, all gathers drained inside the timed region).  ``--gather rccl`` (default) is
+step i+1 (rotating output buffers, all gathers drained inside the timed region).  ``--gather rccl`` is
 ``all_gather_into_tensor`` (RCCL kernels over xGMI); ``--gather sdma`` is ``shard.DirectGather``: the shard is written
 straight into its rows of the receive buffer and travels as one copy-engine transfer per peer + a sequence flag — no
-compute unit.  ``--scaling weak`` keeps 256 images per GPU instead; ``--no-gather`` drops the gather
+compute unit; ``--gather auto`` (default) proves the sdma transport on the node first, then times BOTH
+with the same W + K step protocol and reports the faster one as ``value`` (both in ``multi_gpu``).  ``--scaling weak`` keeps 256 images per GPU instead; ``--no-gather`` drops the gather
 (DDP-style: the LLM consumes the local shard).
 
 Other workloads (each prints the same one-line JSON):
