@@ -421,12 +421,15 @@ enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all hal
                                      tensor) and region attention runs inside the epilogues of the K and V in-projection GEMMs — K, V
                                      are never written, no attention kernel | 1 off (raster rows, tp_region_attention's kernel) |
                                      2 region-major rows + the separate attention kernel (A/B, tests) */
-       TP_TUNE_SPLIT_K = 11,      /* small batches (B <= 3 at the shipped shapes), inference: 0 (default) off | 1: the two K = 4096 GEMMs
-                                     of the path (first K/V layer, mlp[2]) — 80 and 64 workgroups walking 64 K-slabs each at B = 1
-                                     — are split over K into up to 8 groups of the 128-tile kernel with fp32 partials and a
-                                     fixed-order reduction kernel that applies the epilogue.  Deterministic, but NOT the summation
-                                     order of the unsplit kernels: results of a small batch then differ in the last bits from the
-                                     same images inside a large batch (the default keeps them bit-identical). */
+       TP_TUNE_SPLIT_K = 11,      /* small batches (B <= 3 at the shipped shapes), inference: the two K = 4096 GEMMs of the path (first
+                                     K/V layer, mlp[2]) — 80 and 64 workgroups walking 64 K-slabs each at B = 1, a serial chain of
+                                     ~0.65 us steps — are split over K into up to 8 groups of the 128-tile kernel with fp32 partials
+                                     and a fixed-order reduction kernel that applies the epilogue (B = 1: 0.157 -> 0.137 ms).
+                                     0 (default since round 3) / 1: on where at least 4 K-groups fit | 2: off.  Deterministic, but NOT
+                                     the summation order of the unsplit kernels: with 0 / 1 the low bits of a batch of <= 3 images
+                                     differ from the same images inside a larger batch; 2 keeps an image's bits independent of the
+                                     batch it travels in (what rounds 1-2 shipped; the reference's eager PyTorch does not have that
+                                     property either). */
        TP_TUNE_SMALL_GEMM_WAVES = 12, /* the 128 x 128-tile kernel as 4 waves of 64 x 64 or 8 waves of 32 x 64 (bit-identical): 0 (default)
                                      auto by the number of workgroups of the launch | 4 | 8 */
        TP_TUNE_STREAM_K = 13,     /* stream-K decomposition of a persistent GEMM launch whose tile count is not a multiple of the CU

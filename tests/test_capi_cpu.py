@@ -94,9 +94,14 @@ def test_train_hd_and_parts_entry_points_reject_bad_arguments():
     assert lib.tp_backward(ctypes.byref(d), None, st, None, None, None, None, None, None, 0, None) == E
     assert lib.tp_backward_parts(ctypes.byref(d), None, st, None, None, None, None, None, None, 0, None) == E
     assert _capi.last_error()
-    # sizes: the training workspace extends the inference one by the two pre-GELU buffers
-    ws, tws, bws = (f(ctypes.byref(d)) for f in (lib.tp_workspace_bytes, lib.tp_train_workspace_bytes,
-                                                 lib.tp_backward_workspace_bytes))
+    # sizes: the training workspace extends the inference one by the two pre-GELU buffers and every slab the backward reads
+    # (the inference one carries the K-split partials of a small batch, which the training forward never uses: compare without)
+    _capi.set_tuning(_capi.TP_TUNE_SPLIT_K, 2)
+    try:
+        ws, tws, bws = (f(ctypes.byref(d)) for f in (lib.tp_workspace_bytes, lib.tp_train_workspace_bytes,
+                                                     lib.tp_backward_workspace_bytes))
+    finally:
+        _capi.set_tuning(_capi.TP_TUNE_SPLIT_K, 0)
     assert 0 < ws < tws and bws > 0
     bad = _capi.make_desc(1, 24, 5, 256, _capi.TP_BF16)
     assert lib.tp_train_workspace_bytes(ctypes.byref(bad)) == 0
@@ -151,7 +156,7 @@ def test_tuning_keys_match_the_header():
 def test_workspace_is_schedule_aware_and_an_upper_bound_for_the_tuning_at_call_time():
     """tp_workspace_bytes sizes the slabs the schedule of the moment writes (plan_schedule): the scale_factor-2 default has no
     H2 / K | V / Q1pre slab (1.2 GB less at B = 256); a masked forward (TP_DESC_MASKED), the unfused chain and the separate
-    attention kernel need K | V or H2 again; the K-split partials exist only while TP_TUNE_SPLIT_K is on."""
+    attention kernel need K | V or H2 again; the K-split partials exist only while TP_TUNE_SPLIT_K is not off."""
     lib = _capi.load_library()
     B, N, E = 256, 576, 1024
     slab = 2 * B * N * E * 2                       # one [2][B N, 1024] fp16 slab (H2, or K | V)
@@ -172,14 +177,14 @@ def test_workspace_is_schedule_aware_and_an_upper_bound_for_the_tuning_at_call_t
         assert size() == base
         # absorbed schedule (s = 3): qt | u [2][B M, 8, 1024] instead of K | V, no H2
         assert size(s=3) < base + 2 * 8 * B * 64 * E * 2
-        # K-split partials: only while the knob is on, only for batches of at most 8 images
+        # K-split partials: only while the knob is on (the default), only for batches of at most 8 images
         partials = 512 * 128 * 128 * 4
-        small = size(b=1)
-        _capi.set_tuning(_capi.TP_TUNE_SPLIT_K, 1)
-        assert partials <= size(b=1) - small < partials + 4096 and size(b=9) == size(b=9)
+        on = size(b=1)
         big_on = size(b=16)
-        _capi.set_tuning(_capi.TP_TUNE_SPLIT_K, 0)
+        _capi.set_tuning(_capi.TP_TUNE_SPLIT_K, 2)
+        assert partials <= on - size(b=1) < partials + 4096
         assert size(b=16) == big_on
+        _capi.set_tuning(_capi.TP_TUNE_SPLIT_K, 0)
     finally:
         for k, v in _capi._TUNING_DEFAULTS.items():
             _capi.set_tuning(k, v)

@@ -116,7 +116,8 @@ def test_odd_batch_and_single_image():
     params = synth.make_params(4, D)
     m = _module(params, s, D, dtype)
     x, xm = synth.make_inputs(8, 5, dtype)
-    with torch.no_grad():
+    from tests.gpu_util import batch_invariant
+    with torch.no_grad(), batch_invariant():             # (by default a batch of <= 3 images splits its K = 4096 GEMMs over K)
         y5 = m((x.cuda(), xm.cuda()))
         y1 = m((x[2:3].cuda(), xm[2:3].cuda()))
     assert torch.equal(y5[2:3], y1)
@@ -364,9 +365,9 @@ def test_absorbed_schedule_on_the_fused_layernorm_chain(s, B, dtype):
 
 @pytest.mark.parametrize("B,D", [(1, 4096), (2, 4096), (3, 4096)])
 def test_split_k_for_small_batches_is_the_same_function(B, D):
-    """TP_TUNE_SPLIT_K = 1 (opt-in): the two K = 4096 GEMMs of a small batch as K-groups with fp32 partials + a fixed-order
-    reduction.  Not the summation order of the unsplit kernels (so not bit-identical to them), deterministic, and within
-    the gate of the fp64 oracle at the same error level."""
+    """TP_TUNE_SPLIT_K (default on since round 3; 2 = off): the two K = 4096 GEMMs of a small batch as K-groups with fp32
+    partials + a fixed-order reduction.  Not the summation order of the unsplit kernels (so not bit-identical to them),
+    deterministic, and within the gate of the fp64 oracle at the same error level."""
     from tokenpacker_amd import _capi
     dtype, s = torch.bfloat16, 2
     params = synth.make_params(205, D)
@@ -376,7 +377,7 @@ def test_split_k_for_small_batches_is_the_same_function(B, D):
     ys = {}
     try:
         for mode in (0, 1, 1):
-            _capi.set_tuning(_capi.TP_TUNE_SPLIT_K, mode)
+            _capi.set_tuning(_capi.TP_TUNE_SPLIT_K, 2 if mode == 0 else 0)          # ys[0]: off, ys[1]: the default, twice
             m = _module(params, s, D, dtype)
             m.output_fp32 = True
             with torch.no_grad():
@@ -504,7 +505,8 @@ def test_batch_invariance_across_tile_shapes_and_kernels(s):
     xb = torch.randn(Bmax, 577, 1024, generator=g, device="cuda").to(dtype)
     xmb = torch.randn(Bmax, 577, 4096, generator=g, device="cuda").to(dtype)
     x, xm = xb[:, 1:], xmb[:, 1:]                                   # tower layout
-    with torch.no_grad():
+    from tests.gpu_util import batch_invariant
+    with torch.no_grad(), batch_invariant():                        # (TP_TUNE_SPLIT_K = 2: the property is opt-in since round 3)
         alone = {k: m((x[k:k + 1], xm[k:k + 1])) for k in (0, 2, 16, 32, 35, 46, 63, 99)}
         for B in (3, 17, 33, 36, 47, 64, 100):
             y = m((x[:B], xm[:B]))

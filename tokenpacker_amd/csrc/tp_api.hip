@@ -175,7 +175,7 @@ SchedulePlan plan_schedule(const tp_desc* d, bool train, bool masked) {
     P.fuse_attn = P.region_major && tuning(TP_TUNE_FUSE_ATTN) == 0;
     const int fmode = tuning(TP_TUNE_FOLD_OUT_PROJ);
     P.fold = !train && (fmode == 1 || (fmode == 0 && (P.absorb || P.fuse_attn)));
-    P.split_k = tuning(TP_TUNE_SPLIT_K) == 1 && !train && d->batch <= 8;
+    P.split_k = tuning(TP_TUNE_SPLIT_K) != 2 && !train && d->batch <= 8;      // (default on since round 3: see the header)
     P.need_h2 = train || !(P.fuse_ln || P.absorb_raw);
     P.need_kv = train || P.absorb || !P.fuse_attn;
     P.need_q1pre = !P.fuse_q;
@@ -723,12 +723,13 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     auto launch_maybe_splitk = [&](int in_dt, int out_dt, GemmArgs& a, hipStream_t st) -> int {
         const long long tiles = (long long)((a.M + 127) / 128) * (a.N / 128);
         int S = 1;
-        if (plan.split_k && !a.A_parts[0] && a.groups == 1 && (a.flags & ~TP_LINEAR_GELU) == 0)
+        if (plan.split_k && a.groups == 1 && (a.flags & ~TP_LINEAR_GELU) == 0)
             while (S < 8 && tiles * (S * 2) <= 512 && a.K / (S * 2) >= 4 * BK_ELEMS && a.K % (S * 2 * BK_ELEMS) == 0) S *= 2;
         if (S < 4) return launch(in_dt, out_dt, a, st);    // (two K-groups do not pay for the partials' round trip: measured)
         GemmArgs p = a;
         p.groups = S; p.K = a.K / S;
-        p.a_gs = (long long)p.K * 2; p.w_gs = (long long)p.K * 2;
+        p.a_gs = a.A_parts[0] ? 0 : (long long)p.K * 2; p.w_gs = (long long)p.K * 2;      // (four-part A: the kernel walks the sources)
+        p.parts_k_groups = a.A_parts[0] ? 1 : 0;
         p.ldw_bytes = a.ldw_bytes ? a.ldw_bytes : (long long)a.K * 2;
         p.C = slab(W.splitk); p.ldc = a.N; p.c_gs = (long long)a.M * a.N * 4;
         p.bias = nullptr; p.flags = 0; p.tile = 128; p.c_split_cols = 0;

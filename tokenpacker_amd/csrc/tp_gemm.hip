@@ -92,8 +92,10 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
         char* dst = smem + stage * STAGE + wave * CPW * 1024;
         long long a_adv = (long long)kt * ROW_BYTES;            // K advance of the A pieces
         if constexpr (AMODE == 2) {                              // K split over four source tensors
-            const int tpp = p.k_part / BK, part = kt / tpp;
-            a_adv = (p.A_parts[part] - p.A_parts[0]) + (long long)(kt - part * tpp) * ROW_BYTES;
+            // (a K-split launch — groups over K, a_gs = 0 — walks the sources with the group's GLOBAL K-tile index)
+            const int ktg = kt + (p.parts_k_groups ? g * (p.K / BK) : 0);
+            const int tpp = p.k_part / BK, part = ktg / tpp;
+            a_adv = (p.A_parts[part] - p.A_parts[0]) + (long long)(ktg - part * tpp) * ROW_BYTES;
         }
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
@@ -253,12 +255,14 @@ static int launch_types(const GemmArgs& a, hipStream_t stream) {
                 if constexpr (std::is_same<TO, f16_t>::value)
                     return train_epi ? launch_cfg<TI, TO, 128, 128, 64, 64, 2, true>(a, stream)
                                      : launch_cfg<TI, TO, 128, 128, 64, 64, 2, false>(a, stream);
-                set_error("tp gemm: a multi-part A operand is supported for fp16 output only");
+                set_error("tp gemm: a multi-part A operand is supported for fp16 (or K-split fp32) output only");
                 return TP_ERR_INVALID_ARG;
             }
             return strided ? launch_cfg<TI, TO, 128, 128, 64, 64, 1, true>(a, stream)
                            : launch_cfg<TI, TO, 128, 128, 64, 64, 0, true>(a, stream);
         } else {
+            if (a.A_parts[0] && !train_epi && a.parts_k_groups)      // the fp32 partials of a K-split first layer (tp_api.hip)
+                return launch_cfg<TI, TO, 128, 128, 64, 64, 2, false>(a, stream);
             set_error("tp gemm: training epilogues / multi-part A need a 16-bit output");
             return TP_ERR_INVALID_ARG;
         }

@@ -56,6 +56,7 @@ struct GemmArgs {
     long long ldw_bytes;              // between rows of W (0: K * 2 — a contiguous [N, K] weight)
     const char* A_parts[4];           // K split over 4 source tensors of k_part columns each (NULL: A alone)
     int k_part;
+    int parts_k_groups;               // A_parts + groups over K (128-tile kernel): group g covers K-tiles g*K/64 .. of the sources
     int* tile_counters;               // persistent kernel: [groups][8] zeroed ints -> dynamic per-XCD tile queue (NULL: static)
     // "TT" mode (tt_rows > 0; tp_gemm8.hip AMODE 3): C[g][M,N] = sum over rows r of group g's range of A[r][m] W[r][n] —
     // both operands K-major, row strides lda_bytes / ldw_bytes; group g covers contraction rows g*K .. g*K + K - 1 of
