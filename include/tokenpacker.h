@@ -439,6 +439,10 @@ enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all hal
                                      measured SLOWER than full rounds + a half-tile tail at every batch (B = 32: +22 % per forward) —
                                      de-phased K ranges lose the L2 sharing of operands between a tile row's workgroups
                                      (profiles/r03_stream_k_ab.txt).  With 2 an image's low bits depend on the batch it travels in. */
+       TP_TUNE_SMALL_TAIL = 14,   /* a launch of full rounds + a remainder on the persistent 256-tile kernel, K >= 2048: 0 (default) the
+                                     remainder rows run on the 128 x 128-tile kernel (a tail tile is bound by what one CU can load,
+                                     and the finer tile uses four times as many of the idle CUs; bit-identical results) | 1 as
+                                     128 x 256 half tiles of the persistent kernel (round 2) */
        TP_TUNE_COUNT_ = 16 };
 int tp_set_tuning(int key, int value);
 int tp_get_tuning(int key);                  /* the library's current value (not a binding's shadow copy); -1: bad key */
