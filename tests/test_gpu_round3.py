@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import tokenpacker_oracle as orc
-from tokenpacker_amd import TokenPacker, _capi, build_vision_projector, synth
+from tokenpacker_amd import TokenPacker, _capi, synth
 
 pytestmark = pytest.mark.gpu
 

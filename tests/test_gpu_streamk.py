@@ -4,7 +4,6 @@ shares its K-tiles evenly; a tile cut in two hands one fp32 partial over between
 value up to the summation order of the fp32 accumulation), determinism under uneven load (another stream holding CUs,
 repeated launches: every word identical — the hand-over must never read a stale slab), the whole path at the 8-GPU
 shard's batch against the oracle, and the shapes that must NOT take the route."""
-import ctypes
 
 import pytest
 import torch
