@@ -472,8 +472,14 @@ int tp_release_stream(void* stream);
  *                     (wrap-safe signed distance), then stores publish_seq to *seq_cell (NULL: nothing).  A wait longer than
  *                     timeout_ms (<= 0: 30 s) sets bit 0 of *status (device int32, may be NULL) and gives up — the caller
  *                     reads status when it synchronises.  flags: device uint32[world] in THIS rank's memory, zeroed
- *                     once, slot p written only by rank p's tp_gather_push. */
+ *                     once, slot p written only by rank p's tp_gather_push.
+ *   tp_gather_alloc_flags  the flag array as FINE-GRAINED device memory (hipExtMallocWithFlags), zeroed: it is written by
+ *                     other devices' copy engines while a kernel of this device polls it, and ordinary device memory is only
+ *                     coherent across agents at kernel boundaries.  The one allocation the library performs (on request, a few
+ *                     hundred bytes; tp_gather_free_flags releases it) — the caller's framework allocator cannot provide it. */
 #define TP_IPC_HANDLE_BYTES 64
+int tp_gather_alloc_flags(void** flags, size_t bytes);
+int tp_gather_free_flags(void* flags);
 int tp_gather_export(const void* ptr, void* handle /* [TP_IPC_HANDLE_BYTES] */, uint64_t* offset);
 int tp_gather_open(const void* handle, void** base);
 int tp_gather_close(void* base);

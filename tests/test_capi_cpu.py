@@ -210,6 +210,7 @@ def test_gather_entry_points_reject_bad_arguments():
     assert lib.tp_gather_export(None, None, ctypes.byref(off)) == E
     assert lib.tp_gather_open(None, None) == E
     assert lib.tp_gather_close(None) == E
+    assert lib.tp_gather_alloc_flags(None, 256) == E and lib.tp_gather_free_flags(None) == E
     assert lib.tp_gather_sync(None, 2, 0, 0, None, 0, None, 0, None) == E
     fake = ctypes.c_void_p(4096)
     assert lib.tp_gather_sync(fake, 0, 0, 0, None, 0, None, 0, None) == E          # world < 1

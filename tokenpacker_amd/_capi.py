@@ -45,7 +45,7 @@ EXPORTED_SYMBOLS = (
     "tp_wgrad", "tp_wgrad_workspace_bytes", "tp_packed_status_offset", "tp_debug_count_saturated",
     "tp_region_attention_absorbed", "tp_forward_masked",
     "tp_get_tuning", "tp_release_stream", "tp_test_side_cache_size",
-    "tp_linear_sk_workspace_bytes", "tp_gather_export", "tp_gather_open", "tp_gather_close", "tp_gather_push", "tp_gather_sync",
+    "tp_linear_sk_workspace_bytes", "tp_gather_alloc_flags", "tp_gather_free_flags", "tp_gather_export", "tp_gather_open", "tp_gather_close", "tp_gather_push", "tp_gather_sync",
 )
 
 # state-dict name -> tp_weights field order (include/tokenpacker.h)
@@ -160,6 +160,10 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.tp_release_stream.argtypes = [c_void_p]
     lib.tp_test_side_cache_size.restype = c_int
     lib.tp_test_side_cache_size.argtypes = []
+    lib.tp_gather_alloc_flags.restype = c_int
+    lib.tp_gather_alloc_flags.argtypes = [POINTER(c_void_p), c_size_t]
+    lib.tp_gather_free_flags.restype = c_int
+    lib.tp_gather_free_flags.argtypes = [c_void_p]
     lib.tp_gather_export.restype = c_int
     lib.tp_gather_export.argtypes = [c_void_p, c_void_p, POINTER(c_uint64)]
     lib.tp_gather_open.restype = c_int

@@ -82,6 +82,29 @@ int tp_gather_close(void* base) {
     return TP_OK;
 }
 
+// The flag words are written by OTHER devices' copy engines while a kernel of this device polls them.  Ordinary (coarse-grained)
+// device memory is only guaranteed coherent with other agents at kernel boundaries — a polled line may sit in this device's L2.
+// Fine-grained memory (what RCCL keeps its own flags in) is cached so that every agent sees every agent's writes.  torch's
+// allocator cannot provide it, so this is the ONE allocation the library performs, on request: a few hundred bytes per gather.
+int tp_gather_alloc_flags(void** flags, size_t bytes) {
+    if (!flags || bytes == 0 || bytes > (1u << 20)) { set_error("tp_gather_alloc_flags: bad argument"); return TP_ERR_INVALID_ARG; }
+    void* p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) { set_error("tp_gather_alloc_flags: hipExtMallocWithFlags(fine-grained): %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
+    e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();       // zeros in place before the handle leaves this process (set-up, not the data path)
+    if (e != hipSuccess) { (void)hipFree(p); set_error("tp_gather_alloc_flags: hipMemset: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
+    *flags = p;
+    return TP_OK;
+}
+
+int tp_gather_free_flags(void* flags) {
+    if (!flags) { set_error("tp_gather_free_flags: NULL argument"); return TP_ERR_INVALID_ARG; }
+    const hipError_t e = hipFree(flags);
+    if (e != hipSuccess) { set_error("tp_gather_free_flags: hipFree: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
+    return TP_OK;
+}
+
 int tp_gather_sync(const uint32_t* flags, int world, int rank, uint32_t wait_seq, uint32_t* seq_cell, uint32_t publish_seq,
                    int32_t* status, int timeout_ms, void* stream) {
     if (!flags || world < 1 || world > 64 || rank < 0 || rank >= world) {

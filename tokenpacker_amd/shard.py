@@ -226,13 +226,20 @@ class DirectGather:
         try:
             with torch.cuda.device(self.device):
                 self.bufs = [torch.empty((total,) + self.tail, dtype=dtype, device=self.device) for _ in range(depth)]
-                self.flags = torch.zeros(64, dtype=torch.int32, device=self.device)
+                # flags: FINE-GRAINED memory from the library (polled by a kernel here while peers' copy engines write it);
+                # where the runtime refuses it, ordinary memory — correct between processes on one device, documented as such
+                fp = ctypes.c_void_p()
+                if self.lib.tp_gather_alloc_flags(ctypes.byref(fp), 64 * 4) == _capi.TP_OK:
+                    self._flags_ptr, self._flags_owned, self._flags_keep = int(fp.value), True, None
+                else:
+                    self._flags_keep = torch.zeros(64, dtype=torch.int32, device=self.device)
+                    self._flags_ptr, self._flags_owned = self._flags_keep.data_ptr(), False
                 self.cells = torch.zeros(8, dtype=torch.int32, device=self.device)
                 self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
                 torch.cuda.synchronize(self.device)           # the zeros are in place before any peer can write a flag
                 row_bytes = self.bufs[0][0].numel() * self.bufs[0].element_size() if total else 0
                 self._nbytes = (self.hi - self.lo) * row_bytes
-                mine = {"bufs": [self._export(b) for b in self.bufs], "flags": self._export(self.flags)}
+                mine = {"bufs": [self._export(b.data_ptr()) for b in self.bufs], "flags": self._export(self._flags_ptr)}
         except Exception as exc:                              # noqa: reported to every rank below
             err = f"rank {self.rank}: {exc!r}"
         everyone = [None] * self.world
@@ -278,16 +285,16 @@ class DirectGather:
                 self.lib.tp_gather_close(base)
         self._opened = []
 
-    def _export(self, t: torch.Tensor):
+    def _export(self, ptr: int):
         ct, _capi = self._ct, self._capi
         handle = (ct.c_char * _capi.TP_IPC_HANDLE_BYTES)()
         off = ct.c_uint64(0)
-        _capi.check(self.lib.tp_gather_export(t.data_ptr(), handle, ct.byref(off)), "tp_gather_export")
+        _capi.check(self.lib.tp_gather_export(ptr, handle, ct.byref(off)), "tp_gather_export")
         return bytes(handle), int(off.value)
 
     def _sync(self, wait_seq: int, cell: Optional[int], publish: int) -> None:
         cur = torch.cuda.current_stream(self.device)
-        self._capi.check(self.lib.tp_gather_sync(self.flags.data_ptr(), self.world, self.rank, wait_seq & 0xFFFFFFFF,
+        self._capi.check(self.lib.tp_gather_sync(self._flags_ptr, self.world, self.rank, wait_seq & 0xFFFFFFFF,
                                                  cell, publish & 0xFFFFFFFF, self.status.data_ptr(), self.timeout_ms,
                                                  cur.cuda_stream), "tp_gather_sync")
 
@@ -359,6 +366,10 @@ class DirectGather:
         torch.cuda.synchronize(self.device)
         dist.barrier(group=self.group)                        # nobody is still writing into anybody
         self._unmap()
+        if self._flags_owned:
+            with torch.cuda.device(self.device):
+                self.lib.tp_gather_free_flags(self._flags_ptr)
+            self._flags_owned = False
         self.check()
 
 
