@@ -755,6 +755,7 @@ def main():
                                 "gather_requested": args.gather,
                                 "transports_timed_ms_per_step": {k: round(1e3 * v / args.steps, 4) for k, v in per_transport.items()},
                                 "sdma_self_test": ("passed" if dgather is not None else f"not used: {sdma_note}") if args.gather == "auto" and not args.hd else None,
+                                "sdma_flags_fine_grained": (dgather.flags_fine_grained if dgather is not None else None),
                                 "pipelined": bool((chosen == "rccl" and pipe is not None) or (chosen == "sdma" and not args.sync_gather)),
                                 "gather_bytes_received_per_rank": int((total - B) * M * D * 2),
                                 "ranks": dist.get_world_size(), "backend": dist.get_backend(), "rank_devices": rank_info,

@@ -68,6 +68,7 @@ def test_bench_auto_proves_the_sdma_transport_then_times_both():
     d = _bench_no_launcher([])
     mg = d["multi_gpu"]
     assert mg["gather_requested"] == "auto" and mg["sdma_self_test"] == "passed"
+    assert mg["sdma_flags_fine_grained"] is True         # the flags the sync kernel polls are fine-grained device memory
     assert set(mg["transports_timed_ms_per_step"]) == {"rccl", "sdma"}
     best = min(mg["transports_timed_ms_per_step"], key=mg["transports_timed_ms_per_step"].get)
     assert mg["gather"] == best and abs(d["ms_per_step"] - mg["transports_timed_ms_per_step"][best]) < 1e-3

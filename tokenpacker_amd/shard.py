@@ -274,6 +274,7 @@ class DirectGather:
         if any(oks):
             self._unmap()
             raise RuntimeError("DirectGather: mapping the peers' buffers failed: " + "; ".join(e for e in oks if e))
+        self.flags_fine_grained = bool(self._flags_owned)     # (echoed by bench.py: False = the runtime refused fine-grained memory)
         self._push_done = [[None] * len(self.peers) for _ in range(depth)]
         self._step = 0
         self._waited = 0                                      # highest sequence number a sync on the current stream has covered
