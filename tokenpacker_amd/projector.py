@@ -426,7 +426,7 @@ class TokenPacker(nn.Module):
         """Warn ONCE when a forward clamps: after forwards 1, 2, 4, 8, ... (then every 1024th) the status word is copied
         to pinned host memory behind the forward (asynchronously); whichever later forward finds the copy finished
         reads it.  No synchronisation is ever added to the forward."""
-        if self._sat_warned:
+        if self._sat_warned or torch.cuda.is_current_stream_capturing():      # (nothing host-visible inside a graph capture)
             return
         pend = self._sat_pending
         if pend is not None and pend[1].query():
