@@ -387,6 +387,12 @@ int tp_debug_count_saturated(const tp_desc* desc, const void* workspace, size_t 
 int tp_test_occupy_cus(int workgroups, int microseconds, void* scratch_int, void* stream);
 /* ---- test hook: entries of the per-caller-stream side-stream cache (tp_release_stream, LRU eviction) */
 int tp_test_side_cache_size(void);
+/* ---- test hook: the pack-time factorisation behind TP_TUNE_TRI_STATS on ONE layer.  w2 [1024][1024] fp16 and b2 [1024] fp32
+ * (or NULL) in; r [1024][1024] fp16 (upper triangular), c_tilde [1024] fp32 and wbar [1025] fp32 (column means of w2, then
+ * mean(b2)) out, with  sum_n ((w2 h + b2)_n - mean)^2 = || r h + c_tilde ||^2  for every h.  scratch: device memory of
+ * tp_test_pack_qr_scratch_bytes() bytes. */
+size_t tp_test_pack_qr_scratch_bytes(void);
+int tp_test_pack_qr(const void* w2_f16, const float* b2, void* r_f16, float* c_tilde, float* wbar, void* scratch, void* stream);
 
 /* ---- tuning knobs (benchmarks / deployment policy; defaults are what tp_forward ships with) --------------------
  * The table is ONE process-wide array of atomics: tp_set_tuning is NOT scoped to a stream, a call or a thread — two
@@ -443,6 +449,11 @@ enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all hal
                                      remainder rows run on the 128 x 128-tile kernel (a tail tile is bound by what one CU can load,
                                      and the finer tile uses four times as many of the idle CUs; bit-identical results) | 1 as
                                      128 x 256 half tiles of the persistent kernel (round 2) */
+       TP_TUNE_TRI_STATS = 15,    /* inference, fused LayerNorm chain: 0 (default, round 3) the layer in front of a LayerNorm is replaced, for
+                                     its statistics, by the UPPER-TRIANGULAR factor R of its centred weight (W2c = Q R, Householder QR at
+                                     pack time): var = ||R h + c~||^2 / E, a sum of squares, on 40 of the 64 (N-tile, K-tile) pairs; the
+                                     consumers use centred chain weights (W'·W2c, W'·b2c) and need no mean at all | 1: the full
+                                     statistics GEMM on W2 with (mean, M2), as rounds 1-2 shipped */
        TP_TUNE_COUNT_ = 16 };
 int tp_set_tuning(int key, int value);
 int tp_get_tuning(int key);                  /* the library's current value (not a binding's shadow copy); -1: bad key */

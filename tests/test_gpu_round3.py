@@ -68,8 +68,8 @@ def _legal_tunings(s):
     """Every combination of the schedule knobs plan_schedule reads, for scale factor s (values outside a knob's documented
     range are not enumerated)."""
     keys = (_capi.TP_TUNE_FUSE_KV_LN, _capi.TP_TUNE_FUSE_ATTN, _capi.TP_TUNE_ABSORB_KV, _capi.TP_TUNE_FOLD_OUT_PROJ,
-            _capi.TP_TUNE_Q_SIDE_STREAM, _capi.TP_TUNE_LN_MERGE)
-    ranges = ((0, 1), (0, 1, 2) if s == 2 else (0,), (0, 1, 2), (0, 1, 2), (0, 1), (0, 1))
+            _capi.TP_TUNE_Q_SIDE_STREAM, _capi.TP_TUNE_LN_MERGE, _capi.TP_TUNE_TRI_STATS)
+    ranges = ((0, 1), (0, 1, 2) if s == 2 else (0,), (0, 1, 2), (0, 1, 2), (0, 1), (0, 1), (0, 1))
     for combo in itertools.product(*ranges):
         yield dict(zip(keys, combo))
 

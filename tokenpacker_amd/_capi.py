@@ -24,6 +24,7 @@ TP_TUNE_LN_MERGE = 9
 TP_TUNE_SPLIT_K = 11
 TP_TUNE_SMALL_GEMM_WAVES = 12
 TP_TUNE_STREAM_K = 13
+TP_TUNE_TRI_STATS = 15
 TP_TUNE_SMALL_TAIL = 14
 TP_WGRAD_X_TRANSPOSED = 1
 TP_NUM_STAGES = 10
@@ -44,7 +45,7 @@ EXPORTED_SYMBOLS = (
     "tp_forward_parts", "tp_forward_train_parts", "tp_backward_parts", "tp_test_occupy_cus", "tp_hd_slice",
     "tp_wgrad", "tp_wgrad_workspace_bytes", "tp_packed_status_offset", "tp_debug_count_saturated",
     "tp_region_attention_absorbed", "tp_forward_masked",
-    "tp_get_tuning", "tp_release_stream", "tp_test_side_cache_size",
+    "tp_get_tuning", "tp_release_stream", "tp_test_side_cache_size", "tp_test_pack_qr", "tp_test_pack_qr_scratch_bytes",
     "tp_linear_sk_workspace_bytes", "tp_gather_alloc_flags", "tp_gather_free_flags", "tp_gather_export", "tp_gather_open", "tp_gather_close", "tp_gather_push", "tp_gather_sync",
 )
 
@@ -160,6 +161,10 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.tp_release_stream.argtypes = [c_void_p]
     lib.tp_test_side_cache_size.restype = c_int
     lib.tp_test_side_cache_size.argtypes = []
+    lib.tp_test_pack_qr_scratch_bytes.restype = c_size_t
+    lib.tp_test_pack_qr_scratch_bytes.argtypes = []
+    lib.tp_test_pack_qr.restype = c_int
+    lib.tp_test_pack_qr.argtypes = [c_void_p] * 7
     lib.tp_gather_alloc_flags.restype = c_int
     lib.tp_gather_alloc_flags.argtypes = [POINTER(c_void_p), c_size_t]
     lib.tp_gather_free_flags.restype = c_int
@@ -247,7 +252,7 @@ def strides3(st) -> "ctypes.Array":
 # the library's defaults (tests reset the table to these)
 _TUNING_DEFAULTS = {TP_TUNE_GEMM_TILE: 0, TP_TUNE_XCD_SWIZZLE: 1, TP_TUNE_GEMM_KERNEL: 0, TP_TUNE_FOLD_OUT_PROJ: 0,
                     TP_TUNE_DYNAMIC_TILES: 1, TP_TUNE_Q_SIDE_STREAM: 1, TP_TUNE_RESERVE_CUS: 0, TP_TUNE_ABSORB_KV: 0, TP_TUNE_FUSE_KV_LN: 1,
-                    TP_TUNE_FUSE_ATTN: 0, TP_TUNE_LN_MERGE: 0, TP_TUNE_SPLIT_K: 0, TP_TUNE_SMALL_GEMM_WAVES: 0, TP_TUNE_STREAM_K: 0, TP_TUNE_SMALL_TAIL: 0}
+                    TP_TUNE_FUSE_ATTN: 0, TP_TUNE_LN_MERGE: 0, TP_TUNE_SPLIT_K: 0, TP_TUNE_SMALL_GEMM_WAVES: 0, TP_TUNE_STREAM_K: 0, TP_TUNE_SMALL_TAIL: 0, TP_TUNE_TRI_STATS: 0}
 
 
 def set_tuning(key: int, value: int) -> None:

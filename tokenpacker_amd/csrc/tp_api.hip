@@ -59,6 +59,11 @@ PackedLayout packed_layout(int D) {
     L.w_qt_c = take(E * E * 2);
     L.w_c_kv = take(2 * E * E * 2);      L.d_in_kv = take(2 * E * 4);
     L.w_c_q = take(E * E * 2);
+    L.w_cc_kv = take(2 * E * E * 2);     L.d_cc_kv = take(2 * E * 4);
+    L.w_cc_q = take(E * E * 2);          L.w_qt_cc = take(E * E * 2);
+    L.w_r_kv = take(2 * E * E * 2);      L.c_r_kv = take(2 * E * 4);
+    L.w_r_q = take(E * E * 2);
+    L.wbar = take(3 * (E + 1) * 4);      L.scratch_qr = take(pack_qr_scratch_bytes(3));
     L.w_out = take(E * E * 2);           L.b_out = take(E * 4);
     L.w_m0 = take((size_t)D * E * 2);    L.b_m0 = take((size_t)D * 4);
     L.w_m2 = take((size_t)D * D * 2);    L.b_m2 = take((size_t)D * 4);
@@ -175,6 +180,7 @@ SchedulePlan plan_schedule(const tp_desc* d, bool train, bool masked) {
     P.fuse_attn = P.region_major && tuning(TP_TUNE_FUSE_ATTN) == 0;
     const int fmode = tuning(TP_TUNE_FOLD_OUT_PROJ);
     P.fold = !train && (fmode == 1 || (fmode == 0 && (P.absorb || P.fuse_attn)));
+    P.tri = !train && chain && tuning(TP_TUNE_TRI_STATS) != 1;
     P.split_k = tuning(TP_TUNE_SPLIT_K) != 2 && !train && d->batch <= 8;      // (default on since round 3: see the header)
     P.need_h2 = train || !(P.fuse_ln || P.absorb_raw);
     P.need_kv = train || P.absorb || !P.fuse_attn;
@@ -362,6 +368,17 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
     // Every INFERENCE pack carries every inference-only weight, whatever the tuning table says at pack time: the schedule is
     // chosen per forward (plan_schedule) and must find its operands whichever knob was turned in between.
     if (!train_pack) {
+        // triangular statistics (tp_pack_qr.hip): W2 / b2 centred over the output index (fp64), factored W2c = Q R; the chain
+        // weights of the centred form are built below from the same fp32 products as the plain ones
+        float* wbar = (float*)(P + L.wbar);
+        for (int g = 0; g < 2; ++g)
+            TP_TRY(pack_qr_center_launch(P + L.w_kv2 + (size_t)g * E * E * 2, (const float*)(P + L.b_kv2) + g * E, P + L.scratch_qr, g,
+                                         wbar + g * (E + 1), stream));
+        TP_TRY(pack_qr_center_launch(P + L.w_q1, nullptr, P + L.scratch_qr, 2, wbar + 2 * (E + 1), stream));
+        TP_TRY(pack_qr_factor_launch(P + L.scratch_qr, 3, stream));
+        for (int g = 0; g < 2; ++g)
+            TP_TRY(pack_qr_extract_launch(P + L.scratch_qr, g, P + L.w_r_kv + (size_t)g * E * E * 2, (float*)(P + L.c_r_kv) + g * E, stream, sat));
+        TP_TRY(pack_qr_extract_launch(P + L.scratch_qr, 2, P + L.w_r_q, nullptr, stream, sat));
         for (int g = 0; g < 2; ++g) {
             TP_TRY(pack_transpose_f16_launch(P + L.w_kv2 + (size_t)g * E * E * 2, P + L.scratch_t, (int)E, stream));   // W2^T [k][j]
             GemmArgs a = plain_gemm(P + L.w_in_kv + (size_t)g * E * E * 2, E, P + L.scratch_t, P + L.scratch_p, E, (int)E, (int)E,
@@ -371,7 +388,12 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
             TP_TRY(pack_round_f16_launch((const float*)(P + L.scratch_p), P + L.w_c_kv + (size_t)g * E * E * 2, (long long)E * E, stream, sat));
             TP_TRY(pack_bias_fold_launch(P + L.w_in_kv + (size_t)g * E * E * 2, (const float*)(P + L.b_kv2) + g * E, nullptr,
                                          (float*)(P + L.d_in_kv) + g * E, (int)E, (int)E, stream));
+            // the centred chain: Wc' = W'·W2c = Wc - c (x) wbar,  d' = W'·b2c = d - c mean(b2)   (c = rowsum of the rounded W')
+            TP_TRY(pack_center_product_launch((const float*)(P + L.scratch_p), (const float*)(P + L.c_in_kv) + g * E, wbar + g * (E + 1),
+                                              P + L.w_cc_kv + (size_t)g * E * E * 2, (const float*)(P + L.d_in_kv) + g * E,
+                                              (float*)(P + L.d_cc_kv) + g * E, stream, sat));
         }
+        TP_TRY(pack_head_transpose_launch(P + L.w_cc_kv, P + L.w_qt_cc, stream));
         // (the absorbed schedule on this chain: qt = per-head Q_h·Wc_k,h — the per-head transposes of the ROUNDED Wc_k)
         TP_TRY(pack_head_transpose_launch(P + L.w_c_kv, P + L.w_qt_c, stream));
         {   // query side: Q = rstd·(q0·Wcq^T − mu·c_q) + b'_q,  Wcq = W'q·Wq1  (q_proj_1 has no bias)
@@ -380,6 +402,8 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
             a.tile = 128;
             TP_TRY(gemm_launch(TP_F16, TP_F32, a, stream));
             TP_TRY(pack_round_f16_launch((const float*)(P + L.scratch_p), P + L.w_c_q, (long long)E * E, stream, sat));
+            TP_TRY(pack_center_product_launch((const float*)(P + L.scratch_p), (const float*)(P + L.c_in_q), wbar + 2 * (E + 1),
+                                              P + L.w_cc_q, nullptr, nullptr, stream, sat));
         }
         hipError_t e = hipMemsetD32Async((hipDeviceptr_t)(status + 2), 1, 1, stream);
         if (e != hipSuccess) { set_error("tp_pack_weights: hipMemsetD32Async(status): %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
@@ -743,9 +767,12 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     const int parts_q = gemm_stats_parts(E);
     // (fused LayerNorm chain, inference: Q1pre is computed for its row statistics only; the in-projection reads q0)
     const bool fuse_q = plan.fuse_q;
+    const bool tri = plan.tri;                          // centred chain weights + triangular statistics GEMMs (tp_pack_qr.hip): no mean anywhere
     auto q_proj = [&](hipStream_t st) -> int {          // 5. Q1pre = q0 · Wq1^T (no bias), LayerNorm partials
-        GemmArgs a = plain_gemm(ws + W.q0, E, pw + P.w_q1, slab(W.q1pre), E, rows_q, E, E, nullptr,
+        // (triangular statistics: the weight is R of W2c = Q R — the row's variance is the second moment of q0·R^T)
+        GemmArgs a = plain_gemm(ws + W.q0, E, tri ? pw + P.w_r_q : pw + P.w_q1, slab(W.q1pre), E, rows_q, E, E, nullptr,
                                 TP_LINEAR_ROW_STATS | (fuse_q ? TP_LINEAR_NO_STORE : 0));
+        a.tri = tri ? 1 : 0;
         a.stats_out = (float*)(ws + W.stats_q);
         a.stream_k = 1;                                 // (the query side may run beside the K/V side: one set of stream-K slabs)
         return launch(TP_F16, TP_F16, a, st);
@@ -756,18 +783,19 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     auto merge_in_kernel = [&](GemmArgs& a, const float* slabs, long long slabs_gs) -> bool {
         if (train || tuning(TP_TUNE_LN_MERGE) == 1 || !gemm_uses_small_kernel(a)) return false;
         a.stats_parts = slabs; a.stats_parts_gs = slabs_gs; a.ln_inv_dim = 1.0f / E; a.ln_eps = desc->ln_eps;
+        a.ln_second_moment = tri ? 1 : 0;
         a.stats_in = nullptr;
         return true;
     };
     static_assert(kEmbed / 128 == 8, "ln_merge_slabs<8>");
     auto q_inproj = [&](hipStream_t st) -> int {        // 6. Q = LN(Q1pre) · Winq^T + b
-        GemmArgs a = plain_gemm(fuse_q ? ws + W.q0 : slab(W.q1pre), E, fuse_q ? pw + P.w_c_q : pw + P.w_in_q, ws + W.q, E, rows_q, E, E,
-                                (const float*)(pw + P.b_in_q), TP_LINEAR_LN_FOLD);
+        GemmArgs a = plain_gemm(fuse_q ? ws + W.q0 : slab(W.q1pre), E, fuse_q ? (tri ? pw + P.w_cc_q : pw + P.w_c_q) : pw + P.w_in_q, ws + W.q, E,
+                                rows_q, E, E, (const float*)(pw + P.b_in_q), TP_LINEAR_LN_FOLD);
         a.stats_in = (const float*)(ws + W.mr_q);
         a.colsum = (const float*)(pw + P.c_in_q);
         if (!merge_in_kernel(a, (const float*)(ws + W.stats_q), 0))
             TP_TRY(ln_finalize_launch((const float*)(ws + W.stats_q), (float*)(ws + W.mr_q), rows_q, parts_q, 1, E,
-                                      desc->ln_eps, st));
+                                      desc->ln_eps, st, tri));
         a.stream_k = 1;
         return launch(TP_F16, TP_F16, a, st);
     };
@@ -785,7 +813,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     char* const qt = kv_slab;                                          // [rows_q, 8, E] fp16 (absorbed schedule)
     char* const uu = kv_slab ? kv_slab + (size_t)rows_q * 8 * E * 2 : nullptr;   // [rows_q, 8, E] fp16
     auto qt_gemm = [&](hipStream_t st) -> int {         // qt[m, h, :] = Q[m, h*128:(h+1)*128] · W'k[h*128:(h+1)*128, :]
-        GemmArgs a = plain_gemm(ws + W.q, E, absorb_raw ? pw + P.w_qt_c : pw + P.w_qt, qt, 8 * E, rows_q, E, kHeadDim, nullptr, 0);
+        GemmArgs a = plain_gemm(ws + W.q, E, absorb_raw ? (tri ? pw + P.w_qt_cc : pw + P.w_qt_c) : pw + P.w_qt, qt, 8 * E, rows_q, E, kHeadDim, nullptr, 0);
         a.groups = kHeads; a.a_gs = kHeadDim * 2; a.w_gs = (long long)E * kHeadDim * 2; a.c_gs = E * 2;
         return launch(TP_F16, TP_F16, a, st);
     };
@@ -834,8 +862,11 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     const int parts_kv = gemm_stats_parts(E);
     {
         const bool stats_only = fuse_ln || absorb_raw;
-        GemmArgs a = plain_gemm(ws + W.hkv, hkv_ld, pw + P.w_kv2, stats_only ? nullptr : slab(W.h2), E, rows_kv, E, E,
-                                (const float*)(pw + P.b_kv2), TP_LINEAR_ROW_STATS | (stats_only ? TP_LINEAR_NO_STORE : 0));
+        const bool tri_kv = tri && stats_only;
+        GemmArgs a = plain_gemm(ws + W.hkv, hkv_ld, tri_kv ? pw + P.w_r_kv : pw + P.w_kv2, stats_only ? nullptr : slab(W.h2), E, rows_kv, E, E,
+                                tri_kv ? (const float*)(pw + P.c_r_kv) : (const float*)(pw + P.b_kv2),
+                                TP_LINEAR_ROW_STATS | (stats_only ? TP_LINEAR_NO_STORE : 0));
+        a.tri = tri_kv ? 1 : 0;
         a.groups = 2; a.a_gs = hkv_gs; a.w_gs = (long long)E * E * 2; a.c_gs = kvE * 2; a.bias_gs = E;
         a.stats_out = (float*)(ws + W.stats_kv); a.stats_out_gs = (long long)parts_kv * rows_kv * 2;
         TP_TRY(launch(TP_F16, TP_F16, a, stream));
@@ -846,7 +877,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         if (kv_finalized) return TP_OK;
         kv_finalized = true;
         return ln_finalize_launch((const float*)(ws + W.stats_kv), (float*)(ws + W.mr_kv), rows_kv, parts_kv, 2, E,
-                                  desc->ln_eps, stream);
+                                  desc->ln_eps, stream, tri && (fuse_ln || absorb_raw));
     };
     bool joined = false;
     auto join_side = [&]() -> int {
@@ -861,10 +892,10 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     auto attn_gemm = [&](const int kv) -> int {
         // steps 4 + 7 as two launches: the K launch (step 4) turns its tile of K into logits against the region's query, the
         // V launch (step 7) its tile of V into softmax-weighted sums -> O.  K and V are never written.
-        GemmArgs a = plain_gemm(ws + W.hkv + (size_t)kv * hkv_gs, hkv_ld, pw + P.w_c_kv + (size_t)kv * E * E * 2,
+        GemmArgs a = plain_gemm(ws + W.hkv + (size_t)kv * hkv_gs, hkv_ld, (tri ? pw + P.w_cc_kv : pw + P.w_c_kv) + (size_t)kv * E * E * 2,
                                 kv == 0 ? nullptr : ws + W.o, E, rows_kv, E, E, (const float*)(pw + P.b_in_kv) + kv * E,
                                 TP_LINEAR_LN_FOLD);
-        a.acc_init = (const float*)(pw + P.d_in_kv) + kv * E;
+        a.acc_init = (const float*)(tri ? pw + P.d_cc_kv : pw + P.d_in_kv) + kv * E;
         a.stats_in = (const float*)(ws + W.mr_kv) + (size_t)kv * rows_kv * 2;
         a.colsum = (const float*)(pw + P.c_in_kv) + kv * E;
         a.attn_mode = kv + 1;
@@ -885,8 +916,8 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         a.groups = 2; a.a_gs = kvE * 2; a.w_gs = (long long)E * E * 2; a.c_gs = kvE * 2; a.bias_gs = E;
         if (fuse_ln) {                                  // {K,V} = rstd·(Hkv[:, g]·Wc^T + d − mu·c) + b'
             a.A = (const char*)(ws + W.hkv); a.lda_bytes = hkv_ld * 2; a.a_gs = hkv_gs;
-            a.W = pw + P.w_c_kv;
-            a.acc_init = (const float*)(pw + P.d_in_kv); a.acc_init_gs = E;
+            a.W = tri ? pw + P.w_cc_kv : pw + P.w_c_kv;
+            a.acc_init = (const float*)(tri ? pw + P.d_cc_kv : pw + P.d_in_kv); a.acc_init_gs = E;
         }
         a.stats_in = (const float*)(ws + W.mr_kv); a.stats_in_gs = (long long)rows_kv * 2;
         a.colsum = (const float*)(pw + P.c_in_kv); a.colsum_gs = E;
@@ -907,17 +938,18 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         if (absorb_raw)
             TP_TRY(region_attention_absorbed_launch(qt, ws + W.hkv, ws + W.hkv + (size_t)hkv_gs, (const float*)(ws + W.mr_kv),
                                                     (const float*)(ws + W.mr_kv) + (size_t)rows_kv * 2, uu, B, g, s, stream, attn_mask, mask_mode,
-                                                    (int)hkv_ld, ws + W.q, (const float*)(pw + P.d_in_kv), (const float*)(pw + P.c_in_kv), mr_u));
+                                                    (int)hkv_ld, ws + W.q, (const float*)(tri ? pw + P.d_cc_kv : pw + P.d_in_kv),
+                                                    (const float*)(pw + P.c_in_kv), mr_u));
         else
             TP_TRY(region_attention_absorbed_launch(qt, slab(W.h2), slab(W.h2) + kvE * 2, (const float*)(ws + W.mr_kv),
                                                     (const float*)(ws + W.mr_kv) + (size_t)rows_kv * 2, uu, B, g, s, stream, attn_mask, mask_mode));
         // O[:, h*128:(h+1)*128] = u[:, h, :] · W'v[h*128:(h+1)*128, :]^T + b'v   (eight N = 128 groups)
         // RAW: a_h (u_h · Wc_v,h^T + d_v,h - (e_h / a_h) c_v,h) + b'v,h — a LayerNorm-fold epilogue with (mean, rstd) := mr_u
-        GemmArgs a = plain_gemm(uu, 8 * E, (absorb_raw ? pw + P.w_c_kv : pw + P.w_in_kv) + (size_t)E * E * 2, ws + W.o, E, rows_q, kHeadDim, E,
+        GemmArgs a = plain_gemm(uu, 8 * E, (absorb_raw ? (tri ? pw + P.w_cc_kv : pw + P.w_c_kv) : pw + P.w_in_kv) + (size_t)E * E * 2, ws + W.o, E, rows_q, kHeadDim, E,
                                 (const float*)(pw + P.b_in_kv) + E, absorb_raw ? TP_LINEAR_LN_FOLD : 0);
         a.groups = kHeads; a.a_gs = E * 2; a.w_gs = (long long)kHeadDim * E * 2; a.c_gs = kHeadDim * 2; a.bias_gs = kHeadDim;
         if (absorb_raw) {
-            a.acc_init = (const float*)(pw + P.d_in_kv) + E; a.acc_init_gs = kHeadDim;
+            a.acc_init = (const float*)(tri ? pw + P.d_cc_kv : pw + P.d_in_kv) + E; a.acc_init_gs = kHeadDim;
             a.colsum = (const float*)(pw + P.c_in_kv) + E; a.colsum_gs = kHeadDim;
             a.stats_in = mr_u; a.stats_in_gs = (long long)rows_q * 2;
         }
@@ -993,5 +1025,15 @@ int tp_forward_staged(const tp_desc* desc, const void* x, const int64_t x_stride
 int tp_release_stream(void* stream) { return release_stream_state((hipStream_t)stream); }
 
 int tp_test_side_cache_size(void) { return side_cache_size(); }
+
+size_t tp_test_pack_qr_scratch_bytes(void) { return pack_qr_scratch_bytes(1); }
+
+int tp_test_pack_qr(const void* w2_f16, const float* b2, void* r_f16, float* c_tilde, float* wbar, void* scratch, void* stream) {
+    if (!w2_f16 || !r_f16 || !c_tilde || !wbar || !scratch) { set_error("tp_test_pack_qr: NULL argument"); return TP_ERR_INVALID_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    TP_TRY(pack_qr_center_launch(w2_f16, b2, scratch, 0, wbar, st));
+    TP_TRY(pack_qr_factor_launch(scratch, 1, st));
+    return pack_qr_extract_launch(scratch, 0, r_f16, c_tilde, st, nullptr);
+}
 
 }  // extern "C"

@@ -88,7 +88,10 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
         }
     }
 
-    auto issue = [&](int kt, int stage) {
+    // statistics-only launches on an UPPER-TRIANGULAR weight (GemmArgs::tri): W[n][k] = 0 for k < n0 — start at K-tile n0 / 64
+    const int kt0 = (XMODE == 1 && p.tri) ? n0 / BK : 0;
+    auto issue = [&](int kt_rel, int stage) {
+        const int kt = kt_rel + kt0;
         char* dst = smem + stage * STAGE + wave * CPW * 1024;
         long long a_adv = (long long)kt * ROW_BYTES;            // K advance of the A pieces
         if constexpr (AMODE == 2) {                              // K split over four source tensors
@@ -111,7 +114,7 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
     const int frag_off1 = (lane & 15) * ROW_BYTES + (((4 + (lane >> 4)) ^ (lane & 7)) << 4);
 
     // the first K-slabs go out before anything else touches memory: the parameter loads below then wait WITH them
-    const int nk = p.K / BK;
+    const int nk = p.K / BK - kt0;
     issue(0, 0);
     f32x4 acc[FM][FN];
 #pragma unroll
@@ -145,7 +148,7 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
                     st[i][pp] = *(const float2*)(p.stats_parts + g * p.stats_parts_gs + ((long long)pp * p.M + m) * 2);
             }
 #pragma unroll
-            for (int i = 0; i < FM; ++i) mean_rstd[i] = ln_merge_values<8>(st[i], p.ln_inv_dim, p.ln_eps);
+            for (int i = 0; i < FM; ++i) mean_rstd[i] = ln_merge_values<8>(st[i], p.ln_inv_dim, p.ln_eps, p.ln_second_moment != 0);
         } else {
 #pragma unroll
             for (int i = 0; i < FM; ++i) {

@@ -228,6 +228,12 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
             if ((blk << 3) + 8 <= tiles_m) { tm = (blk << 3) + (j >> 2); tile_n = (half << 2) + (j & 3); }
         }
         m0 = p.m_begin + tm * BM; n0 = tile_n * BN;
+        if constexpr (XMODE == 1) {
+            // statistics-only launch on an UPPER-TRIANGULAR weight (GemmArgs::tri, tp_pack_qr.hip): W[n][k] = 0 for k < n0 —
+            // this tile's K loop starts at K-tile n0 / 64 (16 / 12 / 8 / 4 K-tiles for the four column tiles of E = 1024)
+            kt_base = p.tri ? n0 / BK : 0;
+            nk = nk_full - kt_base;
+        }
         // K-major operands: per-lane source offsets of DMA instruction idx = 2 wave + q of a group — k rows 4 idx ..
         // 4 idx + 3, chunk slot lane / 8 holds column block (lane / 8) ^ (wave & 1), row (lane % 8) / 2, half lane % 2
         if constexpr (W_KMAJOR) {
@@ -320,7 +326,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
                                                          is_a ? voff_a[sub][q] : voff_w[sub][q], 0, 0, 0);
             return;
         }
-        const int soff = (SK ? kt_base + kt : kt) * ROW_BYTES;
+        const int soff = ((SK || XMODE == 1) ? kt_base + kt : kt) * ROW_BYTES;      // (XMODE 1: kt_base = the triangular skip, 0 otherwise)
         if constexpr (is_a && AMODE == 2) {
             // K-tile kt lives in source kt / tpp: pick that source's base with scalar selects and rebuild the
             // descriptor (words 2, 3 are constants) — four resident descriptors cost 12 more SGPRs, which pushed

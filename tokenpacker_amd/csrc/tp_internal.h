@@ -57,6 +57,10 @@ struct GemmArgs {
     const char* A_parts[4];           // K split over 4 source tensors of k_part columns each (NULL: A alone)
     int k_part;
     int parts_k_groups;               // A_parts + groups over K (128-tile kernel): group g covers K-tiles g*K/64 .. of the sources
+    int tri;                          // statistics-only launches (NO_STORE): W is UPPER TRIANGULAR (W[n][k] = 0 for k < n): the output
+                                      // tile at column n0 starts its K loop at K-tile n0 / 64 (tp_pack_qr.hip)
+    int ln_second_moment;             // stats_parts consumers: the slabs are those of a triangular statistics GEMM — rstd from the
+                                      // second moment (M2 + n mean^2), mean := 0
     int* tile_counters;               // persistent kernel: [groups][8] zeroed ints -> dynamic per-XCD tile queue (NULL: static)
     // "TT" mode (tt_rows > 0; tp_gemm8.hip AMODE 3): C[g][M,N] = sum over rows r of group g's range of A[r][m] W[r][n] —
     // both operands K-major, row strides lda_bytes / ldw_bytes; group g covers contraction rows g*K .. g*K + K - 1 of
@@ -114,8 +118,10 @@ bool gemm_uses_small_kernel(const GemmArgs& a);        // whether gemm_launch wo
 // M2 = sum of squared deviations from the slab's own mean): Chan's merge in slab order -> (mean, rstd) of nn.LayerNorm
 // (biased variance).  All slabs are fetched before any is used (independent loads in flight).  Used by ln_finalize_kernel
 // and by the 128-tile GEMM's LN-fold prologue: one arithmetic, identical bits.
+// `second_moment`: the slabs describe y = R h + c~ of a triangular statistics GEMM (tp_pack_qr.hip), whose SECOND MOMENT is the
+// variance wanted: M2 + n mean^2 (Chan's merge is exact algebra; every term is a sum of squares) -> (0, rstd).
 template <int NPARTS>
-__device__ __forceinline__ float2 ln_merge_values(const float2 (&st)[NPARTS], float inv_dim, float eps) {
+__device__ __forceinline__ float2 ln_merge_values(const float2 (&st)[NPARTS], float inv_dim, float eps, bool second_moment = false) {
     float s1 = 0.f, q = 0.f, between = 0.f;
 #pragma unroll
     for (int pp = 0; pp < NPARTS; ++pp) { s1 += st[pp].x; q += st[pp].y; }
@@ -123,14 +129,16 @@ __device__ __forceinline__ float2 ln_merge_values(const float2 (&st)[NPARTS], fl
 #pragma unroll
     for (int pp = 0; pp < NPARTS; ++pp) { const float d = st[pp].x - mu; between = fmaf(d, d, between); }
     const float var = (q + 128.0f * between) * inv_dim;         // biased variance (nn.LayerNorm); >= 0 by construction
+    if (second_moment) return make_float2(0.f, 1.0f / sqrtf(fmaf(mu, mu, var) + eps));
     return make_float2(mu, 1.0f / sqrtf(var + eps));
 }
 template <int NPARTS>
-__device__ __forceinline__ float2 ln_merge_slabs(const float* __restrict__ pg, long long M, long long m, float inv_dim, float eps) {
+__device__ __forceinline__ float2 ln_merge_slabs(const float* __restrict__ pg, long long M, long long m, float inv_dim, float eps,
+                                                 bool second_moment = false) {
     float2 st[NPARTS];
 #pragma unroll
     for (int pp = 0; pp < NPARTS; ++pp) st[pp] = *(const float2*)(pg + ((long long)pp * M + m) * 2);
-    return ln_merge_values<NPARTS>(st, inv_dim, eps);
+    return ln_merge_values<NPARTS>(st, inv_dim, eps, second_moment);
 }
 
 int gemm_pick_tile(int M, int N, int forced, int groups = 1);     // -> 128 or 256
@@ -163,6 +171,14 @@ int region_attention_absorbed_launch(const void* qt, const void* h2k, const void
                                      int ld = kEmbed, const void* q = nullptr, const float* d_k = nullptr, const float* c_k = nullptr,
                                      float* mr_u = nullptr);
 int pack_head_transpose_launch(const void* w_f16, void* dst_f16, hipStream_t stream);    // [8*128, 1024] -> [8][1024][128]
+// tp_pack_qr.hip: W2 (fp16 [E,E]) and b2 (fp32 [E] or NULL) centred into matrix m of `scratch` (fp64), wbar [E+1] = the column means
+// and mean(b2); Householder QR of the nmat matrices; R (fp16, upper triangular) and c~ (fp32) out; the centred chain weight
+size_t pack_qr_scratch_bytes(int nmat);
+int pack_qr_center_launch(const void* w2_f16, const float* b2, void* scratch, int m, float* wbar, hipStream_t stream);
+int pack_qr_factor_launch(void* scratch, int nmat, hipStream_t stream);
+int pack_qr_extract_launch(const void* scratch, int m, void* r_f16, float* ctil, hipStream_t stream, int* sat);
+int pack_center_product_launch(const float* P, const float* c, const float* wbar, void* out_f16, const float* d, float* d_out,
+                               hipStream_t stream, int* sat);
 bool absorb_kv(const tp_desc* desc, bool train);          // whether tp_forward runs the absorbed schedule for desc
 bool fold_out_proj(const tp_desc* desc, bool train);      // whether out_proj is folded into mlp[0] for desc
 int hd_slice_launch(const float* img, int H, int W, int h_block, int w_block, int h_res, int w_res, int hg, int wg,
@@ -171,7 +187,7 @@ int occupy_cus_launch(int blocks, int usec, int* sink, hipStream_t stream);
 int hd_assemble_launch(const tp_hd_image* plan_host, int n_images, const void* tokens, const int32_t* crop_map, const void* sep,
                        const void* ret, void* out, int M, int D, hipStream_t stream);
 int ln_finalize_launch(const float* parts, float* mean_rstd, long long M, int nparts, int groups, int ln_dim,
-                       float eps, hipStream_t stream);
+                       float eps, hipStream_t stream, bool second_moment = false);
 int pack_cast_f32_launch(int dtype, const void* src, float* dst, int n, hipStream_t stream);
 // `sat` (optional): device int incremented once per element that did not fit fp16 and was clamped to +-65504
 int pack_cast_f16_launch(int dtype, const void* src, void* dst_f16, long long n, hipStream_t stream, int* sat = nullptr);
@@ -194,6 +210,16 @@ struct PackedLayout {
     size_t w_in_q, c_in_q, b_in_q;      // LN-folded in-proj for q
     size_t w_c_kv, d_in_kv;       // fused LayerNorm chain: Wc = W'·W2 [2][1024,1024] f16, d = W'·b2 [2][1024] f32
     size_t w_c_q;                 // the same for the query side: W'q·Wq1 [1024,1024] f16 (q_proj_1 has no bias: d = 0)
+    // triangular statistics (TP_TUNE_TRI_STATS, tp_pack_qr.hip): the chain with the mean folded away — Wc' = W'·W2c, d' = W'·b2c
+    // (W2c / b2c: W2 / b2 centred over the output index), and the statistics GEMM's weight R (upper triangular, W2c = Q R) with
+    // its constant c~ = Q^T b2c:  var = || R h + c~ ||^2 / E
+    size_t w_cc_kv, d_cc_kv;      // [2][1024,1024] f16, [2][1024] f32
+    size_t w_cc_q;                // [1024,1024] f16
+    size_t w_qt_cc;               // per-head transposes of Wc'_k (absorbed schedule)
+    size_t w_r_kv, c_r_kv;        // [2][1024,1024] f16 (zeros below the diagonal), [2][1024] f32
+    size_t w_r_q;                 // [1024,1024] f16
+    size_t wbar;                  // pack scratch: [3][1025] f32 column means of W2 (k, v, q) and the mean of b2 behind each
+    size_t scratch_qr;            // pack scratch: three fp64 [1024][1025] matrices + Householder vectors
     size_t w_qt;                  // [8][1024][128] f16: per-head transposes of the LN-folded K in-proj (absorbed schedule)
     size_t w_qt_c;                // the same of Wc_k (absorbed schedule on the fused LayerNorm chain: the kernel walks Hkv)
     size_t w_out, b_out;          // [1024,1024] f16, [1024] f32
@@ -217,6 +243,7 @@ struct SchedulePlan {
     bool region_major, fuse_attn;  // scale_factor 2: region-major K/V rows; attention inside the in-projections' epilogues
     bool fold;                     // out_proj folded into mlp[0]
     bool split_k;                  // TP_TUNE_SPLIT_K applies to this batch
+    bool tri;                      // TP_TUNE_TRI_STATS: centred chain weights, triangular statistics GEMM, no mean anywhere
     bool need_h2, need_kv, need_q1pre, need_a1;   // workspace slabs the schedule writes
 };
 SchedulePlan plan_schedule(const tp_desc* desc, bool train, bool masked);

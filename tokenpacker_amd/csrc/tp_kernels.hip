@@ -594,13 +594,13 @@ int hd_slice_launch(const float* img, int H, int W, int h_block, int w_block, in
 template <int NPARTS>
 __global__ void __launch_bounds__(256)
 ln_finalize_kernel(const float* __restrict__ parts, float* __restrict__ mean_rstd, long long M, int nparts,
-                   float inv_dim, float eps) {
+                   float inv_dim, float eps, bool second_moment) {
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int g = blockIdx.y;
     if (m >= M) return;
     const float* pg = parts + (long long)g * nparts * M * 2;
     if constexpr (NPARTS > 0) {
-        *(float2*)(mean_rstd + ((long long)g * M + m) * 2) = ln_merge_slabs<NPARTS>(pg, M, m, inv_dim, eps);
+        *(float2*)(mean_rstd + ((long long)g * M + m) * 2) = ln_merge_slabs<NPARTS>(pg, M, m, inv_dim, eps, second_moment);
         return;
     } else {
         float s1 = 0.f, q = 0.f, between = 0.f, mu;
@@ -614,17 +614,18 @@ ln_finalize_kernel(const float* __restrict__ parts, float* __restrict__ mean_rst
             between = fmaf(d, d, between);
         }
         const float var = (q + 128.0f * between) * inv_dim;    // biased variance (nn.LayerNorm); >= 0 by construction
-        *(float2*)(mean_rstd + ((long long)g * M + m) * 2) = make_float2(mu, 1.0f / sqrtf(var + eps));
+        *(float2*)(mean_rstd + ((long long)g * M + m) * 2) = second_moment ? make_float2(0.f, 1.0f / sqrtf(fmaf(mu, mu, var) + eps))
+                                                                          : make_float2(mu, 1.0f / sqrtf(var + eps));
     }
 }
 
 int ln_finalize_launch(const float* parts, float* mean_rstd, long long M, int nparts, int groups, int ln_dim,
-                       float eps, hipStream_t stream) {
+                       float eps, hipStream_t stream, bool second_moment) {
     dim3 grid((unsigned)((M + 255) / 256), (unsigned)groups);
     if (nparts == 8)
-        hipLaunchKernelGGL(ln_finalize_kernel<8>, grid, dim3(256), 0, stream, parts, mean_rstd, M, nparts, 1.0f / ln_dim, eps);
+        hipLaunchKernelGGL(ln_finalize_kernel<8>, grid, dim3(256), 0, stream, parts, mean_rstd, M, nparts, 1.0f / ln_dim, eps, second_moment);
     else
-        hipLaunchKernelGGL(ln_finalize_kernel<0>, grid, dim3(256), 0, stream, parts, mean_rstd, M, nparts, 1.0f / ln_dim, eps);
+        hipLaunchKernelGGL(ln_finalize_kernel<0>, grid, dim3(256), 0, stream, parts, mean_rstd, M, nparts, 1.0f / ln_dim, eps, second_moment);
     return check_launch("ln_finalize_kernel");
 }
 
