@@ -445,16 +445,12 @@ enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all hal
                                      measured SLOWER than full rounds + a half-tile tail at every batch (B = 32: +22 % per forward) —
                                      de-phased K ranges lose the L2 sharing of operands between a tile row's workgroups
                                      (profiles/r03_stream_k_ab.txt).  With 2 an image's low bits depend on the batch it travels in. */
-       TP_TUNE_SMALL_TAIL = 14,   /* a launch of full rounds + a remainder on the persistent 256-tile kernel, K >= 2048: 0 (default) the
-                                     remainder rows run on the 128 x 128-tile kernel (a tail tile is bound by what one CU can load,
-                                     and the finer tile uses four times as many of the idle CUs; bit-identical results) | 1 as
-                                     128 x 256 half tiles of the persistent kernel (round 2) */
-       TP_TUNE_TRI_STATS = 15,    /* inference, fused LayerNorm chain: 0 (default, round 3) the layer in front of a LayerNorm is replaced, for
+       TP_TUNE_TRI_STATS = 14,    /* inference, fused LayerNorm chain: 0 (default, round 3) the layer in front of a LayerNorm is replaced, for
                                      its statistics, by the UPPER-TRIANGULAR factor R of its centred weight (W2c = Q R, Householder QR at
                                      pack time): var = ||R h + c~||^2 / E, a sum of squares, on 40 of the 64 (N-tile, K-tile) pairs; the
                                      consumers use centred chain weights (W'·W2c, W'·b2c) and need no mean at all | 1: the full
                                      statistics GEMM on W2 with (mean, M2), as rounds 1-2 shipped */
-       TP_TUNE_COUNT_ = 16 };
+       TP_TUNE_COUNT_ = 15 };
 int tp_set_tuning(int key, int value);
 int tp_get_tuning(int key);                  /* the library's current value (not a binding's shadow copy); -1: bad key */
 

@@ -24,8 +24,7 @@ TP_TUNE_LN_MERGE = 9
 TP_TUNE_SPLIT_K = 11
 TP_TUNE_SMALL_GEMM_WAVES = 12
 TP_TUNE_STREAM_K = 13
-TP_TUNE_TRI_STATS = 15
-TP_TUNE_SMALL_TAIL = 14
+TP_TUNE_TRI_STATS = 14
 TP_WGRAD_X_TRANSPOSED = 1
 TP_NUM_STAGES = 10
 TP_NUM_DEBUG_BUFFERS = 9
@@ -252,7 +251,7 @@ def strides3(st) -> "ctypes.Array":
 # the library's defaults (tests reset the table to these)
 _TUNING_DEFAULTS = {TP_TUNE_GEMM_TILE: 0, TP_TUNE_XCD_SWIZZLE: 1, TP_TUNE_GEMM_KERNEL: 0, TP_TUNE_FOLD_OUT_PROJ: 0,
                     TP_TUNE_DYNAMIC_TILES: 1, TP_TUNE_Q_SIDE_STREAM: 1, TP_TUNE_RESERVE_CUS: 0, TP_TUNE_ABSORB_KV: 0, TP_TUNE_FUSE_KV_LN: 1,
-                    TP_TUNE_FUSE_ATTN: 0, TP_TUNE_LN_MERGE: 0, TP_TUNE_SPLIT_K: 0, TP_TUNE_SMALL_GEMM_WAVES: 0, TP_TUNE_STREAM_K: 0, TP_TUNE_SMALL_TAIL: 0, TP_TUNE_TRI_STATS: 0}
+                    TP_TUNE_FUSE_ATTN: 0, TP_TUNE_LN_MERGE: 0, TP_TUNE_SPLIT_K: 0, TP_TUNE_SMALL_GEMM_WAVES: 0, TP_TUNE_STREAM_K: 0, TP_TUNE_TRI_STATS: 0}
 
 
 def set_tuning(key: int, value: int) -> None:

@@ -57,7 +57,7 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
     int bid = blockIdx.x;
     if (xcd_swizzle) bid = xcd_remap(bid, gridDim.x);
     const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
-    const int m0 = p.m_begin + tile_m * BM, n0 = tile_n * BN;      // (row window [m_begin, m_end): the tail of a split launch)
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int g = blockIdx.y;
 
     const char* __restrict__ Ag = p.A + g * p.a_gs;
@@ -207,7 +207,7 @@ int gemm_pick_tile(int M, int N, int forced, int groups) {
 template <typename TI, typename TO, int BM, int BN, int WM, int WN, int AMODE, bool TRAIN_EPI = false, int XMODE = 0, bool WIDE = false>
 static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     if constexpr (!WIDE && BM == 128 && BN == 128 && WM == 64 && WN == 64) {
-        const long long wgs = (long long)(((a.m_end > 0 ? a.m_end : a.M) - a.m_begin + BM - 1) / BM) * (a.N / BN) * (a.groups > 0 ? a.groups : 1);
+        const long long wgs = (long long)((a.M + BM - 1) / BM) * (a.N / BN) * (a.groups > 0 ? a.groups : 1);
         const int mode = tuning(TP_TUNE_SMALL_GEMM_WAVES);
         if (mode == 8 || (mode == 0 && wgs <= 512))
             return launch_cfg<TI, TO, BM, BN, 32, 64, AMODE, TRAIN_EPI, XMODE, true>(a, stream);
@@ -225,8 +225,7 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
         set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", lds, hipGetErrorString(attr_err));
         return TP_ERR_LAUNCH;
     }
-    const int m_end = a.m_end > 0 ? a.m_end : a.M;
-    const int tiles_m = (m_end - a.m_begin + BM - 1) / BM, tiles_n = a.N / BN;
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
     dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)a.groups, 1);
     hipLaunchKernelGGL(kern, grid, dim3(threads), lds, stream, a, tiles_n, tuning(TP_TUNE_XCD_SWIZZLE));
     return check_launch("gemm_kernel");
@@ -288,11 +287,7 @@ static int launch_types(const GemmArgs& a, hipStream_t stream) {
 // 8.4 + 1.47 K/64 us (profiles/README.md).  Same epilogue, bit-identical results whatever the shape.
 // (d) stream-K (tp_gemm8.hip SK, TP_TUNE_STREAM_K = 2, opt-in): the launch's K-tiles shared evenly by the workgroups; measured
 //   slower than (b) at every batch (stream_k_pays below).
-// (e) full rounds as full tiles + the remaining rows on the 128 x 128-tile kernel (round 3).  A tail tile is not MFMA-bound but
-//   bound by what ONE CU can pull through its load path (~50-60 GB/s: a 128 x 256 half tile of a K = 4096 launch moves 3 MiB in
-//   50-63 us, a 128 x 128 tile 2 MiB in ~44 us), and a tail leaves most CUs idle — so the finer tile, on four times as many CUs
-//   as full tiles would use, finishes first although its main loop is the slower one.  Same epilogue, bit-identical results.
-enum { ROUTE_SMALL = 0, ROUTE_G8 = 1, ROUTE_G8_HALF = 2, ROUTE_G8_SPLIT = 3, ROUTE_G8_SK = 4, ROUTE_G8_SPLIT_SMALL = 5 };
+enum { ROUTE_SMALL = 0, ROUTE_G8 = 1, ROUTE_G8_HALF = 2, ROUTE_G8_SPLIT = 3, ROUTE_G8_SK = 4 };
 // Opt-in only (TP_TUNE_STREAM_K = 2).  The cost model this started with — U K-tiles at the main loop's 1.47 us + one epilogue per
 // tile started + ~14 us for the partial handed over and the one taken in, against the round count of the alternatives —
 // predicted -8 % on the first K/V layer of a 32-image shard; MEASURED: +39 % (0.265 -> 0.369 ms), +25 % per forward at B = 100
@@ -327,16 +322,7 @@ static int gemm_route(const GemmArgs& a, long long* head_rows_out) {
             }
             if (stream_k_pays(a, cost_a < cost_b ? (cost_a < cost_c ? cost_a : cost_c) : (cost_b < cost_c ? cost_b : cost_c))) return ROUTE_G8_SK;
             if (TH >= 64 && cost_c < cost_a - 0.05 && cost_c <= cost_b) return ROUTE_G8_HALF;
-            if (cost_b < cost_a - 0.05) {
-                *head_rows_out = head_rows;
-                // (e): the tail rows as 128 x 128 tiles when they fit ONE wave of the chip at two workgroups per CU and the K
-                // loop is long (K <= 1024: 15 vs 17 us, not worth a second code path); TP_TUNE_SMALL_TAIL 1 = off
-                const long long tail_small = (long long)((a.M - head_rows + 127) / 128) * (a.N / 128);
-                if (tuning(TP_TUNE_SMALL_TAIL) != 1 && a.K >= 2048 && tail_small <= 2 * per && !a.acc_init && !a.attn_mode &&
-                    !(a.flags & TP_LINEAR_NO_STORE))
-                    return ROUTE_G8_SPLIT_SMALL;
-                return ROUTE_G8_SPLIT;
-            }
+            if (cost_b < cost_a - 0.05) { *head_rows_out = head_rows; return ROUTE_G8_SPLIT; }
         }
     }
     if ((a.half_tiles && a.N % 256 == 0) ||
@@ -414,13 +400,6 @@ int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stre
             rest.m_begin = (int)head_rows; rest.half_tiles = 1; rest.tile_counters = nullptr;
             if (int rc = gemm8_launch(in_dtype, out_dtype, head, stream)) return rc;
             return gemm8_launch(in_dtype, out_dtype, rest, stream);
-        }
-        if (route == ROUTE_G8_SPLIT_SMALL) {
-            GemmArgs head = a, rest = a;
-            head.m_end = (int)head_rows;
-            rest.m_begin = (int)head_rows; rest.tile = 128; rest.tile_counters = nullptr;
-            if (int rc = gemm8_launch(in_dtype, out_dtype, head, stream)) return rc;
-            return gemm_launch(in_dtype, out_dtype, rest, stream);       // (tile = 128: routed to the 128-tile kernel below)
         }
         if (route == ROUTE_G8_SK) {
             GemmArgs sk = a; sk.stream_k = 2;
