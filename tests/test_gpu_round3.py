@@ -24,13 +24,14 @@ def _module(params, s, D, dtype, grid=24):
 
 # Stated claim (README / DESIGN §3), measured on MI355X over 16 seeds x s in {2, 3, 4} x {bf16 with fp32 output, fp16}
 # (profiles/r03_parity_seed_sweep.json); metric max|y - y_ref| / max|y_ref| against the fp64 oracle on the SAME rounded
-# operands:
+# operands.  EVERY seed of EVERY configuration <= 1e-3, medians <= 8e-4:
 #   scale_factor 2 — the north_star's gated configuration, attention inside the in-projection epilogues, 5 fp16 roundings in
-#     series on the value path: EVERY seed <= 1e-3 (measured: median 6.5e-4 / 7.3e-4, worst seed 8.2e-4 / 8.5e-4);
+#     series on the value path: measured median 6.8e-4 / 7.2e-4, worst seed 8.4e-4 / 8.8e-4;
 #   scale_factor 3, 4 — the absorbed schedule carries one rounding more (u between the attention kernel and the per-head V
-#     GEMM): median <= 8.5e-4, worst seed <= 1.1e-3 (measured: medians 7.2e-4 .. 8.1e-4, worst seed 1.016e-3), rel-L2 <= 8.5e-4.
-GATES = {2: dict(median=8.0e-4, max=1.0e-3, l2=7.5e-4), 3: dict(median=8.5e-4, max=1.1e-3, l2=8.5e-4),
-         4: dict(median=8.5e-4, max=1.1e-3, l2=8.5e-4)}
+#     GEMM): measured medians 7.1e-4 .. 7.8e-4, worst seed 9.9e-4 (1.016e-3 before the chain weights were centred),
+#     rel-L2 <= 8.2e-4.
+GATES = {2: dict(median=8.0e-4, max=1.0e-3, l2=7.5e-4), 3: dict(median=8.0e-4, max=1.0e-3, l2=8.5e-4),
+         4: dict(median=8.0e-4, max=1.0e-3, l2=8.5e-4)}
 
 
 def test_parity_seed_sweep():
