@@ -191,3 +191,22 @@ def test_release_stream_and_lru_of_the_side_stream_cache():
             assert torch.equal(m((x, xm)), y0)                             # and the stream still works afterwards
         torch.cuda.synchronize()
     assert base >= 1
+
+
+@pytest.mark.parametrize("s", [2, 3])
+def test_side_stream_forms_are_bit_identical(s):
+    """TP_TUNE_Q_SIDE_STREAM 0 (one stream) | 1 (side stream): where the query side runs must not change a bit of the output."""
+    dtype, D, B = torch.bfloat16, 256, 5
+    params = synth.make_params(700 + s, D)
+    x, xm = synth.make_inputs(701 + s, B, dtype)
+    m = _module(params, s, D, dtype)
+    ys = []
+    try:
+        for mode in (0, 1):
+            _capi.set_tuning(_capi.TP_TUNE_Q_SIDE_STREAM, mode)
+            with torch.no_grad():
+                ys.append(m((x.cuda(), xm.cuda())).clone())
+            torch.cuda.synchronize()
+    finally:
+        _capi.set_tuning(_capi.TP_TUNE_Q_SIDE_STREAM, _capi._TUNING_DEFAULTS[_capi.TP_TUNE_Q_SIDE_STREAM])
+    assert torch.equal(ys[0], ys[1])

@@ -722,7 +722,16 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     const long long hkv_gs = hkv_split ? kvE * 2 : (long long)E * 2;    // bytes from the K half to the V half
 
     // tile-queue heads of the persistent GEMM launches: 64 ints per launch (<= 16 launches), zeroed once per forward
-    int* counters = tuning(TP_TUNE_DYNAMIC_TILES) ? (int*)(ws + W.counters) : nullptr;
+    // A persistent launch reads its queue head only when it has more tiles than workgroups (tp_gemm8.hip: "one tile per workgroup"
+    // otherwise).  A batch so small that NO launch of the forward can (counted in 128-row half tiles, the finest the routes use, on
+    // the widest weight of either side) needs neither the heads nor the fill kernel in front of them — ~10 us of a 0.13 ms forward.
+    bool queues_possible = true;
+    if (!train) {
+        const long long nwg = gemm8_persistent_cus();
+        const long long cols_q = std::max<long long>(D / 256, plan.absorb ? 8 * E / 256 : E / 256);
+        queues_possible = (rows_kv + 127) / 128 * (2 * E / 256) > nwg || (rows_q + 127) / 128 * cols_q > nwg;
+    }
+    int* counters = (tuning(TP_TUNE_DYNAMIC_TILES) && queues_possible) ? (int*)(ws + W.counters) : nullptr;
     if (counters) {
         hipError_t e = hipMemsetAsync(counters, 0, kCounterBytes, stream);
         if (e != hipSuccess) { set_error("tp_forward: hipMemsetAsync: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
