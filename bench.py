@@ -362,19 +362,7 @@ def run_e2e(args, world, rank, device, dtype, dist):
         return out, float(el.item())
 
     with torch.no_grad():
-        per_transport = {}
-        if len(transports) > 1:              # auto: the same protocol once per transport; the faster one is the job's
-            for t_name in transports:
-                cur["t"] = t_name
-                y, el = timed_region()
-                per_transport[t_name] = el
-            cur["t"] = min(per_transport, key=per_transport.get)     # (max-reduced times: every rank picks the same)
-            elapsed = per_transport[cur["t"]]
-        else:
-            y, elapsed = timed_region()
-            if transports:
-                per_transport[cur["t"]] = elapsed
-        chosen = cur["t"]
+        y, elapsed = timed_region()               # (no collective on this path: every rank prefills its own samples)
         step(timed=True)
         torch.cuda.synchronize(device)
     assert y.shape == (b, T, D) and torch.isfinite(y[:1].float()).all()

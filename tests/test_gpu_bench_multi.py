@@ -65,3 +65,15 @@ def test_hd_line_ragged():
     d = _run(["--hd", "--hd-images", "3"], nproc=2)              # 27 crops over 2 ranks: 14 + 13
     assert d["config"]["global_batch"] == 27 and d["config"]["per_gpu_batch"] == 14
     assert "ragged" in d["multi_gpu"]["collective"]
+
+
+def test_e2e_line_single_rank():
+    """`bench.py --e2e` (tower -> projector -> prefill) on one rank with a two-layer prefill: the path must run and print its
+    one line (a NameError lived here for half a round because nothing exercised it)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--e2e", "--e2e-batch", "2", "--e2e-layers", "2", "--steps", "1", "--warmup", "1"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["unit"] == "tokens/s" and d["value"] > 0 and d["split_ms"]["projector_hip"] > 0

@@ -17,6 +17,7 @@ namespace tp {
 namespace {
 
 constexpr int QE = kEmbed;             // matrix order
+static_assert(QE == 1024, "one thread per row in qr_center_kernel / qr_vec_kernel (1024-thread blocks)");
 constexpr int QP = kEmbed + 1;         // row pitch: E columns of W2c + the b2c column carried through the reflections
 
 __device__ __forceinline__ double block_sum_1024(double v, double* red) {
@@ -66,24 +67,29 @@ qr_vec_kernel(double* __restrict__ Aall, double* __restrict__ Vall, double* __re
     if (r == 0) betas[blockIdx.x] = vtv > 0.0 ? 2.0 / vtv : 0.0;
 }
 
-// A[j.., c] -= beta v (v^T A[j.., c]) for the columns c > j (c = E: the bias column).  64 columns x 4 row slices per block.
+// A[j.., c] -= beta v (v^T A[j.., c]) for the columns c > j (c = E: the bias column).  16 columns x 16 row slices per block: 128-byte
+// row segments, and 64 blocks per matrix while the trailing block is wide (the factorisation is latency-bound on ~1000 dependent
+// launch pairs; with 64-column blocks only 16 workgroups per matrix were in flight).
 __global__ void __launch_bounds__(256)
 qr_apply_kernel(double* __restrict__ Aall, const double* __restrict__ Vall, const double* __restrict__ betas, const int j) {
-    __shared__ double part[4][64];
+    __shared__ double part[16][17];
     double* A = Aall + (long long)blockIdx.y * QE * QP;
     const double* V = Vall + (long long)blockIdx.y * QE;
     const double beta = betas[blockIdx.y];
-    const int cl = threadIdx.x & 63, rs = threadIdx.x >> 6;
-    const int c = j + 1 + blockIdx.x * 64 + cl;
+    const int cl = threadIdx.x & 15, rs = threadIdx.x >> 4;
+    const int c = j + 1 + blockIdx.x * 16 + cl;
     const bool ok = c <= QE;
     double w = 0.0;
     if (ok)
-        for (int r = j + rs; r < QE; r += 4) w = fma(V[r], A[(long long)r * QP + c], w);
+        for (int r = j + rs; r < QE; r += 16) w = fma(V[r], A[(long long)r * QP + c], w);
     part[rs][cl] = w;
     __syncthreads();
-    w = beta * (((part[0][cl] + part[1][cl]) + part[2][cl]) + part[3][cl]);
+    w = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w += part[i][cl];           // fixed order: the factor does not depend on the launch geometry
+    w *= beta;
     if (ok)
-        for (int r = j + rs; r < QE; r += 4) A[(long long)r * QP + c] -= w * V[r];
+        for (int r = j + rs; r < QE; r += 16) A[(long long)r * QP + c] -= w * V[r];
 }
 
 // R (upper triangle, fp16 — the statistics GEMM's weight, zeros below the diagonal) and c~ = the transformed bias column (fp32)
@@ -130,7 +136,7 @@ int pack_qr_factor_launch(void* scratch, int nmat, hipStream_t stream) {
     double* betas = V + (size_t)nmat * QE;
     for (int j = 0; j < QE - 1; ++j) {
         hipLaunchKernelGGL(qr_vec_kernel, dim3(nmat), dim3(1024), 0, stream, A, V, betas, j);
-        hipLaunchKernelGGL(qr_apply_kernel, dim3((QE - j + 63) / 64, nmat), dim3(256), 0, stream, A, V, betas, j);
+        hipLaunchKernelGGL(qr_apply_kernel, dim3((QE - j + 15) / 16, nmat), dim3(256), 0, stream, A, V, betas, j);
     }
     return check_launch("qr_apply_kernel");
 }
