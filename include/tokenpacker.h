@@ -437,7 +437,9 @@ enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all hal
                                      batch it travels in (what rounds 1-2 shipped; the reference's eager PyTorch does not have that
                                      property either). */
        TP_TUNE_SMALL_GEMM_WAVES = 12, /* the 128 x 128-tile kernel as 4 waves of 64 x 64 or 8 waves of 32 x 64 (bit-identical): 0 (default)
-                                     auto by the number of workgroups of the launch | 4 | 8 */
+                                     auto by the number of workgroups of the launch | 4 | 8.  A launch of the 8-wave form with at
+                                     most one workgroup per CU keeps FOUR K-slabs in its LDS ring (three in flight, counted vmcnt;
+                                     round 3: a one-image forward 0.132 -> 0.128 ms) | 9: 8 waves with the double buffer (A/B) */
        TP_TUNE_STREAM_K = 13,     /* stream-K decomposition of a persistent GEMM launch whose tile count is not a multiple of the CU
                                      count (tp_gemm8.hip SK): the launch's K-tiles are shared evenly, a tile cut in two hands one fp32
                                      partial over between neighbouring workgroups (write-through slab + flag, fixed summation order).

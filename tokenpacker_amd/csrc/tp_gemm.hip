@@ -26,16 +26,20 @@
 
 namespace tp {
 
-template <int BM, int BN>
-constexpr int gemm_lds_bytes() { return 2 * (BM + BN) * ROW_BYTES; }
+template <int BM, int BN, int NST = 2>
+constexpr int gemm_lds_bytes() { return NST * (BM + BN) * ROW_BYTES; }
 
 // STRIDED_A: A rows live in batches of rows_per_batch rows with a batch stride (the CLIP tower's
 // [:,1:] slices) — only the first K/V layer needs it, which also gives that launch (45 % of the path's
 // FLOPs) its own kernel symbol in profiles.
 // TI: operand element type (bf16 / fp16) — selects the MFMA;  TO: output element type (bf16 / fp16 / float).
-template <typename TI, typename TO, int BM, int BN, int WM, int WN, int AMODE, bool TRAIN_EPI, int XMODE = 0>   // XMODE: tp_gemm8.hip
+// NST: K-slab buffers in the LDS ring; NST - 1 slabs are in flight while one is consumed.  2 = the double buffer every full-chip
+// launch uses (two workgroups per CU hide each other's slab round trip); 4 = the small-batch form (one workgroup per CU, 8 waves:
+// a K step is ~0.1 us of MFMA behind a ~0.5 us slab round trip — with one slab in flight the K loop IS that round trip).
+template <typename TI, typename TO, int BM, int BN, int WM, int WN, int AMODE, bool TRAIN_EPI, int XMODE = 0, int NST = 2>   // XMODE: tp_gemm8.hip
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
+    static_assert(NST == 2 || NST == 4, "ring depth");
     using T = TI;
     using X8 = typename Vec<TI>::x8;
     constexpr int NWM = BM / WM, NWN = BN / WN, NW = NWM * NWN;
@@ -116,6 +120,10 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
     // the first K-slabs go out before anything else touches memory: the parameter loads below then wait WITH them
     const int nk = p.K / BK - kt0;
     issue(0, 0);
+    if constexpr (NST > 2) {
+#pragma unroll
+        for (int s_ = 1; s_ < NST - 1; ++s_) if (s_ < nk) issue(s_, s_);
+    }
     f32x4 acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -160,13 +168,24 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
     }
 
     for (int kt = 0; kt < nk; ++kt) {
-        // slab kt has landed for every wave; every wave is done reading the other buffer
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        // slab kt has landed for every wave; every wave is done reading the buffer the next issue overwrites
+        if constexpr (NST == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        } else {
+            // slabs kt + 1 .. kt + NST - 2 stay in flight (CPW DMA instructions per wave each; everything older — slab kt and
+            // the epilogue parameters fetched behind the prologue — has retired by then: vmcnt retires in order)
+            const int ahead = nk - 1 - kt;
+            if (ahead >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * CPW) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                  // (a __syncthreads() would drain vmcnt)
+        }
+        if (kt + NST - 1 < nk) issue(kt + NST - 1, (kt + NST - 1) & (NST - 1));
 
-        const char* sA = smem + (kt & 1) * STAGE + wm * WM * ROW_BYTES;
-        const char* sB = smem + (kt & 1) * STAGE + A_BYTES + wn * WN * ROW_BYTES;
+        const char* sA = smem + (kt & (NST - 1)) * STAGE + wm * WM * ROW_BYTES;
+        const char* sB = smem + (kt & (NST - 1)) * STAGE + A_BYTES + wn * WN * ROW_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int off = ks ? frag_off1 : frag_off0;
@@ -204,17 +223,22 @@ int gemm_pick_tile(int M, int N, int forced, int groups) {
 // The 128 x 128 tile exists as 4 waves of 64 x 64 (two workgroups = 8 waves per CU) and as 8 waves of 32 x 64 (16 waves per CU):
 // a launch that leaves most CUs with ONE workgroup (a small batch) runs one wave per SIMD with the first and hides neither
 // its LDS nor its barrier latency.  Same MFMA shape, same K order: bit-identical.  WIDE selects the 8-wave form.
-template <typename TI, typename TO, int BM, int BN, int WM, int WN, int AMODE, bool TRAIN_EPI = false, int XMODE = 0, bool WIDE = false>
+template <typename TI, typename TO, int BM, int BN, int WM, int WN, int AMODE, bool TRAIN_EPI = false, int XMODE = 0, bool WIDE = false, int NST = 2>
 static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     if constexpr (!WIDE && BM == 128 && BN == 128 && WM == 64 && WN == 64) {
         const long long wgs = (long long)((a.M + BM - 1) / BM) * (a.N / BN) * (a.groups > 0 ? a.groups : 1);
         const int mode = tuning(TP_TUNE_SMALL_GEMM_WAVES);
-        if (mode == 8 || (mode == 0 && wgs <= 512))
+        if (mode == 8 || mode == 9 || (mode == 0 && wgs <= 512)) {
+            // at most one workgroup per CU: the four-slab ring (mode 9 forces the double buffer for an A/B, bit-identical)
+            if constexpr (!TRAIN_EPI)
+                if (mode != 9 && wgs <= gemm8_persistent_cus())
+                    return launch_cfg<TI, TO, BM, BN, 32, 64, AMODE, TRAIN_EPI, XMODE, true, 4>(a, stream);
             return launch_cfg<TI, TO, BM, BN, 32, 64, AMODE, TRAIN_EPI, XMODE, true>(a, stream);
+        }
     }
-    constexpr int lds = gemm_lds_bytes<BM, BN>();
+    constexpr int lds = gemm_lds_bytes<BM, BN, NST>();
     constexpr int threads = (BM / WM) * (BN / WN) * 64;
-    auto kern = gemm_kernel<TI, TO, BM, BN, WM, WN, AMODE, TRAIN_EPI, XMODE>;
+    auto kern = gemm_kernel<TI, TO, BM, BN, WM, WN, AMODE, TRAIN_EPI, XMODE, NST>;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [&] {
