@@ -16,7 +16,7 @@ def run(tag):
             torch.cuda.synchronize(); print(tag, "B=%d" % B, "%.4f ms" % ((time.perf_counter() - t) / 200 * 1e3), flush=True)
 run("new")
 _capi._lib = None
-_capi.load_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "old", "libtokenpacker_hip_old.so"))
+_capi.load_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "old", "libtokenpacker_hip_old.so"))    # built by hand from an earlier tp_gemm.hip (not kept in the tree)
 run("old")
 _capi._lib = None
 _capi.load_library()
