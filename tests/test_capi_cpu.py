@@ -132,6 +132,8 @@ def test_train_hd_and_parts_entry_points_reject_bad_arguments():
     assert lib.tp_debug_count_saturated(ctypes.byref(d), None, 0, None, None) == E
     assert lib.tp_hd_slice(None, 100, 100, 1, 1, 336, 336, 0, 0, None, 336, None) == E
     assert lib.tp_test_occupy_cus(0, 1, None, None) == E
+    assert lib.tp_test_pack_qr(None, None, None, None, None, None, None) == E          # (test hook of the pack-time QR)
+    assert lib.tp_test_pack_qr_scratch_bytes() == 1024 * 1025 * 8 + 1024 * 8 + 256
     # the weight-gradient contraction on its own
     assert lib.tp_wgrad_workspace_bytes(1024, 4096) == 16 * 1024 * 4096 * 4
     assert lib.tp_wgrad_workspace_bytes(0, 4096) == 0
