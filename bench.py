@@ -47,6 +47,9 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
                  pid), the NCCL_* / HSA_* variables that are set, the gather mode, forward-only / gather-only times,
                  and with --probe-other-gather the transport not selected.
   stages_ms    — per-kernel breakdown of one forward.
+  memory_side  — mlp0_gelu / kv_layer2_stats: a launch that stores 128 KiB per 23-us tile over one that stores nothing; tells a
+                 run in the node's slow memory-side power state (mid-sized batches, profiles/r03u_mid_batch_anomaly.txt) from a
+                 normal one.
 """
 from __future__ import annotations
 
@@ -731,6 +734,11 @@ def main():
                          "algorithmic_bytes": float(B * 576 * 4096 * 2 + 2048 * 4096 * 2 + B * 576 * 2048 * 2)},
             "stages_ms": {n: round(v, 4) for n, v in zip(_capi.STAGE_NAMES, stage_ms)},
         }
+        # the store-heavy short-K launch over the launch that stores nothing: 0.8 - 0.9 normally, ~1.3 in the slow memory-side
+        # power state some boxes put a 32 ... 128-image forward in (profiles/r03u_mid_batch_anomaly.txt)
+        if stage_ms[2] > 0 and s == 2:
+            out["memory_side"] = {"mlp0_over_statistics": round(stage_ms[8] / stage_ms[2], 3),
+                                  "note": "mlp0_gelu / kv_layer2_stats of this rank's forward; ~0.85 normal, >= 1.2 = the node's slow memory-side power state"}
         if gather:
             # max over ranks; gather_only moves (N-1)/N of [total, M, D] into every rank per step
             out["multi_gpu"] = {"forward_only_ms": round(float(t[1].item()), 4),
