@@ -387,6 +387,12 @@ int tp_debug_count_saturated(const tp_desc* desc, const void* workspace, size_t 
 int tp_test_occupy_cus(int workgroups, int microseconds, void* scratch_int, void* stream);
 /* ---- test hook: entries of the per-caller-stream side-stream cache (tp_release_stream, LRU eviction) */
 int tp_test_side_cache_size(void);
+/* ---- test hook: launches of the pair GEMM kernel (tp_gemm_pair.hip) issued by this process so far — lets a test prove that the
+ * launch it compares against the other kernels really took the pair route (TP_TUNE_PAIR_GEMM) */
+long long tp_test_pair_launch_count(void);
+/* ---- test hook: workgroups of the pair kernel the runtime admits per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor;
+ * the design needs 2); negative on error */
+int tp_test_pair_occupancy(void);
 /* ---- test hook: the pack-time factorisation behind TP_TUNE_TRI_STATS on ONE layer.  w2 [1024][1024] fp16 and b2 [1024] fp32
  * (or NULL) in; r [1024][1024] fp16 (upper triangular), c_tilde [1024] fp32 and wbar [1025] fp32 (column means of w2, then
  * mean(b2)) out, with  sum_n ((w2 h + b2)_n - mean)^2 = || r h + c_tilde ||^2  for every h.  scratch: device memory of
@@ -452,7 +458,13 @@ enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all hal
                                      pack time): var = ||R h + c~||^2 / E, a sum of squares, on 40 of the 64 (N-tile, K-tile) pairs; the
                                      consumers use centred chain weights (W'·W2c, W'·b2c) and need no mean at all | 1: the full
                                      statistics GEMM on W2 with (mean, M2), as rounds 1-2 shipped */
-       TP_TUNE_COUNT_ = 15 };
+       TP_TUNE_PAIR_GEMM = 15,    /* the 256 x 128-tile "pair" kernel (tp_gemm_pair.hip: two co-resident 4-wave workgroups per CU, a tile's
+                                     epilogue under the other workgroup's MFMAs; bit-identical to the other GEMM kernels): 0 (default) for
+                                     every launch it supports that fills the chip at least 1.5 times with its 512 workgroups | 1 never |
+                                     2 wherever it is supported */
+       TP_TUNE_PAIR_STAGGER = 16, /* percent (default 100) of half a tile period by which the second workgroup of each CU starts late in
+                                     a pair-kernel launch (0: both start together — their epilogues then coincide for ever) */
+       TP_TUNE_COUNT_ = 17 };
 int tp_set_tuning(int key, int value);
 int tp_get_tuning(int key);                  /* the library's current value (not a binding's shadow copy); -1: bad key */
 

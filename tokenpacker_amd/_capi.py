@@ -25,6 +25,9 @@ TP_TUNE_SPLIT_K = 11
 TP_TUNE_SMALL_GEMM_WAVES = 12
 TP_TUNE_STREAM_K = 13
 TP_TUNE_TRI_STATS = 14
+TP_TUNE_PAIR_GEMM = 15
+TP_TUNE_PAIR_STAGGER = 16
+TP_TUNE_COUNT = 17
 TP_WGRAD_X_TRANSPOSED = 1
 TP_NUM_STAGES = 10
 TP_NUM_DEBUG_BUFFERS = 9
@@ -44,7 +47,7 @@ EXPORTED_SYMBOLS = (
     "tp_forward_parts", "tp_forward_train_parts", "tp_backward_parts", "tp_test_occupy_cus", "tp_hd_slice",
     "tp_wgrad", "tp_wgrad_workspace_bytes", "tp_packed_status_offset", "tp_debug_count_saturated",
     "tp_region_attention_absorbed", "tp_forward_masked",
-    "tp_get_tuning", "tp_release_stream", "tp_test_side_cache_size", "tp_test_pack_qr", "tp_test_pack_qr_scratch_bytes",
+    "tp_get_tuning", "tp_release_stream", "tp_test_side_cache_size", "tp_test_pair_launch_count", "tp_test_pair_occupancy", "tp_test_pack_qr", "tp_test_pack_qr_scratch_bytes",
     "tp_linear_sk_workspace_bytes", "tp_gather_alloc_flags", "tp_gather_free_flags", "tp_gather_export", "tp_gather_open", "tp_gather_close", "tp_gather_push", "tp_gather_sync",
 )
 
@@ -160,6 +163,10 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.tp_release_stream.argtypes = [c_void_p]
     lib.tp_test_side_cache_size.restype = c_int
     lib.tp_test_side_cache_size.argtypes = []
+    lib.tp_test_pair_launch_count.restype = c_int64
+    lib.tp_test_pair_launch_count.argtypes = []
+    lib.tp_test_pair_occupancy.restype = c_int
+    lib.tp_test_pair_occupancy.argtypes = []
     lib.tp_test_pack_qr_scratch_bytes.restype = c_size_t
     lib.tp_test_pack_qr_scratch_bytes.argtypes = []
     lib.tp_test_pack_qr.restype = c_int
@@ -251,7 +258,8 @@ def strides3(st) -> "ctypes.Array":
 # the library's defaults (tests reset the table to these)
 _TUNING_DEFAULTS = {TP_TUNE_GEMM_TILE: 0, TP_TUNE_XCD_SWIZZLE: 1, TP_TUNE_GEMM_KERNEL: 0, TP_TUNE_FOLD_OUT_PROJ: 0,
                     TP_TUNE_DYNAMIC_TILES: 1, TP_TUNE_Q_SIDE_STREAM: 1, TP_TUNE_RESERVE_CUS: 0, TP_TUNE_ABSORB_KV: 0, TP_TUNE_FUSE_KV_LN: 1,
-                    TP_TUNE_FUSE_ATTN: 0, TP_TUNE_LN_MERGE: 0, TP_TUNE_SPLIT_K: 0, TP_TUNE_SMALL_GEMM_WAVES: 0, TP_TUNE_STREAM_K: 0, TP_TUNE_TRI_STATS: 0}
+                    TP_TUNE_FUSE_ATTN: 0, TP_TUNE_LN_MERGE: 0, TP_TUNE_SPLIT_K: 0, TP_TUNE_SMALL_GEMM_WAVES: 0, TP_TUNE_STREAM_K: 0, TP_TUNE_TRI_STATS: 0,
+                    TP_TUNE_PAIR_GEMM: 0, TP_TUNE_PAIR_STAGGER: 100}
 
 
 def set_tuning(key: int, value: int) -> None:
@@ -263,7 +271,7 @@ def get_tuning(key: int) -> int:
     """The library's current value of a tuning key (``tp_get_tuning``: the table itself, not a copy kept on this side —
     another binding or a direct ``tp_set_tuning`` call cannot make it lie)."""
     v = load_library().tp_get_tuning(key)
-    if v == -1 and not (0 <= key < 16):
+    if v == -1 and not (0 <= key < TP_TUNE_COUNT):
         raise ValueError(f"tp_get_tuning: {last_error()}")
     return v
 

@@ -40,7 +40,7 @@ int check_launch(const char* what) {
     return TP_OK;
 }
 
-static std::atomic<int> g_tuning[TP_TUNE_COUNT_] = {{0}, {1}, {0}, {0}, {1}, {1}, {0}, {0}, {1}, {0}, {0}, {0}, {0}, {0}, {0}};   // [6] RESERVE_CUS, [7] ABSORB_KV, [8] FUSE_KV_LN
+static std::atomic<int> g_tuning[TP_TUNE_COUNT_] = {{0}, {1}, {0}, {0}, {1}, {1}, {0}, {0}, {1}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {100}};   // [6] RESERVE_CUS, [7] ABSORB_KV, [8] FUSE_KV_LN
 int tuning(int key) { return (key >= 0 && key < TP_TUNE_COUNT_) ? g_tuning[key].load() : 0; }
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
@@ -1034,6 +1034,9 @@ int tp_forward_staged(const tp_desc* desc, const void* x, const int64_t x_stride
 int tp_release_stream(void* stream) { return release_stream_state((hipStream_t)stream); }
 
 int tp_test_side_cache_size(void) { return side_cache_size(); }
+
+long long tp_test_pair_launch_count(void) { return gemm_pair_launch_count(); }
+int tp_test_pair_occupancy(void) { return gemm_pair_occupancy(); }
 
 size_t tp_test_pack_qr_scratch_bytes(void) { return pack_qr_scratch_bytes(1); }
 

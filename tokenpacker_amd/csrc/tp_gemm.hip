@@ -364,8 +364,21 @@ static int gemm_route(const GemmArgs& a, long long* head_rows_out) {
     return ROUTE_SMALL;
 }
 
+// Whether gemm_launch sends `a` to the pair kernel (tp_gemm_pair.hip): a launch it supports, nothing forced by the caller or the
+// tuning table, and enough 256 x 128 tiles that both workgroups of a CU have work for most of the launch.
+static bool gemm_takes_pair_route(int in_dtype, int out_dtype, const GemmArgs& a) {
+    const int mode = tuning(TP_TUNE_PAIR_GEMM);
+    if (mode == 1 || a.tile != 0 || tuning(TP_TUNE_GEMM_TILE) != 0 || tuning(TP_TUNE_GEMM_KERNEL) != 0 || a.stream_k == 2) return false;
+    if (!gemm_pair_supports(in_dtype, out_dtype, a)) return false;
+    if (mode == 2) return true;
+    const long long tiles = (long long)((a.M + 255) / 256) * (a.N / 128) * (a.groups > 0 ? a.groups : 1);
+    return tiles * 2 >= 3ll * gemm_pair_workgroups();
+}
+
 bool gemm_uses_small_kernel(const GemmArgs& a) {
     long long h = 0;
+    // (the LayerNorm-fold launches that ask are fp16 in / fp16 out)
+    if (a.tt_rows == 0 && !a.stats_parts && gemm_takes_pair_route(TP_F16, TP_F16, a)) return false;
     return a.tt_rows == 0 && gemm_route(a, &h) == ROUTE_SMALL;
 }
 
@@ -407,6 +420,7 @@ int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stre
         set_error("tp gemm: bad row window [%d, %d) of %d rows", a.m_begin, a.m_end, a.M);
         return TP_ERR_INVALID_ARG;
     }
+    if (gemm_takes_pair_route(in_dtype, out_dtype, a)) return gemm_pair_launch(in_dtype, out_dtype, a, stream);
     {
         long long head_rows = 0;
         const int route = gemm_route(a, &head_rows);

@@ -120,7 +120,7 @@ __device__ __forceinline__ float sat_track(float m, float a, float b) {
 __device__ __forceinline__ void sat_report(const GemmArgs& p, float sat_max) {
     // 65520 = the smallest magnitude IEEE round-to-nearest turns into an fp16 inf (what the reference would have produced)
     if (p.sat_flag && __builtin_amdgcn_ballot_w64(!(sat_max < 65520.f)) != 0) {
-        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)
+        if ((threadIdx.x & 63) == 0)                   // (every lane is active here; mbcnt would be hoisted into a register the K loops lack)
             __hip_atomic_fetch_or(p.sat_flag, p.sat_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -128,7 +128,10 @@ __device__ __forceinline__ void sat_report(const GemmArgs& p, float sat_max) {
 // TRAIN_EPI compiles in the two training-only epilogue features (TP_LINEAR_SAVE_PRE, TP_LINEAR_GELU_BWD); the
 // inference kernels are instantiated without them so that their register budget is not taxed.
 // STATS_ONLY (TP_LINEAR_NO_STORE): the row statistics of the unrounded result are the only output — no conversion, no store.
-template <typename TO, int BM, int BN, int WM, int WN, bool LDS_PARAMS = false, bool TRAIN_EPI = false, bool STATS_ONLY = false>
+// LAZY_PAR (with LDS_PARAMS; tp_gemm_pair.hip): bias / colsum and the rows' (mean, rstd at lds_par + 8 BN + 8 row) are read from
+// LDS at the point of use instead of up front — 48 registers less across the epilogue (same values, same arithmetic).
+template <typename TO, int BM, int BN, int WM, int WN, bool LDS_PARAMS = false, bool TRAIN_EPI = false, bool STATS_ONLY = false,
+          bool LAZY_PAR = false>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], const GemmArgs& p, const int g,
                                               const int m0, const int n0, const int tile_n, const int wm,
                                               const int wn, const int lane, const int tid,
@@ -150,8 +153,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
     const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
         (void*)Cg, 0, (int)(unsigned)((long long)p.M * p.ldc * (long long)sizeof(TO)), 0x00020000);
 
+    static_assert(!LAZY_PAR || LDS_PARAMS, "LAZY_PAR reads the parameters from LDS");
     f32x4 bias_v[FN], csum_v[FN];
-    if constexpr (LDS_PARAMS) {
+    const int lc_lazy = wn * WN + (lane >> 4) * 4;     // column inside the tile
+    if constexpr (LAZY_PAR) {
+    } else if constexpr (LDS_PARAMS) {
         const int lc = wn * WN + (lane >> 4) * 4;      // column inside the tile
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
@@ -183,7 +189,12 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * WM + i * 16 + (lane & 15);
         const bool row_ok = m < p.M;
-        const float mu = mean_rstd[i].x, rstd = mean_rstd[i].y;
+        float mu = mean_rstd[i].x, rstd = mean_rstd[i].y;
+        if constexpr (LAZY_PAR) {
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            const f32x2_t mr = *(const f32x2_t*)(lds_par + 2 * BN * 4 + (wm * WM + i * 16 + (lane & 15)) * 8);
+            mu = mr[0]; rstd = mr[1];
+        }
 #pragma unroll
         for (int vs = 0; vs < VW; ++vs) {
             float s1 = 0.f, s2 = 0.f, pivot = 0.f;
@@ -196,8 +207,18 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
             for (int jj = 0; jj < FNV; jj += 2) {
                 const int j0 = vs * FNV + jj, j1 = j0 + 1;
                 f32x4 v0 = acc[i][j0], v1 = acc[i][j1];
+                if constexpr (LAZY_PAR) {
+                    if (flags & TP_LINEAR_LN_FOLD) {
+                        const f32x4 c0 = *(const f32x4*)(lds_par + BN * 4 + (lc_lazy + j0 * 16) * 4);
+                        const f32x4 c1 = *(const f32x4*)(lds_par + BN * 4 + (lc_lazy + j1 * 16) * 4);
+                        v0 = rstd * (v0 - mu * c0); v1 = rstd * (v1 - mu * c1);
+                    }
+                    v0 += *(const f32x4*)(lds_par + (lc_lazy + j0 * 16) * 4);
+                    v1 += *(const f32x4*)(lds_par + (lc_lazy + j1 * 16) * 4);
+                } else {
                 if (flags & TP_LINEAR_LN_FOLD) { v0 = rstd * (v0 - mu * csum_v[j0]); v1 = rstd * (v1 - mu * csum_v[j1]); }
                 v0 += bias_v[j0]; v1 += bias_v[j1];
+                }
                 if constexpr (TRAIN_EPI) {
                 if (flags & TP_LINEAR_GELU_BWD) {          // backward of a GELU layer: dZ = dA * gelu'(Z), Z fp16 [M, ldz]
                     const f16_t* zrow = (const f16_t*)(p.Z + g * p.z_gs) + (long long)(row_ok ? m : 0) * p.ldz + col_base;
@@ -288,6 +309,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
             constexpr float inv_nl = 1.0f / (4 * FNV);
             rs1[i][vs] = fmaf(s1, inv_nl, pivot); rs2[i][vs] = fmaf(-s1 * inv_nl, s1, s2);
         }
+        // (pair kernel: one fragment row at a time — interleaved rows cost registers the prefetched parameters of the next tile need)
+        if constexpr (LAZY_PAR) __builtin_amdgcn_sched_barrier(0);
     }
 
     // (not in the training epilogues: their register budget is exhausted — one more live value spills; a training forward
@@ -357,7 +380,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
 // the kernel a batch size selects.  `lds_q` (persistent kernel): the tile's queries [BM / 4][BN] fp16 staged in LDS;
 // `lds_par`: bias[BN] | colsum[BN] staged by the caller, and for the V launch the tile's logits [BN / 128][BM] at +LG_OFF.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool LDS_PARAMS>
+// Q_LDS: the tile's queries are staged in LDS (`lds_q`); false: read from GemmArgs::attn_q by the epilogue (tp_gemm_pair.hip)
+template <int BM, int BN, int WM, int WN, bool LDS_PARAMS, bool Q_LDS = LDS_PARAMS>
 __device__ __forceinline__ void attn_logits_epilogue(f32x4 (&acc)[WM / 16][WN / 16], const GemmArgs& p, const int g,
                                                      const int m0, const int n0, const int wm, const int wn,
                                                      const int lane, const int tid, const float2 (&mean_rstd)[WM / 16],
@@ -379,6 +403,20 @@ __device__ __forceinline__ void attn_logits_epilogue(f32x4 (&acc)[WM / 16][WN / 
             csum_v[j] = *(const f32x4*)(colsum + col_base + j * 16);
         }
     }
+    // Q_LDS = false with staged parameters (tp_gemm_pair.hip): every query fragment of the wave's rows is fetched up front — one
+    // memory round trip instead of one per fragment row (the fragment registers of the K loop are free here)
+    constexpr bool Q_AHEAD = LDS_PARAMS && !Q_LDS;
+    f16x4 qv[Q_AHEAD ? FM : 1][Q_AHEAD ? FN : 1];
+    if constexpr (Q_AHEAD) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            int m = m0 + wm * WM + i * 16 + r16;
+            m = m < p.M ? m : p.M - 1;
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                qv[i][j] = *(const f16x4*)(p.attn_q + (long long)(m >> 2) * p.attn_ldq_bytes + (col_base + j * 16) * 2);
+        }
+    }
     float part[FM];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -393,7 +431,9 @@ __device__ __forceinline__ void attn_logits_epilogue(f32x4 (&acc)[WM / 16][WN / 
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             f16x4 q;
-            if constexpr (LDS_PARAMS) {
+            if constexpr (Q_AHEAD) {
+                q = qv[i][j];
+            } else if constexpr (Q_LDS) {
                 q = *(const f16x4*)(lds_q + (rr >> 2) * (BN * 2) + (wn * WN + j * 16 + cg * 4) * 2);
             } else {
                 int m = m0 + rr;

@@ -144,6 +144,12 @@ __device__ __forceinline__ float2 ln_merge_slabs(const float* __restrict__ pg, l
 int gemm_pick_tile(int M, int N, int forced, int groups = 1);     // -> 128 or 256
 // 256x256x64 ping-pong kernel (tp_gemm8.hip); gemm_launch routes tile-256 problems to it
 int gemm8_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream);
+// 256x128x64 pair kernel (tp_gemm_pair.hip): two co-resident 4-wave workgroups per CU, epilogues under the other's MFMAs
+bool gemm_pair_supports(int in_dtype, int out_dtype, const GemmArgs& a);
+int gemm_pair_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream);
+long long gemm_pair_launch_count();
+int gemm_pair_occupancy();
+int gemm_pair_workgroups();                            // workgroups of a pair launch (two per CU)
 int gemm8_persistent_cus();                            // workgroups of a persistent launch (CUs rounded down to 8)
 constexpr int kStreamKMaxWorkgroups = 256;             // slabs / flags of the stream-K hand-over are sized for this many workgroups
 constexpr size_t kStreamKSlabBytes = (size_t)kStreamKMaxWorkgroups * 256 * 256 * 4;     // 64 MiB

@@ -19,7 +19,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tokenpacker_amd import _capi  # noqa: E402
 
 G, S, F = _capi.TP_LINEAR_GELU, _capi.TP_LINEAR_ROW_STATS, _capi.TP_LINEAR_LN_FOLD
-VARIANTS = [("tile128", 128, 0), ("twophase256", 256, 1), ("pp_persistent", 256, 0), ("pp_onetile", 256, 2)]
+# (name, forced tile, TP_TUNE_GEMM_KERNEL, TP_TUNE_PAIR_GEMM, TP_TUNE_PAIR_STAGGER)
+VARIANTS = [("tile128", 128, 0, 1, 100), ("pp_persistent", 256, 0, 1, 100), ("pair", 0, 0, 2, 100), ("pair_nostagger", 0, 0, 2, 0)]
 
 
 def shapes(B, s, D):
@@ -56,7 +57,7 @@ def main():
         stats = torch.empty(8 * M * 2, device="cuda")
         fl = 2.0 * M * N * K
 
-        def make(tile, kern):
+        def make(tile, kern, pair, stagger):
             a = _capi.tp_linear_args()
             a.M, a.N, a.K, a.flags = M, N, K, flags
             a.dtype = _capi.TP_BF16 if dt == torch.bfloat16 else _capi.TP_F16
@@ -67,11 +68,13 @@ def main():
 
             def run():
                 _capi.set_tuning(_capi.TP_TUNE_GEMM_KERNEL, kern)
+                _capi.set_tuning(_capi.TP_TUNE_PAIR_GEMM, pair)
+                _capi.set_tuning(_capi.TP_TUNE_PAIR_STAGGER, stagger)
                 rc = lib.tp_linear(ctypes.byref(a), st)
                 assert rc == 0, _capi.last_error()
             return run
 
-        runs = [(v, make(t, k)) for v, t, k in VARIANTS if N % t == 0]
+        runs = [(v, make(t, k, pr, sg)) for v, t, k, pr, sg in VARIANTS if t == 0 or N % t == 0]
         runs.append(("torch.matmul", lambda: torch.matmul(A, W.t())))
         times = {v: [] for v, _ in runs}
         for v, fn in runs:                       # warm-up
@@ -93,6 +96,8 @@ def main():
             results.append(rec)
             print(rec, flush=True)
         _capi.set_tuning(_capi.TP_TUNE_GEMM_KERNEL, 0)
+        _capi.set_tuning(_capi.TP_TUNE_PAIR_GEMM, 0)
+        _capi.set_tuning(_capi.TP_TUNE_PAIR_STAGGER, 100)
         del A, W, C, mr, stats
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     json.dump(results, open(args.out, "w"), indent=1)

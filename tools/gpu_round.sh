@@ -14,6 +14,16 @@ echo "== rocminfo =="; /opt/rocm/bin/rocminfo 2>/dev/null | grep -E "Marketing N
 if has smoke; then
   echo "== smoke =="; timeout 600 python __graft_entry__.py smoke 2>&1 | tail -5
 fi
+if has pair; then
+  echo "== pair kernel: occupancy, bit-identity tests, same-process A/B =="
+  python - <<'PY'
+from tokenpacker_amd import _capi
+print("pair kernel workgroups per CU (needs 2):", _capi.load_library().tp_test_pair_occupancy())
+PY
+  timeout 900 python -m pytest tests/test_gpu_pair.py -m gpu -x -q -p no:cacheprovider > $OUT/pytest_pair.log 2>&1
+  echo "pytest exit $?"; tail -30 $OUT/pytest_pair.log
+  timeout 600 python tools/pair_ab.py --out $OUT/pair_ab.json > $OUT/pair_ab.log 2>&1; echo "pair_ab exit $?"; cat $OUT/pair_ab.log | cut -c1-600
+fi
 if has ktests; then
   echo "== pytest gpu (kernels only) =="
   timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -p no:cacheprovider > $OUT/pytest_kernels.log 2>&1
