@@ -460,11 +460,13 @@ enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all hal
                                      statistics GEMM on W2 with (mean, M2), as rounds 1-2 shipped */
        TP_TUNE_PAIR_GEMM = 15,    /* the 256 x 128-tile "pair" kernel (tp_gemm_pair.hip: two co-resident 4-wave workgroups per CU, a tile's
                                      epilogue under the other workgroup's MFMAs; bit-identical to the other GEMM kernels): 0 (default) for
-                                     every launch it supports that fills the chip at least 1.5 times with its 512 workgroups | 1 never |
-                                     2 wherever it is supported */
+                                     the short-K launches of 1.5 .. 2.5 rounds of its 512 workgroups, where it measured faster — on
+                                     full-chip launches its 1.5 x operand traffic loses 12-17 % | 1 never | 2 wherever it is supported */
        TP_TUNE_PAIR_STAGGER = 16, /* percent (default 100) of half a tile period by which the second workgroup of each CU starts late in
                                      a pair-kernel launch (0: both start together — their epilogues then coincide for ever) */
-       TP_TUNE_COUNT_ = 17 };
+       TP_TUNE_PAIR_DEBUG = 17,   /* timing probes of the pair kernel (fp16 -> fp16 plain launches; results are GARBAGE with 1..4): low 3 bits 1 no
+                                     DMA in the K loop | 2 no fragment reads | 3 no barriers | 4 no MFMAs; + 8: one workgroup per CU */
+       TP_TUNE_COUNT_ = 18 };
 int tp_set_tuning(int key, int value);
 int tp_get_tuning(int key);                  /* the library's current value (not a binding's shadow copy); -1: bad key */
 

@@ -149,10 +149,11 @@ def test_forward_on_the_pair_kernel_is_the_same_function(s, D, B, dtype, layout)
         _eq(g32, r32, "fp32 output")
 
 
-def test_full_size_default_routes_to_the_pair_kernel_and_is_race_free():
-    """BASELINE config 2 (B = 256, s = 2, D = 4096, bf16): the DEFAULT policy sends the big launches to the pair kernel; the
-    result equals the pair-less path bit for bit, 64 repeats of 4 images give 64 identical copies, and ten forwards under
-    different stagger settings (which move the two workgroups of a CU against each other) are all the same bits."""
+def test_full_size_on_the_pair_kernel_is_race_free():
+    """BASELINE config 2 (B = 256, s = 2, D = 4096, bf16) with every launch forced onto the pair kernel: equal to the pair-less path
+    bit for bit, 64 repeats of 4 images give 64 identical copies, and ten forwards under different stagger settings (which move
+    the two workgroups of a CU against each other) are all the same bits.  The DEFAULT policy sends only the short-K launches of
+    1.5 .. 2.5 rounds there (the query-side GEMMs at this batch): also the same bits."""
     dtype, D, s, B = torch.bfloat16, 4096, 2, 256
     m = _module(synth.make_params(6, D), s, D, dtype)
     x4, xm4 = synth.make_inputs(10, 4, dtype)
@@ -162,13 +163,18 @@ def test_full_size_default_routes_to_the_pair_kernel_and_is_race_free():
         with pair(1):
             ref = m((x, xm))
         n0 = launches()
-        y = m((x, xm))
-        assert launches() - n0 >= 6, "the default policy should route the B = 256 forward's big GEMMs to the pair kernel"
-        _eq(y, ref, "default (pair) vs pair off at B = 256")
+        y0 = m((x, xm))
+        assert launches() - n0 >= 1, "the default policy should route the query-side GEMMs of a B = 256 forward to the pair kernel"
+        _eq(y0, ref, "default policy vs pair off at B = 256")
+        n0 = launches()
+        with pair(2):
+            y = m((x, xm))
+        assert launches() - n0 >= 8
+        _eq(y, ref, "pair forced vs pair off at B = 256")
         yr = y.reshape(B // 4, 4, 144, D)
         assert torch.equal(yr, yr[:1].expand_as(yr)), "batch elements must not interact"
         for st in (0, 100, 37, 250, 100, 0, 63, 100, 180, 100):
-            with pair(0, st):
+            with pair(2, st):
                 _eq(m((x, xm)), y, f"stagger {st}")
     torch.cuda.synchronize()
 

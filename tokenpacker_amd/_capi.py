@@ -27,7 +27,8 @@ TP_TUNE_STREAM_K = 13
 TP_TUNE_TRI_STATS = 14
 TP_TUNE_PAIR_GEMM = 15
 TP_TUNE_PAIR_STAGGER = 16
-TP_TUNE_COUNT = 17
+TP_TUNE_PAIR_DEBUG = 17
+TP_TUNE_COUNT = 18
 TP_WGRAD_X_TRANSPOSED = 1
 TP_NUM_STAGES = 10
 TP_NUM_DEBUG_BUFFERS = 9
@@ -259,7 +260,7 @@ def strides3(st) -> "ctypes.Array":
 _TUNING_DEFAULTS = {TP_TUNE_GEMM_TILE: 0, TP_TUNE_XCD_SWIZZLE: 1, TP_TUNE_GEMM_KERNEL: 0, TP_TUNE_FOLD_OUT_PROJ: 0,
                     TP_TUNE_DYNAMIC_TILES: 1, TP_TUNE_Q_SIDE_STREAM: 1, TP_TUNE_RESERVE_CUS: 0, TP_TUNE_ABSORB_KV: 0, TP_TUNE_FUSE_KV_LN: 1,
                     TP_TUNE_FUSE_ATTN: 0, TP_TUNE_LN_MERGE: 0, TP_TUNE_SPLIT_K: 0, TP_TUNE_SMALL_GEMM_WAVES: 0, TP_TUNE_STREAM_K: 0, TP_TUNE_TRI_STATS: 0,
-                    TP_TUNE_PAIR_GEMM: 0, TP_TUNE_PAIR_STAGGER: 100}
+                    TP_TUNE_PAIR_GEMM: 0, TP_TUNE_PAIR_STAGGER: 100, TP_TUNE_PAIR_DEBUG: 0}
 
 
 def set_tuning(key: int, value: int) -> None:

@@ -364,15 +364,20 @@ static int gemm_route(const GemmArgs& a, long long* head_rows_out) {
     return ROUTE_SMALL;
 }
 
-// Whether gemm_launch sends `a` to the pair kernel (tp_gemm_pair.hip): a launch it supports, nothing forced by the caller or the
-// tuning table, and enough 256 x 128 tiles that both workgroups of a CU have work for most of the launch.
+// Whether gemm_launch sends `a` to the pair kernel (tp_gemm_pair.hip).  Its 256 x 128 tiles move 1.5 x the operand bytes of the
+// 256 x 256 ping-pong tile through the CU's L1 -> LDS path, which is what bounds it (profiles/r04d_pair_probe.json: 1.58 us of memory-side
+// work per K-tile with NO MFMAs against 1.14 us of matrix work) — on full-chip launches it loses 12-17 %.  Where it measured faster
+// (or equal) is the short-K launch of 1.5 .. 2.5 rounds of its 512 workgroups, where the ping-pong kernel's 256 workgroups run 1.125
+// or 2.25 rounds and every tile's epilogue is exposed: the query-side GEMMs at B = 256, the statistics / K / V / mlp[0] launches of
+// a 32 .. 64-image shard (profiles/r04b_pair_ab.json).  TP_TUNE_PAIR_GEMM: 0 that policy | 1 never | 2 wherever supported.
 static bool gemm_takes_pair_route(int in_dtype, int out_dtype, const GemmArgs& a) {
     const int mode = tuning(TP_TUNE_PAIR_GEMM);
     if (mode == 1 || a.tile != 0 || tuning(TP_TUNE_GEMM_TILE) != 0 || tuning(TP_TUNE_GEMM_KERNEL) != 0 || a.stream_k == 2) return false;
     if (!gemm_pair_supports(in_dtype, out_dtype, a)) return false;
     if (mode == 2) return true;
     const long long tiles = (long long)((a.M + 255) / 256) * (a.N / 128) * (a.groups > 0 ? a.groups : 1);
-    return tiles * 2 >= 3ll * gemm_pair_workgroups();
+    const long long wgs = gemm_pair_workgroups();
+    return a.K <= 1024 && tiles * 2 >= 3 * wgs && tiles * 2 < 5 * wgs;
 }
 
 bool gemm_uses_small_kernel(const GemmArgs& a) {

@@ -80,7 +80,9 @@ static_assert(GP_LDS_BYTES <= 80 * 1024, "two workgroups per CU");
 // XMODE: 0 plain | 1 statistics only, optionally on a triangular weight | 2 accumulators pre-loaded from GemmArgs::acc_init |
 //        3 / 4: 2 + region attention in the epilogue (the K launch / the V launch; tp_gemm_common.h).  The K launch's queries
 //        are read from global memory by the epilogue (the other workgroup of the CU covers their latency).
-template <typename TI, typename TO, int AMODE, int XMODE>
+// DBG (TP_TUNE_PAIR_DEBUG, probe builds for timing only — results are garbage): 1 no DMA in the K loop | 2 no fragment reads |
+// 3 no barriers | 4 no MFMAs
+template <typename TI, typename TO, int AMODE, int XMODE, int DBG = 0>
 __global__ void __launch_bounds__(256, 2)
 gemm_pair_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int stagger) {
     using X8 = typename Vec<TI>::x8;
@@ -178,17 +180,28 @@ gemm_pair_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const i
         }
     };
 
-    // ring slot of group `sub` of K-tile kt (sequence index 2 kt + sub, three slots)
-    auto slot_of = [&](const int kt, const int sub) __attribute__((always_inline)) -> int {
-        return (int)((unsigned)(2 * kt + sub) % 3u);
-    };
-    // one 1-KiB piece of an A / W group of K-tile kt (of the tile set up last)
-    auto issue_a = [&](auto SUB_, auto Q_, const int kt) __attribute__((always_inline)) {
-        constexpr int sub = decltype(SUB_)::value, q = decltype(Q_)::value;
-        char* dst = smem + slot_of(kt, sub) * GP_AGRP + (wave * 4 + q) * 1024;
-        const int ktg = kt_base + kt;
+    // Ring slots: group `sub` of K-tile kt has sequence index 2 kt + sub and lives in slot index % 3.  The K loop keeps the BYTE
+    // OFFSETS of the slots it reads in four scalars that advance cyclically (three SALU instructions per advance) — a_p0 / a_p2:
+    // the A slots read in phases 0 / 2 (a0, a1 of the K-tile being computed), w_p0 / w_p1: the W slots read in phases 0 / 1 —
+    // and every piece it issues lands in a slot it has JUST finished reading (header: a1(u+1) -> a0(u)'s, b1(u+1) -> b0(u)'s,
+    // b0(u+2) -> b1(u)'s, a0(u+2) -> a1(u)'s), so no write cursor exists.  A fragment read is base VGPR + slot offset (one
+    // v_add per k-half and group) + immediates; with `% 3` arithmetic on the K-tile index instead the loop carried ~90 scalar /
+    // vector ALU instructions per K-tile beside its 64 MFMAs, and a wave issues one instruction per ~4 cycles: the memory
+    // segments were issue-bound (measured: 1.80 instead of 1.45 us per K-tile and 256 x 256 tile).
+    // K advances through the DMA instructions' scalar offset: soff_k = byte offset of K-tile u + 1 (pieces of tile u + 2: + 128).
+    int soff_k = 0;
+    int a_p0 = 0, a_p2 = 0, w_p0 = 0, w_p1 = 0;
+    auto next_a = [&](const int off) __attribute__((always_inline)) -> int { return off == 2 * GP_AGRP ? 0 : off + GP_AGRP; };
+    auto next_w = [&](const int off) __attribute__((always_inline)) -> int { return off == 2 * GP_WGRP ? 0 : off + GP_WGRP; };
+    // one 1-KiB piece of an A / W group into the slot at byte offset `slot_off`; the K-tile it belongs to lies D tiles ahead of the
+    // one being computed (prologue: D = 0 / 1 for K-tiles 0 / 1 with soff_k preset)
+    auto issue_a = [&](auto SUB_, auto Q_, const int slot_off, auto D_) __attribute__((always_inline)) {
+        constexpr int sub = decltype(SUB_)::value, q = decltype(Q_)::value, D = decltype(D_)::value;
+        char* dst = smem + slot_off + (wave * 4 + q) * 1024;
+        const int soff = soff_k + (D - 1) * ROW_BYTES;
         if constexpr (AMODE == 2) {
-            // K-tile ktg lives in source ktg / tpp: pick that source's base with scalar selects and rebuild the descriptor
+            // the K-tile lives in source ktg / tpp: pick that source's base with scalar selects and rebuild the descriptor
+            const int ktg = soff / ROW_BYTES;
             const int tpp = p.k_part / BK, part = ktg / tpp, so = (ktg - part * tpp) * ROW_BYTES;   // wave-uniform
             const char* b = part == 0 ? p.A_parts[0] : part == 1 ? p.A_parts[1] : part == 2 ? p.A_parts[2] : p.A_parts[3];
             const unsigned long long addr = (unsigned long long)(b + a_tile_off_cur);
@@ -197,76 +210,93 @@ gemm_pair_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const i
             const auto r = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, voff_a[sub][q], so, 0, 0);
         } else {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)dst, 16, voff_a[sub][q], ktg * ROW_BYTES, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)dst, 16, voff_a[sub][q], soff, 0, 0);
         }
     };
-    auto issue_w = [&](auto SUB_, auto Q_, const int kt) __attribute__((always_inline)) {
-        constexpr int sub = decltype(SUB_)::value, q = decltype(Q_)::value;
-        char* dst = smem + GP_L_W + slot_of(kt, sub) * GP_WGRP + (wave * 2 + q) * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void*)dst, 16, voff_w[sub][q], (kt_base + kt) * ROW_BYTES, 0, 0);
+    auto issue_w = [&](auto SUB_, auto Q_, const int slot_off, auto D_) __attribute__((always_inline)) {
+        constexpr int sub = decltype(SUB_)::value, q = decltype(Q_)::value, D = decltype(D_)::value;
+        char* dst = smem + GP_L_W + slot_off + (wave * 2 + q) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void*)dst, 16, voff_w[sub][q], soff_k + (D - 1) * ROW_BYTES, 0, 0);
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
     // K-tile 0 complete + a0 of K-tile 1 (nk >= 3, checked on the host), in the order of first use.  W slot 2 stays empty: it is
     // the epilogue's scratch while this prologue is in flight; b0(1) follows in phase 0 of K-tile 0.
     auto issue_prologue = [&]() __attribute__((always_inline)) {
-        issue_a(I0{}, I0{}, 0); issue_a(I0{}, I1{}, 0); issue_a(I0{}, I2{}, 0); issue_a(I0{}, I3{}, 0);
-        issue_w(I0{}, I0{}, 0); issue_w(I0{}, I1{}, 0);
-        issue_w(I1{}, I0{}, 0); issue_w(I1{}, I1{}, 0);
-        issue_a(I1{}, I0{}, 0); issue_a(I1{}, I1{}, 0); issue_a(I1{}, I2{}, 0); issue_a(I1{}, I3{}, 0);
-        issue_a(I0{}, I0{}, 1); issue_a(I0{}, I1{}, 1); issue_a(I0{}, I2{}, 1); issue_a(I0{}, I3{}, 1);
+        soff_k = (kt_base + 1) * ROW_BYTES;                 // (K-tile 0 = "D = 0", K-tile 1 = D = 1)
+        // sequence indices 0, 1, 2 -> slots 0, 1, 2:  a0(0) b0(0) | b1(0) a1(0) | a0(1)
+        issue_a(I0{}, I0{}, 0, I0{}); issue_a(I0{}, I1{}, 0, I0{}); issue_a(I0{}, I2{}, 0, I0{}); issue_a(I0{}, I3{}, 0, I0{});
+        issue_w(I0{}, I0{}, 0, I0{}); issue_w(I0{}, I1{}, 0, I0{});
+        issue_w(I1{}, I0{}, GP_WGRP, I0{}); issue_w(I1{}, I1{}, GP_WGRP, I0{});
+        issue_a(I1{}, I0{}, GP_AGRP, I0{}); issue_a(I1{}, I1{}, GP_AGRP, I0{}); issue_a(I1{}, I2{}, GP_AGRP, I0{}); issue_a(I1{}, I3{}, GP_AGRP, I0{});
+        issue_a(I0{}, I0{}, 2 * GP_AGRP, I1{}); issue_a(I0{}, I1{}, 2 * GP_AGRP, I1{}); issue_a(I0{}, I2{}, 2 * GP_AGRP, I1{}); issue_a(I0{}, I3{}, 2 * GP_AGRP, I1{});
     };
 
     // ---- fragment read offsets (swizzled; fragment rows are 16-aligned inside a group, so row & 7 == lane & 7)
     const int slot0 = (((lane >> 4)) ^ (lane & 7)) << 4, slot1 = (((4 + (lane >> 4))) ^ (lane & 7)) << 4;
-    const int rd_a = (wm * 64 + (lane & 15)) * ROW_BYTES;     // + i * 2048, i = 0..3
-    const int rd_w = (wn * 32 + (lane & 15)) * ROW_BYTES;     // + j * 2048, j = 0..1
+    // per-lane read bases (k-half 0 / 1); everything else of a fragment's address — ring slot, fragment index — is an immediate
+    const char* const rd_a0 = smem + (wm * 64 + (lane & 15)) * ROW_BYTES + slot0;             // + slot * GP_AGRP + i * 2048, i = 0..3
+    const char* const rd_a1 = smem + (wm * 64 + (lane & 15)) * ROW_BYTES + slot1;
+    const char* const rd_w0 = smem + GP_L_W + (wn * 32 + (lane & 15)) * ROW_BYTES + slot0;    // + slot * GP_WGRP + j * 2048, j = 0..1
+    const char* const rd_w1 = smem + GP_L_W + (wn * 32 + (lane & 15)) * ROW_BYTES + slot1;
 
     f32x4 acc[FM][FN];
     X8 fa[4][2];            // A fragments of the current M-quadrant  [i][k-half]
     X8 fb[2][2][2];         // W fragments                            [b][j][k-half]
+    if constexpr (DBG == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { fa[i][0] = X8{}; fa[i][1] = X8{}; }
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { fb[b][j][0] = X8{}; fb[b][j][1] = X8{}; }
+    }
 
-    // One phase of K-tile u.  P: 0..3;  ISSUE: whether this phase's DMA pieces exist;  WAIT: vmcnt to leave in flight (-1: none).
-    // FIRST: phase 0 of K-tile 0 — what the prologue left out (b0(1)) instead of the steady-state pieces.
-    auto phase = [&](auto P_, auto ISSUE_, auto WAIT_, const int u, auto FIRST_) __attribute__((always_inline)) {
+    // One phase of the K-tile being computed.  P: 0..3;  ISSUE: whether this phase's DMA pieces exist;  WAIT: vmcnt to leave in
+    // flight (-1: none).  FIRST: phase 0 of K-tile 0 — what the prologue left out (b0(1), into W slot 2) instead of the steady-state
+    // pieces.  Slot cursors on entry to phase 0 of K-tile u: a_p0 = slot of a0(u), a_p2 = of a1(u), w_p0 = of b0(u), w_p1 = of b1(u).
+    auto phase = [&](auto P_, auto ISSUE_, auto WAIT_, auto FIRST_) __attribute__((always_inline)) {
         constexpr int P = decltype(P_)::value;
         constexpr bool ISSUE = decltype(ISSUE_)::value;
         constexpr int WAIT = decltype(WAIT_)::value;
         constexpr bool FIRST = decltype(FIRST_)::value;
         // -- memory segment ---------------------------------------------------------------------------
-        if constexpr (P == 0 || P == 1) {                           // W fragments of b0 / b1
+        if constexpr ((P == 0 || P == 1) && DBG != 2) {             // W fragments of b0 / b1
             constexpr int B = P;
-            const char* sw = smem + GP_L_W + slot_of(u, B) * GP_WGRP + rd_w;
+            const int off = B == 0 ? w_p0 : w_p1;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                fb[B][j][0] = *(const X8*)(sw + j * 2048 + slot0);
-                fb[B][j][1] = *(const X8*)(sw + j * 2048 + slot1);
+                fb[B][j][0] = *(const X8*)(rd_w0 + off + j * 2048);
+                fb[B][j][1] = *(const X8*)(rd_w1 + off + j * 2048);
             }
         }
-        if constexpr (P == 0 || P == 2) {                           // A fragments of a0 / a1
-            constexpr int SA = P == 0 ? 0 : 1;
-            const char* sa = smem + slot_of(u, SA) * GP_AGRP + rd_a;
+        if constexpr ((P == 0 || P == 2) && DBG != 2) {             // A fragments of a0 / a1
+            const int off = P == 0 ? a_p0 : a_p2;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                fa[i][0] = *(const X8*)(sa + i * 2048 + slot0);
-                fa[i][1] = *(const X8*)(sa + i * 2048 + slot1);
+                fa[i][0] = *(const X8*)(rd_a0 + off + i * 2048);
+                fa[i][1] = *(const X8*)(rd_a1 + off + i * 2048);
             }
         }
-        if constexpr (FIRST) { issue_w(I0{}, I0{}, 1); issue_w(I0{}, I1{}, 1); }
-        if constexpr (ISSUE) {
-            if constexpr (P == 0) { issue_a(I0{}, I2{}, u + 1); issue_a(I0{}, I3{}, u + 1); }
-            if constexpr (P == 1) { issue_w(I1{}, I0{}, u + 1); issue_w(I1{}, I1{}, u + 1); issue_a(I1{}, I0{}, u + 1); }
-            if constexpr (P == 2) { issue_a(I1{}, I1{}, u + 1); issue_a(I1{}, I2{}, u + 1); issue_a(I1{}, I3{}, u + 1); }
-            if constexpr (P == 3) { issue_w(I0{}, I0{}, u + 2); issue_w(I0{}, I1{}, u + 2); issue_a(I0{}, I0{}, u + 2); issue_a(I0{}, I1{}, u + 2); }
+        if constexpr (FIRST && DBG != 1) { issue_w(I0{}, I0{}, 2 * GP_WGRP, I1{}); issue_w(I0{}, I1{}, 2 * GP_WGRP, I1{}); }
+        if constexpr (ISSUE && DBG != 1) {
+            // P0: a0(u+1) pieces 2, 3 -> the slot of a1(u-1) = the one AFTER a0(u)'s in the cycle... see the cursor notes below
+            if constexpr (P == 0) { const int d = next_a(a_p2); issue_a(I0{}, I2{}, d, I1{}); issue_a(I0{}, I3{}, d, I1{}); }
+            if constexpr (P == 1) { issue_w(I1{}, I0{}, w_p0, I1{}); issue_w(I1{}, I1{}, w_p0, I1{}); issue_a(I1{}, I0{}, a_p0, I1{}); }
+            if constexpr (P == 2) { issue_a(I1{}, I1{}, a_p0, I1{}); issue_a(I1{}, I2{}, a_p0, I1{}); issue_a(I1{}, I3{}, a_p0, I1{}); }
+            if constexpr (P == 3) { issue_w(I0{}, I0{}, w_p1, I2{}); issue_w(I0{}, I1{}, w_p1, I2{}); issue_a(I0{}, I0{}, a_p2, I2{}); issue_a(I0{}, I1{}, a_p2, I2{}); }
         }
         if constexpr (WAIT >= 0) gp_wait_vmcnt<WAIT>();
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        // (the builtin, not inline asm: the compiler then KNOWS the counter is zero and adds no lgkmcnt waits of its own in
+        // front of the MFMAs — six wasted issue slots per phase; 0xc07f = lgkmcnt(0), vmcnt / expcnt untouched)
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if constexpr (DBG != 3) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // -- matrix segment ---------------------------------------------------------------------------
         constexpr int a = (P >= 2) ? 1 : 0, b = (P == 1 || P == 2) ? 1 : 0;
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (DBG != 4) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -274,6 +304,12 @@ gemm_pair_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const i
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[4 * a + i][2 * b + j] = Mma<TI>::run(fb[b][j][ks], fa[i][ks], acc[4 * a + i][2 * b + j]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { asm volatile("" :: "v"(fa[i][0]), "v"(fa[i][1])); }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { asm volatile("" :: "v"(fb[b][j][0]), "v"(fb[b][j][1])); }
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -302,26 +338,30 @@ gemm_pair_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const i
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        int u = 0;
-        phase(I0{}, F_{}, WN_{}, u, T_{});                        // tile 0: a0(1) came whole with the prologue; b0(1) goes out here
-        phase(I1{}, T_{}, W9_{}, u, F_{});
-        phase(I2{}, T_{}, WN_{}, u, F_{});
-        phase(I3{}, T_{}, W10_{}, u, F_{});
-        for (u = 1; u < nk - 2; ++u) {                      // steady state
-            phase(I0{}, T_{}, W10_{}, u, F_{});
-            phase(I1{}, T_{}, W9_{}, u, F_{});
-            phase(I2{}, T_{}, WN_{}, u, F_{});
-            phase(I3{}, T_{}, W10_{}, u, F_{});
+        // Slot cursors: sequence a0(0) a1(0) a0(1) a1(1) ... over slots 0 1 2 0 1 2 ...  =>  a0(u+1) = next(a1(u)), a1(u+1) = next(a0(u+1))
+        // = the slot of a0(u) (three slots: next(next(next(x))) = x), likewise for W.  Where the pieces of phase P go (header):
+        //   P1, P2: a1(u+1) -> a0(u)'s slot = a_p0;  b1(u+1) -> b0(u)'s = w_p0        (read in phase 0)
+        //   P3:     b0(u+2) -> b1(u)'s = w_p1 (read in phase 1);  a0(u+2) -> a1(u)'s = a_p2 (read in phase 2), pieces 0, 1
+        //   P0 of u+1: a0(u+2) pieces 2, 3 -> a1(u)'s slot, which after advance() is next(a_p2)  [a_p2 now = a1(u+1) = a0(u)'s old slot;
+        //           next of it = a1(u)'s old slot: the cycle a0(u) -> a1(u) -> a0(u+1) -> a0(u)]
+        a_p0 = 0; a_p2 = GP_AGRP; w_p0 = 0; w_p1 = GP_WGRP;
+        auto advance = [&]() __attribute__((always_inline)) {   // cursors of K-tile u -> K-tile u + 1
+            const int a0n = next_a(a_p2), w0n = next_w(w_p1);
+            a_p2 = a_p0; w_p1 = w_p0;                       // a1(u+1) took a0(u)'s slot, b1(u+1) b0(u)'s
+            a_p0 = a0n; w_p0 = w0n;
+            soff_k += ROW_BYTES;
+        };
+        // K-tile kinds: steady (every phase issues), last but one (nothing beyond K-tile nk - 1 to fetch), last (drain)
+        // K-tile 0: a0(1) came whole with the prologue; b0(1) goes out in its phase 0
+        phase(I0{}, F_{}, WN_{}, T_{}); phase(I1{}, T_{}, W9_{}, F_{}); phase(I2{}, T_{}, WN_{}, F_{}); phase(I3{}, T_{}, W10_{}, F_{});
+        advance();
+        for (int u = 1; u < nk - 2; ++u) {                  // steady state
+            phase(I0{}, T_{}, W10_{}, F_{}); phase(I1{}, T_{}, W9_{}, F_{}); phase(I2{}, T_{}, WN_{}, F_{}); phase(I3{}, T_{}, W10_{}, F_{});
+            advance();
         }
-        phase(I0{}, T_{}, W10_{}, u, F_{});                       // tile nk-2: nothing beyond tile nk-1 to fetch
-        phase(I1{}, T_{}, W9_{}, u, F_{});
-        phase(I2{}, T_{}, WN_{}, u, F_{});
-        phase(I3{}, F_{}, W6_{}, u, F_{});
-        ++u;
-        phase(I0{}, F_{}, W4_{}, u, F_{});                        // tile nk-1: drain
-        phase(I1{}, F_{}, W0_{}, u, F_{});
-        phase(I2{}, F_{}, WN_{}, u, F_{});
-        phase(I3{}, F_{}, WN_{}, u, F_{});
+        phase(I0{}, T_{}, W10_{}, F_{}); phase(I1{}, T_{}, W9_{}, F_{}); phase(I2{}, T_{}, WN_{}, F_{}); phase(I3{}, F_{}, W6_{}, F_{});
+        advance();
+        phase(I0{}, F_{}, W4_{}, F_{}); phase(I1{}, F_{}, W0_{}, F_{}); phase(I2{}, F_{}, WN_{}, F_{}); phase(I3{}, F_{}, WN_{}, F_{});
     };
 
     // ---- persistent: walk the tile list ----------------------------------------------------------------
@@ -443,9 +483,16 @@ int gemm_pair_occupancy() {
     return n;
 }
 
-template <typename TI, typename TO, int AMODE, int XMODE>
+template <typename TI, typename TO, int AMODE, int XMODE, int DBG = 0>
 static int launch_pair_cfg(const GemmArgs& a, hipStream_t stream) {
-    auto kern = gemm_pair_kernel<TI, TO, AMODE, XMODE>;
+    if constexpr (DBG == 0 && AMODE == 0 && XMODE == 0 && std::is_same<TI, f16_t>::value && std::is_same<TO, f16_t>::value) {
+        const int dbg = tuning(TP_TUNE_PAIR_DEBUG) & 7;
+        if (dbg == 1) return launch_pair_cfg<TI, TO, AMODE, XMODE, 1>(a, stream);
+        if (dbg == 2) return launch_pair_cfg<TI, TO, AMODE, XMODE, 2>(a, stream);
+        if (dbg == 3) return launch_pair_cfg<TI, TO, AMODE, XMODE, 3>(a, stream);
+        if (dbg == 4) return launch_pair_cfg<TI, TO, AMODE, XMODE, 4>(a, stream);
+    }
+    auto kern = gemm_pair_kernel<TI, TO, AMODE, XMODE, DBG>;
     constexpr int lds = GP_LDS_BYTES;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
@@ -459,7 +506,8 @@ static int launch_pair_cfg(const GemmArgs& a, hipStream_t stream) {
     const int tiles_m = (a.M + GP_BM - 1) / GP_BM, tiles_n = a.N / GP_BN;
     const int ntiles = tiles_m * tiles_n;
     int nwg = ntiles;
-    const int cap = gemm_pair_workgroups();
+    int cap = gemm_pair_workgroups();
+    if (tuning(TP_TUNE_PAIR_DEBUG) & 8) cap /= 2;       // (probe: one workgroup per CU)
     if (nwg > cap && cap > 0) nwg = cap;
     // stagger of the second workgroup of each CU: half of the period in which the pair turns over two tiles.  A tile is
     // K / 64 K-tiles of 64 MFMAs x 16 cycles per wave; two of them share a SIMD's pipe at ~0.9 utilisation -> a period of

@@ -22,7 +22,7 @@ print("pair kernel workgroups per CU (needs 2):", _capi.load_library().tp_test_p
 PY
   timeout 900 python -m pytest tests/test_gpu_pair.py -m gpu -x -q -p no:cacheprovider > $OUT/pytest_pair.log 2>&1
   echo "pytest exit $?"; tail -30 $OUT/pytest_pair.log
-  timeout 600 python tools/pair_ab.py --out $OUT/pair_ab.json > $OUT/pair_ab.log 2>&1; echo "pair_ab exit $?"; cat $OUT/pair_ab.log | cut -c1-600
+  timeout 600 python tools/pair_ab.py --batches 256 128 64 32 --out $OUT/pair_ab.json > $OUT/pair_ab.log 2>&1; echo "pair_ab exit $?"; cat $OUT/pair_ab.log | cut -c1-600
 fi
 if has ktests; then
   echo "== pytest gpu (kernels only) =="

@@ -20,8 +20,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from tokenpacker_amd import _capi  # noqa: E402
 
-DEFAULT_ARMS = ["off:PAIR_GEMM=1", "pair:PAIR_GEMM=0", "pair_forced:PAIR_GEMM=2", "pair_nostagger:PAIR_GEMM=0,PAIR_STAGGER=0",
-                "pair_stagger50:PAIR_GEMM=0,PAIR_STAGGER=50", "pair_stagger200:PAIR_GEMM=0,PAIR_STAGGER=200"]
+DEFAULT_ARMS = ["off:PAIR_GEMM=1", "default:PAIR_GEMM=0", "pair_forced:PAIR_GEMM=2", "pair_forced_nostagger:PAIR_GEMM=2,PAIR_STAGGER=0"]
 
 
 def parse_arm(spec):
