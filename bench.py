@@ -15,8 +15,10 @@ the north_star prescribes, so each rank holds ``[256, 144, 4096]``; the gather o
 step i+1 (rotating output buffers, all gathers drained inside the timed region).  ``--gather rccl`` is
 ``all_gather_into_tensor`` (RCCL kernels over xGMI); ``--gather sdma`` is ``shard.DirectGather``: the shard is written
 straight into its rows of the receive buffer and travels as one copy-engine transfer per peer + a sequence flag — no
-compute unit; ``--gather auto`` (default) proves the sdma transport on the node first, then times BOTH
-with the same W + K step protocol and reports the faster one as ``value`` (both in ``multi_gpu``).  ``--scaling weak`` keeps 256 images per GPU instead; ``--no-gather`` drops the gather
+compute unit, self-tested on the node before it is timed; ``--gather auto`` runs the rccl configuration, PRINTS
+its line, and only then runs the sdma configuration in fresh processes (bounded in time), printing its outcome as a second line
+``{"sdma_leg": ...}`` — nothing that transport does can cost the run the rccl line or its exit code.  The default is ``rccl``: the
+one collective the north_star names, and exactly one line.  ``--scaling weak`` keeps 256 images per GPU instead; ``--no-gather`` drops the gather
 (DDP-style: the LLM consumes the local shard).
 
 Other workloads (each prints the same one-line JSON):
@@ -47,6 +49,8 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
                  pid), the NCCL_* / HSA_* variables that are set, the gather mode, forward-only / gather-only times,
                  and with --probe-other-gather the transport not selected.
   stages_ms    — per-kernel breakdown of one forward.
+  clocks       — the device's current sclk / mclk / fclk levels (sysfs pp_dpm_*) and average socket power right before and right after
+                 the timed region, so that a slow run can be tied to an actual clock / power state.
   memory_side  — mlp0_gelu / kv_layer2_stats: a launch that stores 128 KiB per 23-us tile over one that stores nothing; tells a
                  run in the node's slow memory-side power state (mid-sized batches, profiles/r03u_mid_batch_anomaly.txt) from a
                  normal one.
@@ -116,12 +120,14 @@ def parse_args():
                     help="collective backend for N>1 (nccl = RCCL; gloo only to exercise the N>1 flow on one GPU)")
     ap.add_argument("--single-device", action="store_true",
                     help="test aid: every rank uses cuda:0 (with --backend gloo)")
-    ap.add_argument("--gather", default="auto", choices=["auto", "rccl", "sdma"],
-                    help="N>1: how the projected tokens travel — rccl: all_gather_into_tensor (RCCL kernels over xGMI) | "
-                         "sdma: shard.DirectGather, one hipMemcpyAsync per peer on the copy engines, no compute unit | "
-                         "auto (default): a two-step self-test of the sdma transport (every rank checks every peer's rows); if it "
-                         "passes on every rank BOTH transports are timed over the K steps and the faster one is the line's value "
-                         "(both are reported), otherwise rccl alone")
+    ap.add_argument("--gather", default="rccl", choices=["rccl", "sdma", "auto"],
+                    help="N>1: how the projected tokens travel — rccl (default): ONE all_gather_into_tensor per step (RCCL kernels "
+                         "over xGMI), what the north_star names | sdma: shard.DirectGather, one hipMemcpyAsync per peer on the copy "
+                         "engines, no compute unit (self-tested on the node first: every rank checks every peer's rows) | auto: the "
+                         "rccl run first and its line PRINTED; only then the sdma leg, in fresh processes, so that nothing it does "
+                         "(a device fault, a hang: it is bounded by --sdma-leg-timeout) can take the printed result with it; its "
+                         "outcome follows as a second line {\"sdma_leg\": ...}")
+    ap.add_argument("--sdma-leg-timeout", type=float, default=240.0, help="--gather auto: seconds the sdma leg's processes may take")
     ap.add_argument("--gather-depth", type=int, default=3, help="--gather sdma: rotating receive buffers")
     ap.add_argument("--probe-other-gather", action="store_true",
                     help="N>1: after the timed region also time the transport NOT selected by --gather (multi_gpu.other_gather)")
@@ -197,6 +203,33 @@ def cpu_baseline(seconds: float, s: int, D: int, threads: int):
             "sample": f"{n} forwards of B={B}, s={s}, D={D}, fp32, the reference's torch op sequence incl. "
                       f"nn.MultiheadAttention on {cores} host threads of {os.cpu_count()} logical cores, {el:.1f} s "
                       f"(BASELINE config 1 shape)"}
+
+
+def read_clocks(device) -> dict:
+    """Current sclk / mclk / fclk (the level sysfs marks with '*') and average power of the GPU behind `device`, from the amdgpu
+    sysfs files; {} where the box exposes none (never an error: this is a diagnostic)."""
+    import glob
+    try:
+        bus = (getattr(torch.cuda.get_device_properties(device), "pci_bus_id", None) or "").lower()
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        pick = [c for c in cards if bus and os.path.realpath(c).lower().endswith(bus)] or \
+               [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk"))]
+        if not pick:
+            return {}
+        idx = device.index if (not bus and device.index is not None and device.index < len(pick)) else 0
+        dev, out = pick[idx], {}
+        for name in ("sclk", "mclk", "fclk", "socclk"):
+            f = os.path.join(dev, "pp_dpm_" + name)
+            if os.path.exists(f):
+                cur = [l.split(":")[1].strip().rstrip("*").strip() for l in open(f).read().splitlines() if l.strip().endswith("*")]
+                if cur:
+                    out[name] = cur[0]
+        for f in glob.glob(os.path.join(dev, "hwmon", "hwmon*", "power1_average")) + glob.glob(os.path.join(dev, "hwmon", "hwmon*", "power1_input")):
+            out["power_w"] = round(int(open(f).read().strip()) / 1e6, 1)
+            break
+        return out
+    except Exception as exc:             # noqa
+        return {"error": repr(exc)[:120]}
 
 
 def _time_forward(fn, device, warm: int, iters: int) -> float:
@@ -350,16 +383,22 @@ def run_e2e(args, world, rank, device, dtype, dist):
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    clocks = {}
+
     def timed_region():
         """W warm-up steps, then EXACTLY K timed steps between two fences; max over the ranks."""
         for _ in range(max(args.warmup, 1)):
             out = step()
         fence()
+        clocks["before"] = read_clocks(device) if rank == 0 else {}
         t_start = time.perf_counter()
         for _ in range(args.steps):
             out = step()
+        if rank == 0:                        # while the last steps are still executing: the clocks of the loaded chip
+            clocks["during"] = read_clocks(device)
         fence()
         el = torch.tensor([time.perf_counter() - t_start], dtype=torch.float64, device=device)
+        clocks["after"] = read_clocks(device) if rank == 0 else {}
         if world > 1:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         return out, float(el.item())
@@ -428,6 +467,42 @@ def sdma_self_test(total, M, D, dtype, device, depth, world, rank, dist, shard):
     return g, None
 
 
+def run_sdma_leg(args, world) -> None:
+    """--gather auto, AFTER the rccl line has been printed and the process group is gone: the same workload with the
+    copy-engine gather in FRESH processes (``python bench.py --gpus N --gather sdma``, its own rendezvous port), bounded by
+    --sdma-leg-timeout.  Whatever happens in there — a failed self-test, a device fault, a hang — this process only reads
+    the child's exit code; the outcome is printed as a second line and the exit code of the run stays 0."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--gather", "sdma", "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--batch", str(args.batch), "--scaling", args.scaling, "--scale-factor", str(args.scale_factor),
+           "--hidden-size", str(args.hidden_size), "--dtype", args.dtype, "--layout", args.layout, "--backend", args.backend,
+           "--gather-depth", str(args.gather_depth), "--no-cpu-baseline", "--no-extras", "--min-seconds", "0"]
+    if args.single_device:
+        cmd.append("--single-device")
+    if args.sync_gather:
+        cmd.append("--sync-gather")
+    for kv in args.tune:
+        cmd += ["--tune", kv]
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE",
+                        "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS")}
+    leg = {"command": " ".join(cmd[1:])}
+    try:
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.sdma_leg_timeout,
+                             start_new_session=True)
+        lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+        if res.returncode == 0 and lines:
+            d = json.loads(lines[-1])
+            leg.update(status="ok", value=d["value"], unit=d["unit"], ms_per_step=d["ms_per_step"], multi_gpu=d.get("multi_gpu"))
+        else:
+            leg.update(status=f"failed (exit code {res.returncode})", stderr_tail=res.stderr[-600:])
+    except subprocess.TimeoutExpired:
+        leg.update(status=f"timed out after {args.sdma_leg_timeout:.0f} s (its processes were killed)")
+    except Exception as exc:             # noqa: nothing in this leg may cost the run its exit code
+        leg.update(status=f"not run: {exc!r}"[:300])
+    print(json.dumps({"sdma_leg": leg}), flush=True)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
@@ -494,12 +569,14 @@ def main():
     transports, sdma_note = [], None
     if gather and not args.hd:
         if args.gather == "sdma":
-            dgather = shard.DirectGather(total, (M, D), dtype, device, depth=args.gather_depth)
-            transports = ["sdma"]
-        elif args.gather == "auto":
+            # proven on this node before anything is timed with it (set-up errors and a failed self-test are raised on every rank)
             dgather, sdma_note = sdma_self_test(total, M, D, dtype, device, args.gather_depth, world, rank, dist, shard)
-            transports = ["rccl", "sdma"] if dgather is not None else ["rccl"]
-        else:
+            if dgather is None:
+                raise RuntimeError(f"--gather sdma: the copy-engine transport failed its self-test on this node: {sdma_note}")
+            if os.environ.get("TP_BENCH_INJECT_SDMA_FAULT") and rank == world - 1:
+                os.abort()                   # (tests: a device fault inside the sdma leg must not cost the rccl line)
+            transports = ["sdma"]
+        else:                                # rccl, and the first leg of auto
             transports = ["rccl"]
         if "rccl" in transports and not args.sync_gather and not ragged:
             pipe = shard.TokenGatherPipeline(total, depth=2)
@@ -542,33 +619,31 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    clocks = {}
+
     def timed_region():
         """W warm-up steps, then EXACTLY K timed steps between two fences; max over the ranks."""
         for _ in range(max(args.warmup, 1)):
             out = step()
         fence()
+        clocks["before"] = read_clocks(device) if rank == 0 else {}
         t_start = time.perf_counter()
         for _ in range(args.steps):
             out = step()
+        if rank == 0:                        # while the last steps are still executing: the clocks of the loaded chip
+            clocks["during"] = read_clocks(device)
         fence()
         el = torch.tensor([time.perf_counter() - t_start], dtype=torch.float64, device=device)
+        clocks["after"] = read_clocks(device) if rank == 0 else {}
         if world > 1:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         return out, float(el.item())
 
     with torch.no_grad():
         per_transport = {}
-        if len(transports) > 1:              # auto: the same protocol once per transport; the faster one is the job's
-            for t_name in transports:
-                cur["t"] = t_name
-                y, el = timed_region()
-                per_transport[t_name] = el
-            cur["t"] = min(per_transport, key=per_transport.get)     # (max-reduced times: every rank picks the same)
-            elapsed = per_transport[cur["t"]]
-        else:
-            y, elapsed = timed_region()
-            if transports:
-                per_transport[cur["t"]] = elapsed
+        y, elapsed = timed_region()
+        if transports:
+            per_transport[cur["t"]] = elapsed
         chosen = cur["t"]
 
         # The K steps above are the driver's; at 4 ms per step they are < 0.1 s of clock.  Keep stepping (same loop, same
@@ -655,12 +730,11 @@ def main():
                 extra["gather_only_ms"] = probe_sdma(dgather)
             else:
                 extra["gather_only_ms"] = probe_rccl()
-            # the transport NOT chosen, on the same shard: in auto mode it has been set up and proven already; on request
-            # (--probe-other-gather) it is set up here
-            if not args.hd and not ragged:
-                if chosen == "sdma" and ("rccl" in transports or args.probe_other_gather):
+            # the transport NOT chosen, on the same shard, on request only (--probe-other-gather: it is set up IN this process)
+            if not args.hd and not ragged and args.probe_other_gather:
+                if chosen == "sdma":
                     extra["other_gather"] = {"mode": "rccl", "gather_only_ms": probe_rccl()}
-                elif chosen == "rccl" and (dgather is not None or args.probe_other_gather):
+                elif chosen == "rccl":
                     g2 = dgather if dgather is not None else shard.DirectGather(total, (M, D), dtype, device, depth=args.gather_depth,
                                                                                  timeout_ms=5000)
                     extra["other_gather"] = {"mode": "sdma", "gather_only_ms": probe_sdma(g2)}
@@ -736,6 +810,7 @@ def main():
         }
         # the store-heavy short-K launch over the launch that stores nothing: 0.8 - 0.9 normally, ~1.3 in the slow memory-side
         # power state some boxes put a 32 ... 128-image forward in (profiles/r03u_mid_batch_anomaly.txt)
+        out["clocks"] = clocks
         if stage_ms[2] > 0 and s == 2:
             out["memory_side"] = {"mlp0_over_statistics": round(stage_ms[8] / stage_ms[2], 3),
                                   "note": "mlp0_gelu / kv_layer2_stats of this rank's forward; ~0.85 normal, >= 1.2 = the node's slow memory-side power state"}
@@ -750,7 +825,7 @@ def main():
                                 "gather": chosen if chosen else "rccl",
                                 "gather_requested": args.gather,
                                 "transports_timed_ms_per_step": {k: round(1e3 * v / args.steps, 4) for k, v in per_transport.items()},
-                                "sdma_self_test": ("passed" if dgather is not None else f"not used: {sdma_note}") if args.gather == "auto" and not args.hd else None,
+                                "sdma_self_test": "passed" if (dgather is not None and chosen == "sdma") else None,
                                 "sdma_flags_fine_grained": (dgather.flags_fine_grained if dgather is not None else None),
                                 "pipelined": bool((chosen == "rccl" and pipe is not None) or (chosen == "sdma" and not args.sync_gather)),
                                 "gather_bytes_received_per_rank": int((total - B) * M * D * 2),
@@ -775,6 +850,8 @@ def main():
 
     if world > 1:
         dist.destroy_process_group()
+    if world > 1 and rank == 0 and args.gather == "auto" and gather and not args.hd:
+        run_sdma_leg(args, world)
 
 
 if __name__ == "__main__":
