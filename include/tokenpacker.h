@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TP_ABI_VERSION 3
+#define TP_ABI_VERSION 4
 
 typedef enum tp_status {
     TP_OK = 0,
@@ -59,6 +59,7 @@ typedef struct tp_desc {
     int32_t out_dtype;     /* tp_dtype of `out`: == dtype, or TP_F32                              */
     float   ln_eps;        /* 1e-6 (builder.py:48)                                                */
     int32_t flags;         /* 0 | TP_DESC_TRAIN_PACK (tp_pack_weights) | TP_DESC_MASKED (sizes of a masked forward); other bits 0 */
+    const struct tp_tuning* tuning;    /* ABI 4: the tuning context this call reads its knobs from; NULL: the process-wide table */
 } tp_desc;
 /* tp_pack_weights only: the image will serve tp_forward_train / tp_backward — the weights that only the inference
  * schedules read (Wc / d of the fused LayerNorm chain, the per-head transposes of the absorbed schedule, the out_proj fold)
@@ -276,11 +277,8 @@ typedef struct tp_linear_args {
     int32_t tile;              /* 0 = auto, 128 or 256: force the block tile                       */
     int32_t reserved1;
     float*  row_stats_out;     /* ROW_STATS                                                        */
-    void*   sk_workspace;      /* optional: tp_linear_sk_workspace_bytes() of scratch — lets the launch run as stream-K     */
-                               /* (TP_TUNE_STREAM_K; tp_linear zeroes the flag words itself).  NULL: never stream-K        */
 } tp_linear_args;
 int tp_linear(const tp_linear_args* args, void* stream);
-size_t tp_linear_sk_workspace_bytes(void);
 /* (mean, M2) slabs [parts][M][2] written by a TP_LINEAR_ROW_STATS call -> per-row (mean, rstd)
  * [M][2] of nn.LayerNorm(ln_dim, eps) (biased variance), for a TP_LINEAR_LN_FOLD call.  ln_dim == parts * 128. */
 int tp_ln_finalize(const float* row_stats, int parts, int64_t M, int ln_dim, float eps,
@@ -401,39 +399,45 @@ size_t tp_test_pack_qr_scratch_bytes(void);
 int tp_test_pack_qr(const void* w2_f16, const float* b2, void* r_f16, float* c_tilde, float* wbar, void* scratch, void* stream);
 
 /* ---- tuning knobs (benchmarks / deployment policy; defaults are what tp_forward ships with) --------------------
- * The table is ONE process-wide array of atomics: tp_set_tuning is NOT scoped to a stream, a call or a thread — two
- * host threads that want different values must serialise their forwards around it.  Everything else in this header
- * is reentrant (state is per call, per thread (error string) or per caller stream (the forked query-side stream; at
- * most 64 distinct caller streams per device get one, later ones run the query side on the caller's stream)). */
-enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all half tiles by CU rounds) | 128 | 256 */
+ * Two places hold them (ABI 4):
+ *   - a TUNING CONTEXT (tp_tuning_create): a private copy of the table.  Every entry point that takes a tp_desc reads its
+ *     knobs from desc->tuning for the whole call — plan, workspace layout, every launch — whatever other threads do to
+ *     other contexts or to the process-wide table meanwhile.  This is what a serving worker uses (the reference runs
+ *     `generate` on a thread per request, llava/serve/model_worker.py:174): one context per model instance, set once.
+ *   - the PROCESS-WIDE table (tp_set_tuning / tp_get_tuning): what a descriptor with tuning == NULL, the per-kernel entry
+ *     points (tp_linear ...) and tp_tuning_create's initial copy read.  One array of atomics, NOT scoped to a stream, a
+ *     call or a thread: benchmarks and tests flip it between calls; concurrent forwards that rely on it see each
+ *     other's changes (several knobs change the summation order, i.e. low bits).
+ * Everything else in this header is reentrant (state is per call, per thread (error string) or per caller stream (the
+ * forked query-side stream; at most 64 distinct caller streams per device get one, later ones run the query side on the
+ * caller's stream)). */
+enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all half tiles by CU rounds) | 128 | 256 | 2: every tile of the
+                                   ping-pong kernel a 128 x 256 half tile (tests, A/Bs) */
        TP_TUNE_XCD_SWIZZLE = 1, /* 1 (default) | 0 | 2 = A/B: W-half-resident blocking of an XCD's tiles (measured null) */
-       TP_TUNE_GEMM_KERNEL = 2, /* 256-tile main loop: 0 persistent ping-pong (default; tile shape by round count)
-                                   | 1 two-phase | 2 ping-pong, one tile per workgroup
-                                   | 3 persistent ping-pong, every tile a 128x256 half tile            */
-       TP_TUNE_Q_SIDE_STREAM = 5, /* 1 (default): the query side runs on a forked side stream | 0: one stream */
-       TP_TUNE_DYNAMIC_TILES = 4, /* 1 (default): persistent GEMMs draw tiles from per-XCD queues | 0: static striding */
-       TP_TUNE_FOLD_OUT_PROJ = 3, /* out_proj folded into mlp[0] (W = Wm0·Wout, one GEMM less): 0 (default) auto = on the absorbed
+       TP_TUNE_FOLD_OUT_PROJ = 2, /* out_proj folded into mlp[0] (W = Wm0·Wout, one GEMM less): 0 (default) auto = on the absorbed
                                      schedule and on the scale_factor-2 schedule with attention in the in-projection epilogues
                                      (TP_TUNE_FUSE_ATTN 0) | 1 always | 2 never; read at PACK time (tp_pack_weights builds the
                                      folded weight only then) and at forward time */
-       TP_TUNE_RESERVE_CUS = 6,   /* r in 0..7 (default 0): persistent GEMMs launch (CUs/8 - r) workgroups per XCD, leaving
+       TP_TUNE_DYNAMIC_TILES = 3, /* 1 (default): persistent GEMMs draw tiles from per-XCD queues | 0: static striding */
+       TP_TUNE_Q_SIDE_STREAM = 4, /* 1 (default): the query side runs on a forked side stream | 0: one stream */
+       TP_TUNE_RESERVE_CUS = 5,   /* r in 0..7 (default 0): persistent GEMMs launch (CUs/8 - r) workgroups per XCD, leaving
                                      r CUs per XCD to kernels of other streams (RCCL's all-gather overlapping the next forward) */
-       TP_TUNE_ABSORB_KV = 7,     /* K/V in-projection absorbed into the query side (see tp_forward): 0 auto (scale_factor >= 3),
+       TP_TUNE_ABSORB_KV = 6,     /* K/V in-projection absorbed into the query side (see tp_forward): 0 auto (scale_factor >= 3),
                                      1 never, 2 always */
-       TP_TUNE_FUSE_KV_LN = 8,    /* 1 (default): inference: the layer in front of every LayerNorm is computed for its row statistics
+       TP_TUNE_FUSE_KV_LN = 7,    /* 1 (default): inference: the layer in front of every LayerNorm is computed for its row statistics
                                      only and the in-projection behind it reads that layer's INPUT through a pre-multiplied weight
                                      (K/V side: Wc = W'·W2, no H2 written — on the plain schedule through the in-projection GEMM, on
                                      the absorbed schedule through qt and the per-head V GEMM, the attention kernel walking Hkv; query
                                      side: W'q·Wq1, no Q1pre written) | 0: the pre-LayerNorm activations are written and read back.
                                      Read at PACK time (the pre-multiplied weights are built only then) and at forward time */
-       TP_TUNE_LN_MERGE = 9,      /* 0 (default): inference, a LayerNorm's consumer on the 128-tile kernel (small batches) merges the
+       TP_TUNE_LN_MERGE = 8,      /* 0 (default): inference, a LayerNorm's consumer on the 128-tile kernel (small batches) merges the
                                      producer's (mean, M2) slabs itself — no ln_finalize launch | 1: always the separate launch */
-       TP_TUNE_FUSE_ATTN = 10,    /* inference, scale_factor 2, fused LayerNorm chain, no attn_mask: 0 (default) the first K/V layer reads
+       TP_TUNE_FUSE_ATTN = 9,    /* inference, scale_factor 2, fused LayerNorm chain, no attn_mask: 0 (default) the first K/V layer reads
                                      the tower's rows in REGION-MAJOR order (a region's 4 tokens = 4 consecutive rows of every K/V-side
                                      tensor) and region attention runs inside the epilogues of the K and V in-projection GEMMs — K, V
                                      are never written, no attention kernel | 1 off (raster rows, tp_region_attention's kernel) |
                                      2 region-major rows + the separate attention kernel (A/B, tests) */
-       TP_TUNE_SPLIT_K = 11,      /* small batches (B <= 3 at the shipped shapes), inference: the two K = 4096 GEMMs of the path (first
+       TP_TUNE_SPLIT_K = 10,      /* small batches (B <= 3 at the shipped shapes), inference: the two K = 4096 GEMMs of the path (first
                                      K/V layer, mlp[2]) — 80 and 64 workgroups walking 64 K-slabs each at B = 1, a serial chain of
                                      ~0.65 us steps — are split over K into up to 8 groups of the 128-tile kernel with fp32 partials
                                      and a fixed-order reduction kernel that applies the epilogue (B = 1: 0.157 -> 0.137 ms).
@@ -442,33 +446,31 @@ enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all hal
                                      differ from the same images inside a larger batch; 2 keeps an image's bits independent of the
                                      batch it travels in (what rounds 1-2 shipped; the reference's eager PyTorch does not have that
                                      property either). */
-       TP_TUNE_SMALL_GEMM_WAVES = 12, /* the 128 x 128-tile kernel as 4 waves of 64 x 64 or 8 waves of 32 x 64 (bit-identical): 0 (default)
+       TP_TUNE_SMALL_GEMM_WAVES = 11, /* the 128 x 128-tile kernel as 4 waves of 64 x 64 or 8 waves of 32 x 64 (bit-identical): 0 (default)
                                      auto by the number of workgroups of the launch | 4 | 8.  A launch of the 8-wave form with at
                                      most one workgroup per CU keeps FOUR K-slabs in its LDS ring (three in flight, counted vmcnt;
                                      round 3: a one-image forward 0.132 -> 0.128 ms) | 9: 8 waves with the double buffer (A/B) */
-       TP_TUNE_STREAM_K = 13,     /* stream-K decomposition of a persistent GEMM launch whose tile count is not a multiple of the CU
-                                     count (tp_gemm8.hip SK): the launch's K-tiles are shared evenly, a tile cut in two hands one fp32
-                                     partial over between neighbouring workgroups (write-through slab + flag, fixed summation order).
-                                     0 / 1 (default) off | 2 on for every eligible launch.  OPT-IN: correct and deterministic, but
-                                     measured SLOWER than full rounds + a half-tile tail at every batch (B = 32: +22 % per forward) —
-                                     de-phased K ranges lose the L2 sharing of operands between a tile row's workgroups
-                                     (profiles/r03_stream_k_ab.txt).  With 2 an image's low bits depend on the batch it travels in. */
-       TP_TUNE_TRI_STATS = 14,    /* inference, fused LayerNorm chain: 0 (default, round 3) the layer in front of a LayerNorm is replaced, for
+       TP_TUNE_TRI_STATS = 12,    /* inference, fused LayerNorm chain: 0 (default, round 3) the layer in front of a LayerNorm is replaced, for
                                      its statistics, by the UPPER-TRIANGULAR factor R of its centred weight (W2c = Q R, Householder QR at
                                      pack time): var = ||R h + c~||^2 / E, a sum of squares, on 40 of the 64 (N-tile, K-tile) pairs; the
                                      consumers use centred chain weights (W'·W2c, W'·b2c) and need no mean at all | 1: the full
                                      statistics GEMM on W2 with (mean, M2), as rounds 1-2 shipped */
-       TP_TUNE_PAIR_GEMM = 15,    /* the 256 x 128-tile "pair" kernel (tp_gemm_pair.hip: two co-resident 4-wave workgroups per CU, a tile's
+       TP_TUNE_PAIR_GEMM = 13,    /* the 256 x 128-tile "pair" kernel (tp_gemm_pair.hip: two co-resident 4-wave workgroups per CU, a tile's
                                      epilogue under the other workgroup's MFMAs; bit-identical to the other GEMM kernels): 0 (default) for
                                      the short-K launches of 1.5 .. 2.5 rounds of its 512 workgroups, where it measured faster — on
                                      full-chip launches its 1.5 x operand traffic loses 12-17 % | 1 never | 2 wherever it is supported */
-       TP_TUNE_PAIR_STAGGER = 16, /* percent (default 100) of half a tile period by which the second workgroup of each CU starts late in
+       TP_TUNE_PAIR_STAGGER = 14, /* percent (default 100) of half a tile period by which the second workgroup of each CU starts late in
                                      a pair-kernel launch (0: both start together — their epilogues then coincide for ever) */
-       TP_TUNE_PAIR_DEBUG = 17,   /* timing probes of the pair kernel (fp16 -> fp16 plain launches; results are GARBAGE with 1..4): low 3 bits 1 no
+       TP_TUNE_PAIR_DEBUG = 15,   /* timing probes of the pair kernel (fp16 -> fp16 plain launches; results are GARBAGE with 1..4): low 3 bits 1 no
                                      DMA in the K loop | 2 no fragment reads | 3 no barriers | 4 no MFMAs; + 8: one workgroup per CU */
-       TP_TUNE_COUNT_ = 18 };
+       TP_TUNE_COUNT_ = 16 };
 int tp_set_tuning(int key, int value);
 int tp_get_tuning(int key);                  /* the library's current value (not a binding's shadow copy); -1: bad key */
+typedef struct tp_tuning tp_tuning;          /* opaque; host memory owned by the library until tp_tuning_destroy */
+tp_tuning* tp_tuning_create(void);           /* a copy of the process-wide table of the moment; NULL: out of memory */
+void tp_tuning_destroy(tp_tuning* t);        /* (no call that was handed `t` may still be running) */
+int tp_tuning_set(tp_tuning* t, int key, int value);
+int tp_tuning_get(const tp_tuning* t, int key);          /* -1: bad key / NULL */
 
 /* Per-caller-stream state: tp_forward forks the query side onto a side stream it keeps per (device, caller stream).
  * A caller that destroys a stream it has passed to tp_forward releases that state first — a later stream the runtime

@@ -15,12 +15,10 @@ def stream_ptr():
 
 
 def linear(A, W, bias=None, flags=0, tile=0, rows_per_batch=0, a_batch_stride=0, lda=None, M=None,
-           mean_rstd=None, colsum=None, want_stats=False, out_dtype=None, kern=0, sync=True, sk_workspace=None):
+           mean_rstd=None, colsum=None, want_stats=False, out_dtype=None, half=False, sync=True):
     """C = epilogue(A · W^T) through tp_linear.  A may be a 2-D tensor or a raw (ptr-bearing) tensor
-    with explicit M / lda / batch strides.  tile: 0 auto | 128 | 256; a NEGATIVE tile (-256) or kern=1
-    selects the two-phase 256-tile main loop instead of the default ping-pong kernel (tp_gemm8.hip)."""
-    if tile < 0:
-        tile, kern = -tile, 1
+    with explicit M / lda / batch strides.  tile: 0 auto | 128 (the 128-tile kernel, tp_gemm.hip) | 256 (the ping-pong kernel,
+    tp_gemm8.hip); half=True: every tile of the ping-pong kernel a 128 x 256 half tile (TP_TUNE_GEMM_TILE = 2)."""
     lib = _capi.load_library()
     N, K = W.shape
     if M is None:
@@ -42,18 +40,20 @@ def linear(A, W, bias=None, flags=0, tile=0, rows_per_batch=0, a_batch_stride=0,
     args.row_mean_rstd = mean_rstd.data_ptr() if mean_rstd is not None else None
     args.colsum = colsum.data_ptr() if colsum is not None else None
     args.tile = tile
-    args.sk_workspace = sk_workspace.data_ptr() if sk_workspace is not None else None
     stats = None
     if want_stats:
         parts = lib.tp_linear_stats_parts(ctypes.byref(args))
         assert parts > 0
         stats = torch.full((parts, M, 2), float("nan"), dtype=torch.float32, device=W.device)
         args.row_stats_out = stats.data_ptr()
-    _capi.set_tuning(_capi.TP_TUNE_GEMM_KERNEL, kern)
+    if half:
+        args.tile = 0
+        _capi.set_tuning(_capi.TP_TUNE_GEMM_TILE, 2)
     try:
         _capi.check(lib.tp_linear(ctypes.byref(args), stream_ptr()), "tp_linear")
     finally:
-        _capi.set_tuning(_capi.TP_TUNE_GEMM_KERNEL, 0)
+        if half:
+            _capi.set_tuning(_capi.TP_TUNE_GEMM_TILE, 0)
     if sync:
         torch.cuda.synchronize()
     return (C, stats) if want_stats else C

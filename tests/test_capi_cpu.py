@@ -27,11 +27,11 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    # tp_desc: 6 x int32 + float + int32; tp_weights: 23 pointers
-    assert ctypes.sizeof(_capi.tp_desc) == 32
+    # tp_desc: 6 x int32 + float + int32 + the tuning-context pointer; tp_weights: 23 pointers
+    assert ctypes.sizeof(_capi.tp_desc) == 40
     assert ctypes.sizeof(_capi.tp_weights) == 23 * ctypes.sizeof(ctypes.c_void_p)
     assert len(_capi.WEIGHT_FIELDS) == 23
-    assert ctypes.sizeof(_capi.tp_linear_args) == 8 * 4 + 3 * 8 + 6 * 8 + 2 * 4 + 8 + 8
+    assert ctypes.sizeof(_capi.tp_linear_args) == 8 * 4 + 3 * 8 + 6 * 8 + 2 * 4 + 8
 
 
 def test_sizes_and_descriptor_validation():
@@ -224,3 +224,30 @@ def test_gather_entry_points_reject_bad_arguments():
     assert lib.tp_gather_push(1, None, fake, 16, None, fake, None, 0) == E
     assert lib.tp_gather_push(0, None, None, 0, None, None, None, 0) == E          # no sequence cell
     assert _capi.TP_IPC_HANDLE_BYTES == 64
+
+
+def test_tuning_contexts_are_private_copies():
+    """ABI 4: tp_tuning_create copies the process-wide table of the moment; setting a context does not touch the table or another
+    context; an entry point that takes a tp_desc reads desc->tuning (here: the workspace size follows the context's SPLIT_K, not the
+    table's); bad keys / NULL are errors."""
+    lib = _capi.load_library()
+    a, b = _capi.TuningContext(), _capi.TuningContext(split_k=2)
+    try:
+        for k, v in _capi._TUNING_DEFAULTS.items():
+            assert a.get(k) == v
+        assert b.get(_capi.TP_TUNE_SPLIT_K) == 2 and a.get(_capi.TP_TUNE_SPLIT_K) == 0 and _capi.get_tuning(_capi.TP_TUNE_SPLIT_K) == 0
+        size = lambda t: lib.tp_workspace_bytes(ctypes.byref(_capi.make_desc(1, 24, 2, 4096, _capi.TP_BF16, tuning=t)))
+        partials = 512 * 128 * 128 * 4
+        assert size(None) == size(a) and partials <= size(a) - size(b) < partials + 4096
+        _capi.set_tuning(_capi.TP_TUNE_SPLIT_K, 2)                  # the table changes under the contexts' feet: they do not move
+        try:
+            assert size(None) == size(b) and size(a) - size(b) >= partials and a.get(_capi.TP_TUNE_SPLIT_K) == 0
+            c = _capi.TuningContext()                               # ... and a NEW context starts from the table of the moment
+            assert c.get(_capi.TP_TUNE_SPLIT_K) == 2
+            c.close()
+        finally:
+            _capi.set_tuning(_capi.TP_TUNE_SPLIT_K, 0)
+        assert lib.tp_tuning_set(a.handle, _capi.TP_TUNE_COUNT, 0) == _capi.TP_ERR_INVALID_ARG
+        assert lib.tp_tuning_set(None, 0, 0) == _capi.TP_ERR_INVALID_ARG and lib.tp_tuning_get(None, 0) == -1
+    finally:
+        a.close(); b.close()

@@ -19,10 +19,10 @@ TOL_F32OUT = 2e-5
 TOL_ROUND = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
 
 
-# block-tile variants of the MFMA kernel: 128 (two-phase), 256 (ping-pong 8-wave, tp_gemm8.hip), -256 (two-phase 256)
-TILES = [128, 256, -256]
-# TP_TUNE_GEMM_KERNEL values for tile 256: ping-pong persistent 0 / one tile per workgroup 2 (tp_gemm8.hip)
-KERNS = [0, 2, 3]
+# block-tile variants of the MFMA kernels: 128 (two-phase, tp_gemm.hip), 256 (ping-pong 8-wave, tp_gemm8.hip)
+TILES = [128, 256]
+# the ping-pong kernel's tile shapes: 256 x 256 | every tile a 128 x 256 half tile (TP_TUNE_GEMM_TILE = 2)
+HALVES = [False, True]
 
 
 def _rand(shape, dtype, seed, scale=1.0):
@@ -129,32 +129,34 @@ def test_row_stats_do_not_depend_on_tile(dtype):
     W = _rand((1024, 256), dtype, 13, 256 ** -0.5)
     H1, s1 = gu.linear(A, W, tile=128, want_stats=True)
     H2, s2 = gu.linear(A, W, tile=256, want_stats=True)
-    H3, s3 = gu.linear(A, W, tile=-256, want_stats=True)
+    H3, s3 = gu.linear(A, W, tile=256, half=True, want_stats=True)
     assert torch.equal(H1, H2) and torch.equal(s1, s2)
     assert torch.equal(H1, H3) and torch.equal(s1, s3)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("K", [64, 128, 192, 256, 320, 1024])
-@pytest.mark.parametrize("kern", KERNS)
-def test_pingpong_short_and_odd_k(dtype, K, kern):
+@pytest.mark.parametrize("half", HALVES)
+def test_pingpong_short_and_odd_k(dtype, K, half):
     """K-tile counts 1..5 and 16 walk every prologue / tail variant of the ping-pong main loop."""
     M, N = 700, 512
     A = _rand((M, K), dtype, 50 + K)
     W = _rand((N, K), dtype, 51 + K, K ** -0.5)
     ref = _ref_linear(A, W)
-    C32 = gu.linear(A, W, out_dtype=torch.float32, tile=256, kern=kern)
-    gu.assert_close(C32, ref, f"pingpong K={K} {dtype} kern={kern}", TOL_F32OUT)
-    assert torch.equal(C32, gu.linear(A, W, out_dtype=torch.float32, tile=-256))
+    if half and K < 128:
+        pytest.skip("half tiles need K >= 128")
+    C32 = gu.linear(A, W, out_dtype=torch.float32, tile=256, half=half)
+    gu.assert_close(C32, ref, f"pingpong K={K} {dtype} half={half}", TOL_F32OUT)
+    assert torch.equal(C32, gu.linear(A, W, out_dtype=torch.float32, tile=128))
 
 
 @pytest.mark.parametrize("M,N,K,flags", [(36864, 4096, 4096, 0), (147456, 1024, 1024, _capi.TP_LINEAR_ROW_STATS),
                                          (36864, 4096, 1024, _capi.TP_LINEAR_GELU), (20000, 2048, 4096, _capi.TP_LINEAR_GELU)])
-@pytest.mark.parametrize("kern", KERNS)
-def test_pingpong_full_size_race_screen(M, N, K, flags, kern):
+@pytest.mark.parametrize("half", HALVES)
+def test_pingpong_full_size_race_screen(M, N, K, flags, half):
     """Full-size shapes of the B=256 path, random data, every CU busy for many rounds: the
-    ping-pong kernel must reproduce the two-phase kernel BIT FOR BIT (both accumulate each K-slab in the same
-    order), on every one of several back-to-back launches — a DMA/LDS race shows up as a differing tile."""
+    ping-pong kernel must reproduce the two-phase 128-tile kernel (tp_gemm.hip: other tiles, other main loop, same epilogue) BIT
+    FOR BIT (both accumulate each K-slab in the same order), on every one of several back-to-back launches — a DMA/LDS race shows up as a differing tile."""
     dtype = torch.bfloat16
     g = torch.Generator(device="cuda").manual_seed(77)
     A = torch.randn(M, K, generator=g, device="cuda").to(dtype)
@@ -162,9 +164,9 @@ def test_pingpong_full_size_race_screen(M, N, K, flags, kern):
     bias = torch.randn(N, generator=g, device="cuda")
     want_stats = bool(flags & _capi.TP_LINEAR_ROW_STATS)
     fl = flags & ~_capi.TP_LINEAR_ROW_STATS
-    ref = gu.linear(A, W, bias=bias, flags=fl, tile=-256, want_stats=want_stats, out_dtype=torch.float16)
+    ref = gu.linear(A, W, bias=bias, flags=fl, tile=128, want_stats=want_stats, out_dtype=torch.float16)
     for rep in range(4):
-        got = gu.linear(A, W, bias=bias, flags=fl, tile=256, kern=kern, want_stats=want_stats, out_dtype=torch.float16,
+        got = gu.linear(A, W, bias=bias, flags=fl, tile=256, half=half, want_stats=want_stats, out_dtype=torch.float16,
                         sync=False)
         if want_stats:
             assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), f"launch {rep}"

@@ -11,24 +11,16 @@ import os
 from ctypes import (POINTER, Structure, byref, c_char_p, c_float, c_int, c_int32, c_int64,
                     c_size_t, c_uint32, c_uint64, c_void_p)
 
-TP_ABI_VERSION = 3
+TP_ABI_VERSION = 4
 TP_BF16, TP_F16, TP_F32 = 0, 1, 2
 TP_OK, TP_ERR_INVALID_ARG, TP_ERR_BAD_SCALE, TP_ERR_WORKSPACE, TP_ERR_LAUNCH = 0, -1, -2, -3, -4
 TP_LINEAR_GELU, TP_LINEAR_LN_FOLD, TP_LINEAR_ROW_STATS = 1, 2, 4
 TP_LINEAR_NO_STORE = 64
-TP_TUNE_GEMM_TILE, TP_TUNE_XCD_SWIZZLE, TP_TUNE_GEMM_KERNEL, TP_TUNE_FOLD_OUT_PROJ, TP_TUNE_DYNAMIC_TILES = 0, 1, 2, 3, 4
-TP_TUNE_Q_SIDE_STREAM = 5
-TP_TUNE_RESERVE_CUS, TP_TUNE_ABSORB_KV, TP_TUNE_FUSE_KV_LN = 6, 7, 8
-TP_TUNE_FUSE_ATTN = 10
-TP_TUNE_LN_MERGE = 9
-TP_TUNE_SPLIT_K = 11
-TP_TUNE_SMALL_GEMM_WAVES = 12
-TP_TUNE_STREAM_K = 13
-TP_TUNE_TRI_STATS = 14
-TP_TUNE_PAIR_GEMM = 15
-TP_TUNE_PAIR_STAGGER = 16
-TP_TUNE_PAIR_DEBUG = 17
-TP_TUNE_COUNT = 18
+TP_TUNE_GEMM_TILE, TP_TUNE_XCD_SWIZZLE, TP_TUNE_FOLD_OUT_PROJ, TP_TUNE_DYNAMIC_TILES, TP_TUNE_Q_SIDE_STREAM = 0, 1, 2, 3, 4
+TP_TUNE_RESERVE_CUS, TP_TUNE_ABSORB_KV, TP_TUNE_FUSE_KV_LN, TP_TUNE_LN_MERGE, TP_TUNE_FUSE_ATTN = 5, 6, 7, 8, 9
+TP_TUNE_SPLIT_K, TP_TUNE_SMALL_GEMM_WAVES, TP_TUNE_TRI_STATS = 10, 11, 12
+TP_TUNE_PAIR_GEMM, TP_TUNE_PAIR_STAGGER, TP_TUNE_PAIR_DEBUG = 13, 14, 15
+TP_TUNE_COUNT = 16
 TP_WGRAD_X_TRANSPOSED = 1
 TP_NUM_STAGES = 10
 TP_NUM_DEBUG_BUFFERS = 9
@@ -49,7 +41,7 @@ EXPORTED_SYMBOLS = (
     "tp_wgrad", "tp_wgrad_workspace_bytes", "tp_packed_status_offset", "tp_debug_count_saturated",
     "tp_region_attention_absorbed", "tp_forward_masked",
     "tp_get_tuning", "tp_release_stream", "tp_test_side_cache_size", "tp_test_pair_launch_count", "tp_test_pair_occupancy", "tp_test_pack_qr", "tp_test_pack_qr_scratch_bytes",
-    "tp_linear_sk_workspace_bytes", "tp_gather_alloc_flags", "tp_gather_free_flags", "tp_gather_export", "tp_gather_open", "tp_gather_close", "tp_gather_push", "tp_gather_sync",
+    "tp_tuning_create", "tp_tuning_destroy", "tp_tuning_set", "tp_tuning_get", "tp_gather_alloc_flags", "tp_gather_free_flags", "tp_gather_export", "tp_gather_open", "tp_gather_close", "tp_gather_push", "tp_gather_sync",
 )
 
 # state-dict name -> tp_weights field order (include/tokenpacker.h)
@@ -71,7 +63,7 @@ class TokenPackerLibraryError(RuntimeError):
 class tp_desc(Structure):
     _fields_ = [("batch", c_int32), ("raw_grid", c_int32), ("scale_factor", c_int32),
                 ("hidden_size", c_int32), ("dtype", c_int32), ("out_dtype", c_int32),
-                ("ln_eps", c_float), ("flags", c_int32)]
+                ("ln_eps", c_float), ("flags", c_int32), ("tuning", c_void_p)]
 
 
 class tp_weights(Structure):
@@ -89,7 +81,7 @@ class tp_linear_args(Structure):
                 ("a_batch_stride", c_int64), ("lda", c_int64), ("ldc", c_int64),
                 ("A", c_void_p), ("W", c_void_p), ("bias", c_void_p), ("C", c_void_p),
                 ("row_mean_rstd", c_void_p), ("colsum", c_void_p),
-                ("tile", c_int32), ("reserved1", c_int32), ("row_stats_out", c_void_p), ("sk_workspace", c_void_p)]
+                ("tile", c_int32), ("reserved1", c_int32), ("row_stats_out", c_void_p)]
 
 
 class tp_hd_image(Structure):
@@ -152,14 +144,20 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.tp_linear.argtypes = [POINTER(tp_linear_args), c_void_p]
     lib.tp_ln_finalize.restype = c_int
     lib.tp_ln_finalize.argtypes = [c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_void_p]
-    lib.tp_linear_sk_workspace_bytes.restype = c_size_t
-    lib.tp_linear_sk_workspace_bytes.argtypes = []
     lib.tp_linear_stats_parts.restype = c_int
     lib.tp_linear_stats_parts.argtypes = [POINTER(tp_linear_args)]
     lib.tp_set_tuning.restype = c_int
     lib.tp_set_tuning.argtypes = [c_int, c_int]
     lib.tp_get_tuning.restype = c_int
     lib.tp_get_tuning.argtypes = [c_int]
+    lib.tp_tuning_create.restype = c_void_p
+    lib.tp_tuning_create.argtypes = []
+    lib.tp_tuning_destroy.restype = None
+    lib.tp_tuning_destroy.argtypes = [c_void_p]
+    lib.tp_tuning_set.restype = c_int
+    lib.tp_tuning_set.argtypes = [c_void_p, c_int, c_int]
+    lib.tp_tuning_get.restype = c_int
+    lib.tp_tuning_get.argtypes = [c_void_p, c_int]
     lib.tp_release_stream.restype = c_int
     lib.tp_release_stream.argtypes = [c_void_p]
     lib.tp_test_side_cache_size.restype = c_int
@@ -247,9 +245,44 @@ TP_WORKSPACE_STATUS_BYTES = 256
 
 
 def make_desc(batch: int, raw_grid: int, scale_factor: int, hidden_size: int, dtype: int,
-              out_dtype: int | None = None, ln_eps: float = 1e-6, flags: int = 0) -> tp_desc:
+              out_dtype: int | None = None, ln_eps: float = 1e-6, flags: int = 0, tuning=None) -> tp_desc:
+    """`tuning`: a TuningContext (or its raw handle) the call reads its knobs from; None = the process-wide table."""
+    handle = getattr(tuning, "handle", tuning)
     return tp_desc(batch, raw_grid, scale_factor, hidden_size, dtype,
-                   dtype if out_dtype is None else out_dtype, ln_eps, flags)
+                   dtype if out_dtype is None else out_dtype, ln_eps, flags, handle)
+
+
+class TuningContext:
+    """A private copy of the library's tuning table (``tp_tuning_create``).  Calls whose descriptor names it read their knobs
+    from it and from nothing else: another thread's ``set_tuning`` (the process-wide table) or another context cannot change
+    the schedule or the low bits of a forward that runs on this one (include/tokenpacker.h, "tuning knobs")."""
+
+    def __init__(self, **knobs):
+        self.handle = load_library().tp_tuning_create()
+        if not self.handle:
+            raise MemoryError(last_error())
+        for name, value in knobs.items():
+            self.set(globals()["TP_TUNE_" + name.upper()], value)
+
+    def set(self, key: int, value: int) -> None:
+        check(load_library().tp_tuning_set(self.handle, key, value), "tp_tuning_set")
+
+    def get(self, key: int) -> int:
+        v = load_library().tp_tuning_get(self.handle, key)
+        if v == -1 and not (0 <= key < TP_TUNE_COUNT):
+            raise ValueError(f"tp_tuning_get: {last_error()}")
+        return v
+
+    def close(self) -> None:
+        if self.handle:
+            load_library().tp_tuning_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:        # noqa: interpreter shutdown
+            pass
 
 
 def strides3(st) -> "ctypes.Array":
@@ -257,10 +290,10 @@ def strides3(st) -> "ctypes.Array":
 
 
 # the library's defaults (tests reset the table to these)
-_TUNING_DEFAULTS = {TP_TUNE_GEMM_TILE: 0, TP_TUNE_XCD_SWIZZLE: 1, TP_TUNE_GEMM_KERNEL: 0, TP_TUNE_FOLD_OUT_PROJ: 0,
-                    TP_TUNE_DYNAMIC_TILES: 1, TP_TUNE_Q_SIDE_STREAM: 1, TP_TUNE_RESERVE_CUS: 0, TP_TUNE_ABSORB_KV: 0, TP_TUNE_FUSE_KV_LN: 1,
-                    TP_TUNE_FUSE_ATTN: 0, TP_TUNE_LN_MERGE: 0, TP_TUNE_SPLIT_K: 0, TP_TUNE_SMALL_GEMM_WAVES: 0, TP_TUNE_STREAM_K: 0, TP_TUNE_TRI_STATS: 0,
-                    TP_TUNE_PAIR_GEMM: 0, TP_TUNE_PAIR_STAGGER: 100, TP_TUNE_PAIR_DEBUG: 0}
+_TUNING_DEFAULTS = {TP_TUNE_GEMM_TILE: 0, TP_TUNE_XCD_SWIZZLE: 1, TP_TUNE_FOLD_OUT_PROJ: 0, TP_TUNE_DYNAMIC_TILES: 1, TP_TUNE_Q_SIDE_STREAM: 1,
+                    TP_TUNE_RESERVE_CUS: 0, TP_TUNE_ABSORB_KV: 0, TP_TUNE_FUSE_KV_LN: 1, TP_TUNE_LN_MERGE: 0, TP_TUNE_FUSE_ATTN: 0,
+                    TP_TUNE_SPLIT_K: 0, TP_TUNE_SMALL_GEMM_WAVES: 0, TP_TUNE_TRI_STATS: 0, TP_TUNE_PAIR_GEMM: 0, TP_TUNE_PAIR_STAGGER: 100,
+                    TP_TUNE_PAIR_DEBUG: 0}
 
 
 def set_tuning(key: int, value: int) -> None:
@@ -278,5 +311,5 @@ def get_tuning(key: int) -> int:
 
 
 __all__ = [n for n in dir() if n.startswith(("TP_", "tp_"))] + [
-    "load_library", "last_error", "check", "make_desc", "strides3", "set_tuning", "get_tuning",
+    "load_library", "last_error", "check", "make_desc", "strides3", "set_tuning", "get_tuning", "TuningContext",
     "TokenPackerLibraryError", "WEIGHT_FIELDS", "EXPORTED_SYMBOLS", "LIB_PATH", "byref"]

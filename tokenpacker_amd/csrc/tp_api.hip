@@ -40,8 +40,23 @@ int check_launch(const char* what) {
     return TP_OK;
 }
 
-static std::atomic<int> g_tuning[TP_TUNE_COUNT_] = {{0}, {1}, {0}, {0}, {1}, {1}, {0}, {0}, {1}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {100}, {0}};   // [6] RESERVE_CUS, [7] ABSORB_KV, [8] FUSE_KV_LN
-int tuning(int key) { return (key >= 0 && key < TP_TUNE_COUNT_) ? g_tuning[key].load() : 0; }
+// Tuning: the process-wide table and the per-call contexts (include/tokenpacker.h).  An entry point that takes a tp_desc opens a
+// TuningScope on desc->tuning: every tuning() read of that call, on that host thread, comes from the context (a plain array nobody
+// else writes while the call runs) — other threads' tp_set_tuning / tp_tuning_set on other contexts cannot reach it.
+static std::atomic<int> g_tuning[TP_TUNE_COUNT_] = {{0}, {1}, {0}, {1}, {1}, {0}, {0}, {1}, {0}, {0}, {0}, {0}, {0}, {0}, {100}, {0}};
+static_assert(TP_TUNE_XCD_SWIZZLE == 1 && TP_TUNE_DYNAMIC_TILES == 3 && TP_TUNE_Q_SIDE_STREAM == 4 && TP_TUNE_FUSE_KV_LN == 7 &&
+              TP_TUNE_PAIR_STAGGER == 14 && TP_TUNE_COUNT_ == 16, "defaults above are positional");
+}  // namespace tp
+struct tp_tuning { int v[TP_TUNE_COUNT_]; };
+namespace tp {
+static thread_local const tp_tuning* tls_tuning = nullptr;
+int tuning(int key) {
+    if (key < 0 || key >= TP_TUNE_COUNT_) return 0;
+    const tp_tuning* c = tls_tuning;
+    return c ? c->v[key] : g_tuning[key].load();
+}
+TuningScope::TuningScope(const tp_desc* d) : prev_(tls_tuning) { tls_tuning = d ? d->tuning : nullptr; }
+TuningScope::~TuningScope() { tls_tuning = (const tp_tuning*)prev_; }
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
@@ -61,6 +76,7 @@ PackedLayout packed_layout(int D) {
     L.w_c_q = take(E * E * 2);
     L.w_cc_kv = take(2 * E * E * 2);     L.d_cc_kv = take(2 * E * 4);
     L.w_cc_q = take(E * E * 2);          L.w_qt_cc = take(E * E * 2);
+    L.w_cc_v2 = take(2 * E * E * 2);
     L.w_r_kv = take(2 * E * E * 2);      L.c_r_kv = take(2 * E * 4);
     L.w_r_q = take(E * E * 2);
     L.wbar = take(3 * (E + 1) * 4);      L.scratch_qr = take(pack_qr_scratch_bytes(3));
@@ -94,7 +110,7 @@ WorkspaceLayout workspace_layout(int B, int grid, int s, int D, const SchedulePl
     L.stats_kv = take(2 * (size_t)8 * rows_kv * 2 * 4);     // up to 8 slabs (tile 128) per group
     L.mr_kv = take(2 * rows_kv * 2 * 4);                    // per-row (mean, rstd), 2 groups
     // K | V [2][rows_kv, E] (training, masked / plain schedules); the absorbed schedule keeps qt | u [2][rows_q, 8, E] there
-    L.kv = take_if(P.need_kv, P.absorb ? 2 * 8 * rows_q * E * 2 : 2 * rows_kv * E * 2);
+    L.kv = take_if(P.need_kv, P.absorb ? (P.u_split ? 3 : 2) * 8 * rows_q * E * 2 : 2 * rows_kv * E * 2);   // qt | u (| u's residual)
     L.q1pre = take_if(P.need_q1pre, rows_q * E * 2);
     L.stats_q = take((size_t)8 * rows_q * 2 * 4);
     L.mr_q = take(rows_q * 2 * 4);
@@ -103,7 +119,6 @@ WorkspaceLayout workspace_layout(int B, int grid, int s, int D, const SchedulePl
     L.a1 = take_if(P.need_a1, rows_q * E * 2);
     L.a2 = take(rows_q * (size_t)D * 2);
     L.counters = take(kCounterBytes);                       // tile-queue heads + stream-K flags of every launch, zeroed per forward
-    L.sk_slabs = take(kStreamKSlabBytes);                   // stream-K partial accumulators (one 256 KiB slab per workgroup)
     L.splitk = take_if(P.split_k, kSplitKBytes);
     L.z1 = L.z2 = kNoSlab;
     if (P.train) { L.z1 = take(rows_kv * 2 * E * 2); L.z2 = take(rows_q * (size_t)D * 2); }
@@ -181,6 +196,7 @@ SchedulePlan plan_schedule(const tp_desc* d, bool train, bool masked) {
     const int fmode = tuning(TP_TUNE_FOLD_OUT_PROJ);
     P.fold = !train && (fmode == 1 || (fmode == 0 && (P.absorb || P.fuse_attn)));
     P.tri = !train && chain && tuning(TP_TUNE_TRI_STATS) != 1;
+    P.u_split = P.absorb_raw && P.tri;
     P.split_k = tuning(TP_TUNE_SPLIT_K) != 2 && !train && d->batch <= 8;      // (default on since round 3: see the header)
     P.need_h2 = train || !(P.fuse_ln || P.absorb_raw);
     P.need_kv = train || P.absorb || !P.fuse_attn;
@@ -265,6 +281,23 @@ int tp_get_tuning(int key) {
     return g_tuning[key].load();
 }
 
+tp_tuning* tp_tuning_create(void) {
+    tp_tuning* t = new (std::nothrow) tp_tuning;
+    if (!t) { set_error("tp_tuning_create: out of memory"); return nullptr; }
+    for (int k = 0; k < TP_TUNE_COUNT_; ++k) t->v[k] = g_tuning[k].load();
+    return t;
+}
+void tp_tuning_destroy(tp_tuning* t) { delete t; }
+int tp_tuning_set(tp_tuning* t, int key, int value) {
+    if (!t || key < 0 || key >= TP_TUNE_COUNT_) { set_error("tp_tuning_set: bad context / key %d", key); return TP_ERR_INVALID_ARG; }
+    t->v[key] = value;
+    return TP_OK;
+}
+int tp_tuning_get(const tp_tuning* t, int key) {
+    if (!t || key < 0 || key >= TP_TUNE_COUNT_) { set_error("tp_tuning_get: bad context / key %d", key); return -1; }
+    return t->v[key];
+}
+
 }  // extern "C"
 namespace tp {
 // Images one forward launch sequence can take: every GEMM output of the path must stay below the 4 GiB a launch addresses
@@ -282,16 +315,19 @@ using namespace tp;
 extern "C" {
 
 size_t tp_packed_weight_bytes(const tp_desc* desc) {
+    TuningScope tuning_scope(desc);
     if (validate_desc(desc) != TP_OK) return 0;
     return packed_layout(desc->hidden_size).total;
 }
 
 size_t tp_packed_status_offset(const tp_desc* desc) {
+    TuningScope tuning_scope(desc);
     if (validate_desc(desc) != TP_OK) return 0;
     return packed_layout(desc->hidden_size).status;
 }
 
 size_t tp_workspace_bytes(const tp_desc* desc) {
+    TuningScope tuning_scope(desc);
     if (validate_desc(desc) != TP_OK) return 0;
     const long long bc = max_images_per_launch(desc);    // larger batches run as chunks of this size through one workspace
     const int b = (bc >= 1 && desc->batch > bc) ? (int)bc : desc->batch;
@@ -302,6 +338,7 @@ size_t tp_workspace_bytes(const tp_desc* desc) {
 
 int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, size_t packed_bytes,
                     void* stream_) {
+    TuningScope tuning_scope(desc);
     int rc = validate_desc(desc);
     if (rc != TP_OK) return rc;
     if (!raw || !packed) { set_error("tp_pack_weights: NULL argument"); return TP_ERR_INVALID_ARG; }
@@ -379,6 +416,18 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
         for (int g = 0; g < 2; ++g)
             TP_TRY(pack_qr_extract_launch(P + L.scratch_qr, g, P + L.w_r_kv + (size_t)g * E * E * 2, (float*)(P + L.c_r_kv) + g * E, stream, sat));
         TP_TRY(pack_qr_extract_launch(P + L.scratch_qr, 2, P + L.w_r_q, nullptr, stream, sat));
+        // The centred chain weights are built from the UNROUNDED fold (round 4): W'_nk = W_nk gamma_k is exact in fp32, the fp16 W'
+        // the unfused schedules keep is its rounding `hi`; with lo = fp16(W' − hi) the product (hi + lo)·W2 carries the fold to
+        // ~2^-22, so the fold's rounding (one of the ~6 fp16 roundings in series on the value path) is gone from Wcc / dcc — which
+        // need no rowsum of the ROUNDED W' either (no mean term in the centred form).  The QR workspace is dead by now: it holds lo
+        // [E, E] fp16, the second product [E, E] fp32 and the exact rowsum / bias fold.
+        char* const xs = P + L.scratch_qr;
+        char* const lo16 = xs;
+        float* const P2 = (float*)(xs + E * E * 2);
+        float* const c_ex = (float*)(xs + E * E * 2 + E * E * 4);
+        float* const d_ex = c_ex + E;
+        static_assert(kEmbed * kEmbed * 6 + 2 * kEmbed * 4 <= 3 * (size_t)kEmbed * (kEmbed + 1) * 8, "QR scratch holds the residual products");
+        const void* const gammas[3] = {raw->ln_k_1_weight, raw->ln_v_1_weight, raw->ln_q_1_weight};
         for (int g = 0; g < 2; ++g) {
             TP_TRY(pack_transpose_f16_launch(P + L.w_kv2 + (size_t)g * E * E * 2, P + L.scratch_t, (int)E, stream));   // W2^T [k][j]
             GemmArgs a = plain_gemm(P + L.w_in_kv + (size_t)g * E * E * 2, E, P + L.scratch_t, P + L.scratch_p, E, (int)E, (int)E,
@@ -388,12 +437,24 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
             TP_TRY(pack_round_f16_launch((const float*)(P + L.scratch_p), P + L.w_c_kv + (size_t)g * E * E * 2, (long long)E * E, stream, sat));
             TP_TRY(pack_bias_fold_launch(P + L.w_in_kv + (size_t)g * E * E * 2, (const float*)(P + L.b_kv2) + g * E, nullptr,
                                          (float*)(P + L.d_in_kv) + g * E, (int)E, (int)E, stream));
-            // the centred chain: Wc' = W'·W2c = Wc - c (x) wbar,  d' = W'·b2c = d - c mean(b2)   (c = rowsum of the rounded W')
-            TP_TRY(pack_center_product_launch((const float*)(P + L.scratch_p), (const float*)(P + L.c_in_kv) + g * E, wbar + g * (E + 1),
-                                              P + L.w_cc_kv + (size_t)g * E * E * 2, (const float*)(P + L.d_in_kv) + g * E,
-                                              (float*)(P + L.d_cc_kv) + g * E, stream, sat));
+            // the centred chain: Wc' = W'·W2c = (hi + lo)·W2 - c (x) wbar,  d' = W'·b2c = W'·b2 - c mean(b2)   (c = rowsum of the EXACT W')
+            TP_TRY(pack_ln_fold_residual_launch(dt, inw + (size_t)(1 + g) * E * E * 2, gammas[g], (const float*)(P + L.b_kv2) + g * E, lo16,
+                                                c_ex, d_ex, (int)E, (int)E, stream));
+            GemmArgs a2 = plain_gemm(lo16, E, P + L.scratch_t, (char*)P2, E, (int)E, (int)E, (int)E, nullptr, 0);
+            a2.tile = 128;
+            TP_TRY(gemm_launch(TP_F16, TP_F32, a2, stream));
+            TP_TRY(pack_center_product_launch((const float*)(P + L.scratch_p), c_ex, wbar + g * (E + 1),
+                                              P + L.w_cc_kv + (size_t)g * E * E * 2, d_ex,
+                                              (float*)(P + L.d_cc_kv) + g * E, stream, sat, P2));
         }
         TP_TRY(pack_head_transpose_launch(P + L.w_cc_kv, P + L.w_qt_cc, stream));
+        {   // Wc'_v with every row twice side by side: the absorbed schedule's per-head V GEMM contracts u = hi | lo (2 E wide)
+            const char* src = P + L.w_cc_kv + E * E * 2;
+            for (int half = 0; half < 2; ++half) {
+                hipError_t e2 = hipMemcpy2DAsync(P + L.w_cc_v2 + half * E * 2, 2 * E * 2, src, E * 2, E * 2, E, hipMemcpyDeviceToDevice, stream);
+                if (e2 != hipSuccess) { set_error("tp_pack_weights: hipMemcpy2DAsync: %s", hipGetErrorString(e2)); return TP_ERR_LAUNCH; }
+            }
+        }
         // (the absorbed schedule on this chain: qt = per-head Q_h·Wc_k,h — the per-head transposes of the ROUNDED Wc_k)
         TP_TRY(pack_head_transpose_launch(P + L.w_c_kv, P + L.w_qt_c, stream));
         {   // query side: Q = rstd·(q0·Wcq^T − mu·c_q) + b'_q,  Wcq = W'q·Wq1  (q_proj_1 has no bias)
@@ -402,8 +463,12 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
             a.tile = 128;
             TP_TRY(gemm_launch(TP_F16, TP_F32, a, stream));
             TP_TRY(pack_round_f16_launch((const float*)(P + L.scratch_p), P + L.w_c_q, (long long)E * E, stream, sat));
-            TP_TRY(pack_center_product_launch((const float*)(P + L.scratch_p), (const float*)(P + L.c_in_q), wbar + 2 * (E + 1),
-                                              P + L.w_cc_q, nullptr, nullptr, stream, sat));
+            TP_TRY(pack_ln_fold_residual_launch(dt, inw, gammas[2], nullptr, lo16, c_ex, nullptr, (int)E, (int)E, stream));
+            GemmArgs a2 = plain_gemm(lo16, E, P + L.scratch_t, (char*)P2, E, (int)E, (int)E, (int)E, nullptr, 0);
+            a2.tile = 128;
+            TP_TRY(gemm_launch(TP_F16, TP_F32, a2, stream));
+            TP_TRY(pack_center_product_launch((const float*)(P + L.scratch_p), c_ex, wbar + 2 * (E + 1),
+                                              P + L.w_cc_q, nullptr, nullptr, stream, sat, P2));
         }
         hipError_t e = hipMemsetD32Async((hipDeviceptr_t)(status + 2), 1, 1, stream);
         if (e != hipSuccess) { set_error("tp_pack_weights: hipMemsetD32Async(status): %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
@@ -471,6 +536,7 @@ int tp_hd_slice(const float* image, int H, int W, int h_block, int w_block, int 
 }
 
 int tp_debug_count_saturated(const tp_desc* desc, const void* workspace, size_t workspace_bytes, int32_t* counts, void* stream_) {
+    TuningScope tuning_scope(desc);
     TP_TRY(validate_desc(desc));
     if (!workspace || !counts) { set_error("tp_debug_count_saturated: NULL argument"); return TP_ERR_INVALID_ARG; }
     const int B = desc->batch, g = desc->raw_grid, s = desc->scale_factor, D = desc->hidden_size;
@@ -486,7 +552,7 @@ int tp_debug_count_saturated(const tp_desc* desc, const void* workspace, size_t 
         {W.q0, rows_q * E}, {W.hkv, rows_kv * 2 * E},
         {W.h2, n_if(W.h2, 2 * rows_kv * E)},
         // (the absorbed schedule keeps qt | u [2][rows_q, 8, E] where K | V would be)
-        {W.kv, n_if(W.kv, plan.absorb ? 2 * rows_q * 8 * E : 2 * rows_kv * E)},
+        {W.kv, n_if(W.kv, plan.absorb ? (plan.u_split ? 3 : 2) * rows_q * 8 * E : 2 * rows_kv * E)},
         {W.q1pre, n_if(W.q1pre, rows_q * E)},
         {W.q, rows_q * E}, {W.o, rows_q * E}, {W.a1, n_if(W.a1, rows_q * E)}, {W.a2, rows_q * (long long)D}};
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * TP_NUM_DEBUG_BUFFERS, stream);
@@ -582,17 +648,8 @@ int tp_linear(const tp_linear_args* a, void* stream) {
     g.M = a->M; g.N = a->N; g.K = a->K; g.flags = a->flags;
     g.groups = 1; g.tile = a->tile;
     if (a->flags & TP_LINEAR_OUT_F32) { set_error("tp_linear: TP_LINEAR_OUT_F32 was replaced by out_dtype = TP_F32"); return TP_ERR_INVALID_ARG; }
-    if (a->sk_workspace) {                              // [flags: one int per workgroup][slabs]
-        if ((uintptr_t)a->sk_workspace & 255) { set_error("tp_linear: sk_workspace must be 256-byte aligned"); return TP_ERR_INVALID_ARG; }
-        hipError_t e = hipMemsetAsync(a->sk_workspace, 0, kStreamKMaxWorkgroups * 4, (hipStream_t)stream);
-        if (e != hipSuccess) { set_error("tp_linear: hipMemsetAsync: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
-        g.sk_flags = (int*)a->sk_workspace;
-        g.sk_slabs = (float*)((char*)a->sk_workspace + kStreamKMaxWorkgroups * 4);
-    }
     return gemm_launch(a->dtype, a->out_dtype, g, (hipStream_t)stream);
 }
-
-size_t tp_linear_sk_workspace_bytes(void) { return kStreamKSlabBytes + kStreamKMaxWorkgroups * 4; }
 
 }  // extern "C"  (forward_impl has C++ linkage: tp_train.hip calls it too)
 
@@ -655,6 +712,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
                  const int64_t xm_strides[3], const void* packed_weights, void* out, void* workspace,
                  size_t workspace_bytes, void* stream_, void* const* stage_events, bool train,
                  const void* const* xm_parts, const float* attn_mask, int mask_mode) {
+    TuningScope tuning_scope(desc);
     TP_TRY(validate_desc(desc));
     TP_TRY(check_strides("x", x, x_strides));
     if (xm_parts) {                                     // x_multi given as the four [B, N, 1024] hidden-state slices
@@ -741,13 +799,8 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     auto launch = [&](int in_dt, int out_dt, GemmArgs& a, hipStream_t st) -> int {
         if (counters && launch_no < kMaxLaunches) {
             a.tile_counters = counters + 64 * launch_no;                         // [groups <= 8][8 XCDs] heads per launch
-            a.sk_flags = counters + 64 * kMaxLaunches + kStreamKMaxWorkgroups * launch_no;     // stream-K: one flag per workgroup
-            a.sk_slabs = (float*)(ws + W.sk_slabs);                              // (launches of one stream run one after the other)
             ++launch_no;
-        } else { a.tile_counters = nullptr; a.sk_flags = nullptr; a.sk_slabs = nullptr; }
-        // stream-K (GemmArgs::stream_k = 1: never): not for the training forward (its SAVE_PRE kernels cannot, and the whole
-        // forward must be the inference forward of the same schedule bit for bit); the query side's launches opt out themselves
-        if (train) a.stream_k = 1;
+        } else a.tile_counters = nullptr;
         a.sat_flag = (int*)(ws + W.status); a.sat_bit = 1 << stage_idx;          // sticky fp16-saturation bits, by stage (bit 0: query side)
         return gemm_launch(in_dt, out_dt, a, st);
     };
@@ -783,7 +836,6 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
                                 TP_LINEAR_ROW_STATS | (fuse_q ? TP_LINEAR_NO_STORE : 0));
         a.tri = tri ? 1 : 0;
         a.stats_out = (float*)(ws + W.stats_q);
-        a.stream_k = 1;                                 // (the query side may run beside the K/V side: one set of stream-K slabs)
         return launch(TP_F16, TP_F16, a, st);
     };
     // Small M (the 128-tile kernel): the consumer of a LayerNorm merges the producer's (mean, M2) slabs itself — one launch
@@ -805,7 +857,6 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         if (!merge_in_kernel(a, (const float*)(ws + W.stats_q), 0))
             TP_TRY(ln_finalize_launch((const float*)(ws + W.stats_q), (float*)(ws + W.mr_q), rows_q, parts_q, 1, E,
                                       desc->ln_eps, st, tri));
-        a.stream_k = 1;
         return launch(TP_F16, TP_F16, a, st);
     };
     const bool absorb = plan.absorb;
@@ -820,7 +871,8 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     const bool fuse_attn = plan.fuse_attn;
     char* const kv_slab = slab(W.kv);                                  // K | V, or qt | u on the absorbed schedule (NULL: neither)
     char* const qt = kv_slab;                                          // [rows_q, 8, E] fp16 (absorbed schedule)
-    char* const uu = kv_slab ? kv_slab + (size_t)rows_q * 8 * E * 2 : nullptr;   // [rows_q, 8, E] fp16
+    const bool u_split = plan.u_split;
+    char* const uu = kv_slab ? kv_slab + (size_t)rows_q * 8 * E * 2 : nullptr;   // [rows_q, 8, E] fp16 (u_split: [rows_q, 8, 2 E] = hi | lo)
     auto qt_gemm = [&](hipStream_t st) -> int {         // qt[m, h, :] = Q[m, h*128:(h+1)*128] · W'k[h*128:(h+1)*128, :]
         GemmArgs a = plain_gemm(ws + W.q, E, absorb_raw ? (tri ? pw + P.w_qt_cc : pw + P.w_qt_c) : pw + P.w_qt, qt, 8 * E, rows_q, E, kHeadDim, nullptr, 0);
         a.groups = kHeads; a.a_gs = kHeadDim * 2; a.w_gs = (long long)E * kHeadDim * 2; a.c_gs = E * 2;
@@ -948,15 +1000,18 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
             TP_TRY(region_attention_absorbed_launch(qt, ws + W.hkv, ws + W.hkv + (size_t)hkv_gs, (const float*)(ws + W.mr_kv),
                                                     (const float*)(ws + W.mr_kv) + (size_t)rows_kv * 2, uu, B, g, s, stream, attn_mask, mask_mode,
                                                     (int)hkv_ld, ws + W.q, (const float*)(tri ? pw + P.d_cc_kv : pw + P.d_in_kv),
-                                                    (const float*)(pw + P.c_in_kv), mr_u));
+                                                    (const float*)(pw + P.c_in_kv), mr_u, u_split));
         else
             TP_TRY(region_attention_absorbed_launch(qt, slab(W.h2), slab(W.h2) + kvE * 2, (const float*)(ws + W.mr_kv),
                                                     (const float*)(ws + W.mr_kv) + (size_t)rows_kv * 2, uu, B, g, s, stream, attn_mask, mask_mode));
         // O[:, h*128:(h+1)*128] = u[:, h, :] · W'v[h*128:(h+1)*128, :]^T + b'v   (eight N = 128 groups)
         // RAW: a_h (u_h · Wc_v,h^T + d_v,h - (e_h / a_h) c_v,h) + b'v,h — a LayerNorm-fold epilogue with (mean, rstd) := mr_u
-        GemmArgs a = plain_gemm(uu, 8 * E, (absorb_raw ? (tri ? pw + P.w_cc_kv : pw + P.w_c_kv) : pw + P.w_in_kv) + (size_t)E * E * 2, ws + W.o, E, rows_q, kHeadDim, E,
-                                (const float*)(pw + P.b_in_kv) + E, absorb_raw ? TP_LINEAR_LN_FOLD : 0);
-        a.groups = kHeads; a.a_gs = E * 2; a.w_gs = (long long)kHeadDim * E * 2; a.c_gs = kHeadDim * 2; a.bias_gs = kHeadDim;
+        // u_split: the contraction runs over hi | lo (K = 2 E) against Wc'_v's rows written twice — u's fp16 rounding drops out
+        const int uK = u_split ? 2 * E : E;
+        GemmArgs a = plain_gemm(uu, 8 * uK, u_split ? pw + P.w_cc_v2
+                                                    : (absorb_raw ? (tri ? pw + P.w_cc_kv : pw + P.w_c_kv) : pw + P.w_in_kv) + (size_t)E * E * 2,
+                                ws + W.o, E, rows_q, kHeadDim, uK, (const float*)(pw + P.b_in_kv) + E, absorb_raw ? TP_LINEAR_LN_FOLD : 0);
+        a.groups = kHeads; a.a_gs = uK * 2; a.w_gs = (long long)kHeadDim * uK * 2; a.c_gs = kHeadDim * 2; a.bias_gs = kHeadDim;
         if (absorb_raw) {
             a.acc_init = (const float*)(tri ? pw + P.d_cc_kv : pw + P.d_in_kv) + E; a.acc_init_gs = kHeadDim;
             a.colsum = (const float*)(pw + P.c_in_kv) + E; a.colsum_gs = kHeadDim;

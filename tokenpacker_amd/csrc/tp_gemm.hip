@@ -213,6 +213,7 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
 // ---- host side ------------------------------------------------------------------------------------
 int gemm_pick_tile(int M, int N, int forced, int groups) {
     if (forced == 0) forced = tuning(TP_TUNE_GEMM_TILE);
+    if (forced == 2) forced = 0;                        // (half tiles: gemm_route's business)
     if (forced == 128) return 128;
     if (forced == 256 && N % 256 == 0) return 256;
     if (N % 256 != 0) return 128;
@@ -294,9 +295,7 @@ static int launch_types(const GemmArgs& a, hipStream_t stream) {
             return TP_ERR_INVALID_ARG;
         }
     }
-    if (tile == 256)
-        return strided ? launch_cfg<TI, TO, 256, 256, 128, 64, 1>(a, stream)
-                       : launch_cfg<TI, TO, 256, 256, 128, 64, 0>(a, stream);
+    if (tile == 256) { set_error("tp gemm: 256-column tiles are served by the ping-pong kernel (tp_gemm8.hip)"); return TP_ERR_INVALID_ARG; }
     return strided ? launch_cfg<TI, TO, 128, 128, 64, 64, 1>(a, stream)
                    : launch_cfg<TI, TO, 128, 128, 64, 64, 0>(a, stream);
 }
@@ -309,20 +308,9 @@ static int launch_types(const GemmArgs& a, hipStream_t stream) {
 // with a half tile at 0.75 of a full tile's time (0.63 at K <= 1024; a one-round tail also pays its first tile's
 // un-hidden DMA latency) and a second launch at ~8 us (dependent-launch gap) relative to a full tile's
 // 8.4 + 1.47 K/64 us (profiles/README.md).  Same epilogue, bit-identical results whatever the shape.
-// (d) stream-K (tp_gemm8.hip SK, TP_TUNE_STREAM_K = 2, opt-in): the launch's K-tiles shared evenly by the workgroups; measured
-//   slower than (b) at every batch (stream_k_pays below).
-enum { ROUTE_SMALL = 0, ROUTE_G8 = 1, ROUTE_G8_HALF = 2, ROUTE_G8_SPLIT = 3, ROUTE_G8_SK = 4 };
-// Opt-in only (TP_TUNE_STREAM_K = 2).  The cost model this started with — U K-tiles at the main loop's 1.47 us + one epilogue per
-// tile started + ~14 us for the partial handed over and the one taken in, against the round count of the alternatives —
-// predicted -8 % on the first K/V layer of a 32-image shard; MEASURED: +39 % (0.265 -> 0.369 ms), +25 % per forward at B = 100
-// (profiles/r03_stream_k_ab.txt): contiguous K-tile ranges put the workgroups that share an A row-panel / a W column-slice at
-// DIFFERENT K positions, the XCD's L2 stops serving 3 of 4 / 7 of 8 operand fetches and the launch becomes fabric-bound.
-static bool stream_k_pays(const GemmArgs& a, double /*best_other*/) {
-    double u = 0;
-    return tuning(TP_TUNE_STREAM_K) == 2 && a.stream_k != 1 && gemm8_stream_k_eligible(a, &u);
-}
+enum { ROUTE_SMALL = 0, ROUTE_G8 = 1, ROUTE_G8_HALF = 2, ROUTE_G8_SPLIT = 3 };
 static int gemm_route(const GemmArgs& a, long long* head_rows_out) {
-    const bool free_choice = a.tile == 0 && tuning(TP_TUNE_GEMM_TILE) == 0 && tuning(TP_TUNE_GEMM_KERNEL) == 0 &&
+    const bool free_choice = a.tile == 0 && tuning(TP_TUNE_GEMM_TILE) == 0 &&
                              a.m_begin == 0 && a.m_end == 0 && !a.half_tiles && !a.A_parts[0] && a.N % 256 == 0 && a.K >= 2 * BK;
     if (free_choice) {
         const int cus = gemm8_persistent_cus(), groups = a.groups > 0 ? a.groups : 1;
@@ -344,23 +332,15 @@ static int gemm_route(const GemmArgs& a, long long* head_rows_out) {
                 const long long tail_half = (long long)((a.M - head_rows + 127) / 128) * tiles_n;
                 if (head_rows < a.M) cost_b = (double)full + half * (double)rounds(tail_half) + launch;
             }
-            if (stream_k_pays(a, cost_a < cost_b ? (cost_a < cost_c ? cost_a : cost_c) : (cost_b < cost_c ? cost_b : cost_c))) return ROUTE_G8_SK;
             if (TH >= 64 && cost_c < cost_a - 0.05 && cost_c <= cost_b) return ROUTE_G8_HALF;
             if (cost_b < cost_a - 0.05) { *head_rows_out = head_rows; return ROUTE_G8_SPLIT; }
         }
     }
-    if ((a.half_tiles && a.N % 256 == 0) ||
-        (gemm_pick_tile(a.M, a.N, a.tile, a.groups) == 256 && tuning(TP_TUNE_GEMM_KERNEL) != 1)) {
-        // (a four-part A operand takes none of the tile-shape alternatives above, but its launch must make the SAME stream-K
-        // decision as the concatenated operand's — the two forms are bit-identical, tests/test_gpu_parts.py)
-        if (a.A_parts[0] && a.tile == 0 && tuning(TP_TUNE_GEMM_TILE) == 0 && tuning(TP_TUNE_GEMM_KERNEL) == 0 && !a.half_tiles) {
-            GemmArgs cat = a;
-            for (int i = 0; i < 4; ++i) cat.A_parts[i] = nullptr;
-            long long h = 0;
-            if (gemm_route(cat, &h) == ROUTE_G8_SK) return ROUTE_G8_SK;
-        }
-        return ROUTE_G8;
-    }
+    // TP_TUNE_GEMM_TILE = 2 (tests, A/Bs): every tile of the ping-pong kernel a 128 x 256 half tile
+    if (tuning(TP_TUNE_GEMM_TILE) == 2 && a.tile == 0 && !a.half_tiles && !a.A_parts[0] && a.N % 256 == 0 && a.K >= 2 * BK &&
+        a.m_begin == 0 && a.m_end == 0)
+        return ROUTE_G8_HALF;
+    if ((a.half_tiles && a.N % 256 == 0) || gemm_pick_tile(a.M, a.N, a.tile, a.groups) == 256) return ROUTE_G8;
     return ROUTE_SMALL;
 }
 
@@ -372,7 +352,7 @@ static int gemm_route(const GemmArgs& a, long long* head_rows_out) {
 // a 32 .. 64-image shard (profiles/r04b_pair_ab.json).  TP_TUNE_PAIR_GEMM: 0 that policy | 1 never | 2 wherever supported.
 static bool gemm_takes_pair_route(int in_dtype, int out_dtype, const GemmArgs& a) {
     const int mode = tuning(TP_TUNE_PAIR_GEMM);
-    if (mode == 1 || a.tile != 0 || tuning(TP_TUNE_GEMM_TILE) != 0 || tuning(TP_TUNE_GEMM_KERNEL) != 0 || a.stream_k == 2) return false;
+    if (mode == 1 || a.tile != 0 || tuning(TP_TUNE_GEMM_TILE) != 0) return false;
     if (!gemm_pair_supports(in_dtype, out_dtype, a)) return false;
     if (mode == 2) return true;
     const long long tiles = (long long)((a.M + 255) / 256) * (a.N / 128) * (a.groups > 0 ? a.groups : 1);
@@ -443,10 +423,6 @@ int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stre
             rest.m_begin = (int)head_rows; rest.half_tiles = 1; rest.tile_counters = nullptr;
             if (int rc = gemm8_launch(in_dtype, out_dtype, head, stream)) return rc;
             return gemm8_launch(in_dtype, out_dtype, rest, stream);
-        }
-        if (route == ROUTE_G8_SK) {
-            GemmArgs sk = a; sk.stream_k = 2;
-            return gemm8_launch(in_dtype, out_dtype, sk, stream);
         }
         if (route == ROUTE_G8) return gemm8_launch(in_dtype, out_dtype, a, stream);
     }

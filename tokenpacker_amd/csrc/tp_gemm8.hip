@@ -111,26 +111,14 @@ constexpr int G8_DEPTH = 3;                        // DMA groups left in flight 
 //   Both take their epilogue parameters by LDS-DMA (one 1-KiB instruction per wave, issued with the prologue, two buffers)
 //   instead of the register-carried prefetch of the other modes: nothing rides through the epilogue in registers a
 //   compiler-inserted s_waitcnt could trip over, and the count of instructions behind the queries is the same in every wave.
-// SK (stream-K, GemmArgs::stream_k): instead of whole tiles, the nwg workgroups share the launch's K-tiles EVENLY — the linearised
-//   (tile, K-tile) space is cut into nwg contiguous ranges (cuts closer than SK_MINSEG K-tiles to a tile boundary snap onto it), so
-//   a launch of 2.25 tiles per CU costs 2.25 tile times instead of 3 (or 2 + a half-tile tail launch).  A range covers at least one
-//   whole tile (checked on the host), hence a tile is shared by at most TWO workgroups, neighbours c and c + 1:
-//     c + 1 starts with the tile's TAIL K-range: its very first item; the fp32 accumulators go to slab c + 1 (256 KiB, write-through
-//           16-byte stores, every wave drains, ONE flag store) — at the START of the launch;
-//     c     ends with the tile's HEAD K-range: its last item; it polls flag c + 1 (long set by then), one agent-scope acquire, adds
-//           the slab to its accumulators and runs the ordinary epilogue.  Nobody waits for anybody who waits: no deadlock whatever
-//           the dispatch order; a neighbour that starts late only delays its one consumer.
-//   Summation order = head K-range, then + tail partial: fixed by the decomposition, i.e. deterministic for a given (M, N, K, CUs) —
-//   but NOT the order of the unsplit kernels: a split tile's low bits differ from the same rows computed inside another batch size.
-constexpr int SK_MINSEG = 4;
-template <typename TI, typename TO, int AMODE, bool PERSIST, bool TRAIN_EPI, bool HALF = false, int XMODE = 0, bool SK = false>
+template <typename TI, typename TO, int AMODE, bool TRAIN_EPI, bool HALF = false, int XMODE = 0>
 __global__ void __launch_bounds__(512, 2)
 gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int xcd_swizzle) {
-    static_assert(!SK || (PERSIST && !HALF && XMODE == 0 && !TRAIN_EPI && (AMODE == 0 || AMODE == 1 || AMODE == 2)), "stream-K: plain persistent full-tile kernels");
+    // (always persistent: the one-tile-per-workgroup form — 1..8 % slower, profiles/README.md — was removed in round 4)
     using X8 = typename Vec<TI>::x8;
     constexpr int BM = HALF ? G8_BM / 2 : G8_BM, BN = G8_BN, WM = BM / 2, WN = G8_WN;
     constexpr bool A_KMAJOR = (AMODE == 3 || AMODE == 4), W_KMAJOR = (AMODE == 3);
-    static_assert(!HALF || (!A_KMAJOR && PERSIST), "half tiles: K-contiguous operands, persistent kernel");
+    static_assert(!HALF || !A_KMAJOR, "half tiles: K-contiguous operands");
     constexpr int FM = WM / 16, FN = WN / 16;          // 8 x 4 (HALF: 4 x 4) accumulator fragments per wave
     constexpr int KBUF = HALF ? 3 * G8_GROUP : G8_BUF;  // one K-tile in the ring
     constexpr int RING = HALF ? 3 * KBUF : G8_RING;     // HALF: 144 KiB (three K-tiles), else 128 KiB (two)
@@ -138,8 +126,8 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
     constexpr int PAR_SZ = DMA_PAR ? (HALF ? 5120 : 7168) : G8_PAR;
     constexpr int PAR_MR = 2048, PAR_INIT = (DMA_PAR && HALF) ? 3072 : 4096, PAR_LG = HALF ? 4096 : 5120;
     constexpr int L_PAR = RING, L_RED = RING + g8_par_bytes(HALF, XMODE), L_NEXT = L_RED + g8_red_bytes(HALF, XMODE);
-    static_assert(L_NEXT + 256 == g8_lds_bytes(HALF, true, XMODE) || !PERSIST, "LDS layout");
-    static_assert(XMODE < 3 || (PERSIST && AMODE == 0 && !TRAIN_EPI), "attention epilogues: persistent kernel, contiguous A");
+    static_assert(L_NEXT + 256 == g8_lds_bytes(HALF, true, XMODE), "LDS layout");
+    static_assert(XMODE < 3 || (AMODE == 0 && !TRAIN_EPI), "attention epilogues: contiguous A");
     int ring_base = 0;                                  // XMODE 3, full tiles: parity of the buffer K-tile 0 of this tile uses
     int par_buf = 0;                                    // XMODE 3 / 4: the parameter buffer of the tile being computed
     auto ring_of = [&](const int kt) __attribute__((always_inline)) -> int {
@@ -156,8 +144,8 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
     const int wm = wave >> 2, wn = wave & 3;
     const int g = blockIdx.y;
     const int nk_full = p.K / BK;
-    int nk = nk_full;                                   // K-tiles of the item being set up / computed (SK: a K-range of a tile)
-    int kt_base = 0;                                    // SK: first K-tile of that range
+    int nk = nk_full;                                   // K-tiles of the tile being set up / computed
+    int kt_base = 0;                                    // XMODE 1 on a triangular weight: first K-tile of the tile
     const long long ldw = p.ldw_bytes ? p.ldw_bytes : (long long)p.K * 2;
 
     // ---- this workgroup's tile list: L, L + L_step, ... < L_end (indices into the tile_m-major tile order) ----
@@ -165,20 +153,6 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
     int L, L_end, L_step;
     int* queue = nullptr;                               // per-XCD queue head (tiles beyond the first round), or static
     int queue_base = 0;
-    int sk_u = 0, sk_end = 0, sk_c = 0;                // SK: this workgroup's range of K-tile units and its linear index
-    if constexpr (SK) {
-        // XCD-contiguous linear index: neighbours (which share a tile) sit on one XCD — their slab travels through one L2
-        sk_c = (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3);
-        const long long total = (long long)ntiles * nk_full;
-        auto bound = [&](const int c) -> int {
-            int b = (int)((long long)c * total / nwg);
-            const int r = b % nk_full;
-            if (r < SK_MINSEG) b -= r; else if (r > nk_full - SK_MINSEG) b += nk_full - r;
-            return b;
-        };
-        sk_u = bound(sk_c); sk_end = bound(sk_c + 1);
-        L = sk_u / nk_full; L_end = ntiles; L_step = 1;
-    } else
     if (ntiles <= nwg) {                               // one tile per workgroup
         L = xcd_swizzle ? xcd_remap(blockIdx.x, nwg) : (int)blockIdx.x;
         L_end = L + 1; L_step = 1;
@@ -186,7 +160,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         const int x = blockIdx.x & 7, q = ntiles >> 3, r = ntiles & 7;
         const int start = x * q + (x < r ? x : r);
         L = start + (blockIdx.x >> 3); L_end = start + q + (x < r ? 1 : 0); L_step = nwg >> 3;
-        if (PERSIST && p.tile_counters) { queue = p.tile_counters + g * 8 + x; queue_base = start + L_step; }
+        if (p.tile_counters) { queue = p.tile_counters + g * 8 + x; queue_base = start + L_step; }
     } else {
         L = blockIdx.x; L_end = ntiles; L_step = nwg;
     }
@@ -326,12 +300,12 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
                                                          is_a ? voff_a[sub][q] : voff_w[sub][q], 0, 0, 0);
             return;
         }
-        const int soff = ((SK || XMODE == 1) ? kt_base + kt : kt) * ROW_BYTES;      // (XMODE 1: kt_base = the triangular skip, 0 otherwise)
+        const int soff = (XMODE == 1 ? kt_base + kt : kt) * ROW_BYTES;      // (XMODE 1: kt_base = the triangular skip, 0 otherwise)
         if constexpr (is_a && AMODE == 2) {
             // K-tile kt lives in source kt / tpp: pick that source's base with scalar selects and rebuild the
             // descriptor (words 2, 3 are constants) — four resident descriptors cost 12 more SGPRs, which pushed
             // hipcc into VGPR-held descriptors and waterfall loops around every DMA instruction
-            const int ktg = SK ? kt_base + kt : kt;
+            const int ktg = kt;
             const int tpp = p.k_part / BK, part = ktg / tpp, so = (ktg - part * tpp) * ROW_BYTES;   // wave-uniform
             const char* b = part == 0 ? p.A_parts[0] : part == 1 ? p.A_parts[1] : part == 2 ? p.A_parts[2] : p.A_parts[3];
             const unsigned long long addr = (unsigned long long)(b + a_tile_off_cur);
@@ -525,11 +499,8 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         if constexpr (XMODE >= 2) {                         // accumulators start from a per-column constant (GemmArgs::acc_init)
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                f32x4 dv;
-                if constexpr (PERSIST)                      // staged in LDS with the tile's other epilogue parameters
-                    dv = *(const f32x4*)(smem + L_PAR + par_buf * PAR_SZ + PAR_INIT + (wn * WN + (lane >> 4) * 4 + j * 16) * 4);
-                else
-                    dv = *(const f32x4*)(p.acc_init + g * p.acc_init_gs + n0 + wn * WN + (lane >> 4) * 4 + j * 16);
+                // (staged in LDS with the tile's other epilogue parameters)
+                const f32x4 dv = *(const f32x4*)(smem + L_PAR + par_buf * PAR_SZ + PAR_INIT + (wn * WN + (lane >> 4) * 4 + j * 16) * 4);
 #pragma unroll
                 for (int i = 0; i < FM; ++i) acc[i][j] = dv;
             }
@@ -575,26 +546,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    if constexpr (!PERSIST) {
-        // ---- one tile per workgroup ---------------------------------------------------------------------
-        setup_tile(L);
-        issue_prologue();
-        if (nk >= 2) wait_vmcnt<8>(); else wait_vmcnt<4>();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        k_loop();
-        float2 mean_rstd[FM];
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            mean_rstd[i] = make_float2(0.f, 1.f);
-            if (p.flags & TP_LINEAR_LN_FOLD) {
-                int m = m0 + wm * WM + i * 16 + (lane & 15);
-                m = m < p.M ? m : p.M - 1;
-                mean_rstd[i] = *(const float2*)(p.stats_in + g * p.stats_in_gs + (long long)m * 2);
-            }
-        }
-        gemm_epilogue<TO, BM, BN, WM, WN, false, TRAIN_EPI, XMODE == 1>(acc, p, g, m0, n0, tile_n, wm, wn, lane, tid, mean_rstd, smem);
-    } else {
+    {
         // ---- persistent: walk the tile list ----------------------------------------------------------------
         // Epilogue parameters of a tile, one element per thread: threads 0..255 the tile's bias / colsum column,
         // threads 256..511 the (mean, rstd) of the tile's row.
@@ -656,10 +608,6 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
             else *(float2*)(par + 2 * BN + 2 * (tid - 256)) = pf_mr;
         };
 
-        if constexpr (SK) {                             // the first item may start inside a tile (the tile's tail K-range)
-            kt_base = sk_u - L * nk_full;
-            nk = nk_full - kt_base < sk_end - sk_u ? nk_full - kt_base : sk_end - sk_u;
-        }
         setup_tile(L);
         prefetch_params();
         if constexpr (DMA_PAR) issue_params(0);
@@ -681,20 +629,9 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
             const int m0c = m0, n0c = n0, tile_nc = tile_n;
             int Ln = L + L_step;
             if (queue) Ln = queue_base + __builtin_amdgcn_readfirstlane(*(const int*)(smem + L_NEXT));
-            bool sk_tail = false, sk_need = false;          // SK: this item was a tile's tail K-range / a head that lacks its tail
-            if constexpr (SK) {
-                sk_tail = kt_base > 0;
-                sk_need = !sk_tail && nk < nk_full;
-                sk_u += nk;
-                Ln = sk_u < sk_end ? sk_u / nk_full : L_end;
-            }
             const bool has_next = Ln < L_end;               // wave-uniform
             const char* lds_q = smem + ring_of(nk - 2) * KBUF + (HALF ? 0 : 2 * G8_GROUP);     // XMODE 3: where the queries are
             if (has_next) {
-                if constexpr (SK) {
-                    kt_base = sk_u - Ln * nk_full;
-                    nk = nk_full - kt_base < sk_end - sk_u ? nk_full - kt_base : sk_end - sk_u;
-                }
                 setup_tile(Ln);
                 if constexpr (XMODE == 3 && !HALF) ring_base ^= 1;
                 prefetch_params();
@@ -723,57 +660,6 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
             else if constexpr (XMODE == 4)
                 attn_sum_epilogue<BM, BN, WM, WN, true, PAR_LG>(acc, p, g, m0c, n0c, wm, wn, lane, mean_rstd,
                                                                 smem + L_PAR + par_buf * PAR_SZ);
-            else if constexpr (SK) {
-                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-                // slab c: [wave][fragment i * FN + j][lane] x 16 B — every wave instruction moves 1 KiB contiguous, and the
-                // consumer's lanes hold the same elements (same kernel, same layout)
-                // (the lane's offset is recomputed here from a laundered lane id: hoisted out of the tile loop it would cost the
-                // K loop a register it does not have)
-                int l_ = lane;
-                asm volatile("" : "+v"(l_));
-                const int voff = ((wave * (FM * FN)) * 64 + l_) * 16;
-                if (sk_tail) {
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                        (void*)(p.sk_slabs + (long long)sk_c * (BM * BN)), 0, BM * BN * 4, 0x00020000);
-#pragma unroll
-                    for (int i = 0; i < FM; ++i)
-#pragma unroll
-                        for (int j = 0; j < FN; ++j)
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[i][j]), rs, voff + (i * FN + j) * 1024, 0,
-                                                                   /* sc1: write-through */ 16);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave drains (and the next item's DMA prologue lands)
-                    __builtin_amdgcn_s_barrier();
-                    if (tid == 0) __hip_atomic_store(p.sk_flags + sk_c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    if (sk_need) {
-                        if (tid == 0) {                     // ONE lane polls ONE word, relaxed; then ONE agent-scope acquire
-                            int spins = 0;
-                            while (__hip_atomic_load(p.sk_flags + sk_c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-                                __builtin_amdgcn_s_sleep(8);
-                                if (++spins > (1 << 24)) {  // (a neighbour that never ran: give up loudly instead of hanging the stream)
-                                    if (p.sat_flag) __hip_atomic_fetch_or(p.sat_flag, 1 << 30, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    break;
-                                }
-                            }
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                        }
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_s_barrier();
-                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                            (void*)(p.sk_slabs + (long long)(sk_c + 1) * (BM * BN)), 0, BM * BN * 4, 0x00020000);
-#pragma unroll
-                        for (int i = 0; i < FM; ++i) {
-                            u32x4_t t[FN];
-#pragma unroll
-                            for (int j = 0; j < FN; ++j) t[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (i * FN + j) * 1024, 0, 16);
-#pragma unroll
-                            for (int j = 0; j < FN; ++j) acc[i][j] += __builtin_bit_cast(f32x4, t[j]);
-                        }
-                    }
-                    gemm_epilogue<TO, BM, BN, WM, WN, true, TRAIN_EPI, false>(acc, p, g, m0c, n0c, tile_nc, wm, wn, lane, tid,
-                                                                              mean_rstd, smem + L_RED, smem + L_PAR);
-                }
-            }
             else
             gemm_epilogue<TO, BM, BN, WM, WN, true, TRAIN_EPI, XMODE == 1>(acc, p, g, m0c, n0c, tile_nc, wm, wn, lane, tid,
                                                                            mean_rstd, smem + L_RED, smem + L_PAR);
@@ -806,27 +692,10 @@ int gemm8_persistent_cus() {
     return (per_xcd < 1 ? 1 : per_xcd) * 8;
 }
 
-// Whether a launch can run as stream-K (the SK form of gemm8_kernel), and its K-tile units per workgroup.
-bool gemm8_stream_k_eligible(const GemmArgs& a, double* units_per_wg) {
-    if (!a.sk_slabs || !a.sk_flags || a.groups > 1 || a.half_tiles || a.tt_rows > 0 || a.acc_init || a.attn_mode ||
-        (a.flags & (TP_LINEAR_NO_STORE | TP_LINEAR_SAVE_PRE | TP_LINEAR_GELU_BWD)) || a.N % G8_BN != 0 || a.m_begin != 0 || a.m_end != 0)
-        return false;
-    const int nwg = gemm8_persistent_cus(), nk = a.K / BK;
-    if (nwg % 8 != 0 || nwg > kStreamKMaxWorkgroups) return false;
-    const long long ntiles = (long long)((a.M + G8_BM - 1) / G8_BM) * (a.N / G8_BN);
-    if (ntiles <= nwg || ntiles * nk >= (1ll << 30)) return false;
-    const double u = (double)ntiles * nk / nwg;
-    // A tile is shared by at most TWO workgroups iff no range lies strictly inside a tile, i.e. every range is at least nk
-    // long: raw lengths are floor(u) or ceil(u), and snapping moves each cut by at most SK_MINSEG - 1.
-    if ((long long)u < nk + 2 * (SK_MINSEG - 1) || nk < 2 * SK_MINSEG) return false;
-    if (units_per_wg) *units_per_wg = u;
-    return true;
-}
-
-template <typename TI, typename TO, int AMODE, bool PERSIST, bool TRAIN_EPI, bool HALF = false, int XMODE = 0, bool SK = false>
+template <typename TI, typename TO, int AMODE, bool TRAIN_EPI, bool HALF = false, int XMODE = 0>
 static int launch8_cfg(const GemmArgs& a, hipStream_t stream) {
-    auto kern = gemm8_kernel<TI, TO, AMODE, PERSIST, TRAIN_EPI, HALF, XMODE, SK>;
-    constexpr int lds = g8_lds_bytes(HALF, PERSIST, XMODE);
+    auto kern = gemm8_kernel<TI, TO, AMODE, TRAIN_EPI, HALF, XMODE>;
+    constexpr int lds = g8_lds_bytes(HALF, true, XMODE);
     static_assert(lds <= 160 * 1024, "LDS budget of a CU");
     constexpr int TBM = HALF ? G8_BM / 2 : G8_BM;
     static std::once_flag once;
@@ -843,91 +712,63 @@ static int launch8_cfg(const GemmArgs& a, hipStream_t stream) {
     const int tiles_m = (m_end - a.m_begin + TBM - 1) / TBM, tiles_n = a.N / G8_BN;
     const int ntiles = tiles_m * tiles_n;
     int nwg = ntiles;
-    if (PERSIST) {                                     // one workgroup per CU (140 KiB of LDS each, 156 KiB with half tiles), a multiple of the 8 XCDs
-        const int cap = gemm8_persistent_cus();
-        if (nwg > cap && cap > 0) nwg = cap;
-    }
-    if constexpr (SK) {
-        if (!gemm8_stream_k_eligible(a, nullptr)) { set_error("tp gemm8: launch is not eligible for stream-K"); return TP_ERR_INVALID_ARG; }
-        nwg = gemm8_persistent_cus();
-    }
+    const int cap = gemm8_persistent_cus();            // one workgroup per CU (140 KiB of LDS each, 156 KiB with half tiles), a multiple of the 8 XCDs
+    if (nwg > cap && cap > 0) nwg = cap;
     dim3 grid((unsigned)nwg, (unsigned)a.groups, 1);
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, a, tiles_m, tiles_n, tuning(TP_TUNE_XCD_SWIZZLE));
     return check_launch("gemm8_kernel");
 }
 
-template <typename TI, typename TO, bool PERSIST>
-static int launch8_var(const GemmArgs& a, hipStream_t stream) {
+template <typename TI, typename TO>
+static int launch8_types(const GemmArgs& a, hipStream_t stream) {
     constexpr bool HALF_OUT = !std::is_same<TO, float>::value;
     const bool train_epi = (a.flags & (TP_LINEAR_SAVE_PRE | TP_LINEAR_GELU_BWD)) != 0;
     if (a.tt_rows > 0) {                                // K-major operands (weight gradients): fp32 partials only
-        if constexpr (std::is_same<TO, float>::value && PERSIST)
-            return a.tt_w_kcontig ? launch8_cfg<TI, TO, 4, PERSIST, false>(a, stream) : launch8_cfg<TI, TO, 3, PERSIST, false>(a, stream);
-        set_error("tp gemm8: K-major operands are supported with fp32 output on the persistent kernel only");
+        if constexpr (std::is_same<TO, float>::value)
+            return a.tt_w_kcontig ? launch8_cfg<TI, TO, 4, false>(a, stream) : launch8_cfg<TI, TO, 3, false>(a, stream);
+        set_error("tp gemm8: K-major operands are supported with fp32 output only");
         return TP_ERR_INVALID_ARG;
     }
     const bool strided_a = a.rows_per_batch < a.M || a.a_region_s > 0;     // (region-major rows: the strided-A kernels)
     if (a.A_parts[0]) {                                // K split over four sources: the forward's first layer only
         if (a.half_tiles) { set_error("tp gemm8: half tiles do not take a multi-part A operand"); return TP_ERR_INVALID_ARG; }
-        if constexpr (std::is_same<TO, f16_t>::value && PERSIST) {
-            if (a.stream_k == 2 && !train_epi) return launch8_cfg<TI, TO, 2, PERSIST, false, false, 0, true>(a, stream);
-            return train_epi ? launch8_cfg<TI, TO, 2, PERSIST, true>(a, stream) : launch8_cfg<TI, TO, 2, PERSIST, false>(a, stream);
-        }
-        set_error("tp gemm8: a multi-part A operand is supported for fp16 output on the persistent kernel only");
+        if constexpr (std::is_same<TO, f16_t>::value)
+            return train_epi ? launch8_cfg<TI, TO, 2, true>(a, stream) : launch8_cfg<TI, TO, 2, false>(a, stream);
+        set_error("tp gemm8: a multi-part A operand is supported for fp16 output only");
         return TP_ERR_INVALID_ARG;
     }
     const bool half = a.half_tiles != 0;
     if ((a.flags & TP_LINEAR_NO_STORE) || a.acc_init) {       // the two GEMMs of the fused LayerNorm chain
-        if constexpr (std::is_same<TI, f16_t>::value && std::is_same<TO, f16_t>::value && PERSIST) {
+        if constexpr (std::is_same<TI, f16_t>::value && std::is_same<TO, f16_t>::value) {
             if (strided_a || train_epi || ((a.flags & TP_LINEAR_NO_STORE) && a.acc_init) || (half && a.K < 2 * BK)) {
                 set_error("tp gemm8: NO_STORE / acc_init take a contiguous A, no training epilogue, and not both at once");
                 return TP_ERR_INVALID_ARG;
             }
             if (a.attn_mode == 1)
-                return half ? launch8_cfg<TI, TO, 0, PERSIST, false, true, 3>(a, stream) : launch8_cfg<TI, TO, 0, PERSIST, false, false, 3>(a, stream);
+                return half ? launch8_cfg<TI, TO, 0, false, true, 3>(a, stream) : launch8_cfg<TI, TO, 0, false, false, 3>(a, stream);
             if (a.attn_mode == 2)
-                return half ? launch8_cfg<TI, TO, 0, PERSIST, false, true, 4>(a, stream) : launch8_cfg<TI, TO, 0, PERSIST, false, false, 4>(a, stream);
+                return half ? launch8_cfg<TI, TO, 0, false, true, 4>(a, stream) : launch8_cfg<TI, TO, 0, false, false, 4>(a, stream);
             if (a.flags & TP_LINEAR_NO_STORE)
-                return half ? launch8_cfg<TI, TO, 0, PERSIST, false, true, 1>(a, stream) : launch8_cfg<TI, TO, 0, PERSIST, false, false, 1>(a, stream);
-            return half ? launch8_cfg<TI, TO, 0, PERSIST, false, true, 2>(a, stream) : launch8_cfg<TI, TO, 0, PERSIST, false, false, 2>(a, stream);
+                return half ? launch8_cfg<TI, TO, 0, false, true, 1>(a, stream) : launch8_cfg<TI, TO, 0, false, false, 1>(a, stream);
+            return half ? launch8_cfg<TI, TO, 0, false, true, 2>(a, stream) : launch8_cfg<TI, TO, 0, false, false, 2>(a, stream);
         }
-        set_error("tp gemm8: NO_STORE / acc_init are built for fp16 operands and output on the persistent kernel");
+        set_error("tp gemm8: NO_STORE / acc_init are built for fp16 operands and output");
         return TP_ERR_INVALID_ARG;
     }
-    if (half && (!PERSIST || a.K < 2 * BK)) {
-        set_error("tp gemm8: half tiles need the persistent kernel and K >= 128");
+    if (half && a.K < 2 * BK) {
+        set_error("tp gemm8: half tiles need K >= 128");
         return TP_ERR_INVALID_ARG;
     }
     if (train_epi) {
-        if constexpr (HALF_OUT && PERSIST) {
-            if (half) return strided_a ? launch8_cfg<TI, TO, 1, PERSIST, true, true>(a, stream)
-                                                    : launch8_cfg<TI, TO, 0, PERSIST, true, true>(a, stream);
-            return strided_a ? launch8_cfg<TI, TO, 1, PERSIST, true>(a, stream)
-                                          : launch8_cfg<TI, TO, 0, PERSIST, true>(a, stream);
+        if constexpr (HALF_OUT) {
+            if (half) return strided_a ? launch8_cfg<TI, TO, 1, true, true>(a, stream) : launch8_cfg<TI, TO, 0, true, true>(a, stream);
+            return strided_a ? launch8_cfg<TI, TO, 1, true>(a, stream) : launch8_cfg<TI, TO, 0, true>(a, stream);
         }
-        set_error("tp gemm8: training epilogues need a 16-bit output on the persistent kernel");
+        set_error("tp gemm8: training epilogues need a 16-bit output");
         return TP_ERR_INVALID_ARG;
     }
-    if constexpr (PERSIST) {
-        if (half) return strided_a ? launch8_cfg<TI, TO, 1, PERSIST, false, true>(a, stream)
-                                                : launch8_cfg<TI, TO, 0, PERSIST, false, true>(a, stream);
-        if (a.stream_k == 2)                            // gemm_launch's decision (gemm8_stream_k_eligible + its cost model)
-            return strided_a ? launch8_cfg<TI, TO, 1, PERSIST, false, false, 0, true>(a, stream)
-                             : launch8_cfg<TI, TO, 0, PERSIST, false, false, 0, true>(a, stream);
-    }
-    return strided_a ? launch8_cfg<TI, TO, 1, PERSIST, false>(a, stream)
-                                  : launch8_cfg<TI, TO, 0, PERSIST, false>(a, stream);
-}
-
-// TP_TUNE_GEMM_KERNEL: 0 persistent (default) | 2 one tile per workgroup
-template <typename TI, typename TO>
-static int launch8_types(const GemmArgs& a, hipStream_t stream) {
-    if (tuning(TP_TUNE_GEMM_KERNEL) == 2) return launch8_var<TI, TO, false>(a, stream);
-    if (tuning(TP_TUNE_GEMM_KERNEL) == 3 && !a.half_tiles && !a.A_parts[0] && a.tt_rows == 0 && a.K >= 2 * BK) {
-        GemmArgs h = a; h.half_tiles = 1;               // (A/B and tests: every tile of the launch as a half tile)
-        return launch8_var<TI, TO, true>(h, stream);
-    }
-    return launch8_var<TI, TO, true>(a, stream);
+    if (half) return strided_a ? launch8_cfg<TI, TO, 1, false, true>(a, stream) : launch8_cfg<TI, TO, 0, false, true>(a, stream);
+    return strided_a ? launch8_cfg<TI, TO, 1, false>(a, stream) : launch8_cfg<TI, TO, 0, false>(a, stream);
 }
 
 // Preconditions (checked by gemm_launch): N % 256 == 0, K % 64 == 0, (long long)N_tile_rows * K * 2 < 2^31.

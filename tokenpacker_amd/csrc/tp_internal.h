@@ -29,8 +29,17 @@ template <> struct Vec<f16_t> { using x8 = f16x8; using x4 = f16x4; };
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);      // hipGetLastError -> TP_ERR_LAUNCH
 
-// ---- tuning table (tp_set_tuning) -------------------------------------------------------------
+// ---- tuning: the context of the call in progress on this thread, else the process-wide table (tp_api.hip) ----------------
 int tuning(int key);
+// Opened by every entry point that takes a tp_desc: tuning() reads desc->tuning (NULL: the process-wide table) until it closes.
+struct TuningScope {
+    explicit TuningScope(const tp_desc* d);
+    ~TuningScope();
+    TuningScope(const TuningScope&) = delete;
+    TuningScope& operator=(const TuningScope&) = delete;
+private:
+    const void* prev_;
+};
 
 // ---- GEMM (tp_gemm.hip) -----------------------------------------------------------------------
 // C[g][M,N] = epilogue(A[g][M,K] * W[g][N,K]^T) for g in [0, groups)
@@ -106,10 +115,6 @@ struct GemmArgs {
     // (a device int32 the caller zeroed at some point), a wave that clamped anything ORs sat_bit into it.  One v_max3 per
     // two output elements and, for a tile that did saturate, one atomic — nothing otherwise.
     int* sat_flag; int sat_bit;
-    // Stream-K (tp_gemm8.hip SK): the launch's K-tiles are shared evenly by the persistent workgroups; a tile cut in two hands
-    // its tail partial over through sk_slabs [workgroups][256 x 256] fp32 and sk_flags [workgroups] (zeroed ints).
-    // stream_k: 0 = gemm_launch decides (cost model, TP_TUNE_STREAM_K), 1 = never for this launch.
-    float* sk_slabs; int* sk_flags; int stream_k;
 };
 int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream);
 bool gemm_uses_small_kernel(const GemmArgs& a);        // whether gemm_launch would run `a` on the 128-tile kernel (tp_gemm.hip)
@@ -151,11 +156,8 @@ long long gemm_pair_launch_count();
 int gemm_pair_occupancy();
 int gemm_pair_workgroups();                            // workgroups of a pair launch (two per CU)
 int gemm8_persistent_cus();                            // workgroups of a persistent launch (CUs rounded down to 8)
-constexpr int kStreamKMaxWorkgroups = 256;             // slabs / flags of the stream-K hand-over are sized for this many workgroups
-constexpr size_t kStreamKSlabBytes = (size_t)kStreamKMaxWorkgroups * 256 * 256 * 4;     // 64 MiB
-bool gemm8_stream_k_eligible(const GemmArgs& a, double* units_per_wg);
-constexpr int kMaxLaunches = 16;                       // GEMM launches of one forward that get queue heads / stream-K flags
-constexpr size_t kCounterBytes = (size_t)kMaxLaunches * (64 + kStreamKMaxWorkgroups) * 4;
+constexpr int kMaxLaunches = 16;                       // GEMM launches of one forward that get tile-queue heads
+constexpr size_t kCounterBytes = (size_t)kMaxLaunches * 64 * 4;
 inline int gemm_stats_parts(int N) { return N / 128; }   // one (sum, sumsq) slab per 128 output columns
 
 // ---- small kernels (tp_kernels.hip) -----------------------------------------------------------
@@ -175,7 +177,8 @@ int region_attention_absorbed_launch(const void* qt, const void* h2k, const void
                                      // RAW form (q != NULL): h2k / h2v are the K / V halves of Hkv (row stride ld elements), qt was built
                                      // from Wc_k; q [B*M, 1024] fp16, d_k / c_k [1024] fp32 -> u normalised + mr_u [8][B*M][2]
                                      int ld = kEmbed, const void* q = nullptr, const float* d_k = nullptr, const float* c_k = nullptr,
-                                     float* mr_u = nullptr);
+                                     // u_split: u [B*M, 8, 2 E] = fp16(u) | fp16(u - fp16(u))
+                                     float* mr_u = nullptr, bool u_split = false);
 int pack_head_transpose_launch(const void* w_f16, void* dst_f16, hipStream_t stream);    // [8*128, 1024] -> [8][1024][128]
 // tp_pack_qr.hip: W2 (fp16 [E,E]) and b2 (fp32 [E] or NULL) centred into matrix m of `scratch` (fp64), wbar [E+1] = the column means
 // and mean(b2); Householder QR of the nmat matrices; R (fp16, upper triangular) and c~ (fp32) out; the centred chain weight
@@ -184,7 +187,10 @@ int pack_qr_center_launch(const void* w2_f16, const float* b2, void* scratch, in
 int pack_qr_factor_launch(void* scratch, int nmat, hipStream_t stream);
 int pack_qr_extract_launch(const void* scratch, int m, void* r_f16, float* ctil, hipStream_t stream, int* sat);
 int pack_center_product_launch(const float* P, const float* c, const float* wbar, void* out_f16, const float* d, float* d_out,
-                               hipStream_t stream, int* sat);
+                               hipStream_t stream, int* sat, const float* P2 = nullptr);
+// lo = fp16(W' − fp16(W')), c_exact = rowsum(W'), d_exact = W'·v (v may be NULL), W' = w·diag(gamma) exact in fp32 (tp_kernels.hip)
+int pack_ln_fold_residual_launch(int dtype, const void* w, const void* gamma, const float* v, void* lo_f16, float* c_exact,
+                                 float* d_exact, int n_out, int n_in, hipStream_t stream);
 bool absorb_kv(const tp_desc* desc, bool train);          // whether tp_forward runs the absorbed schedule for desc
 bool fold_out_proj(const tp_desc* desc, bool train);      // whether out_proj is folded into mlp[0] for desc
 int hd_slice_launch(const float* img, int H, int W, int h_block, int w_block, int h_res, int w_res, int hg, int wg,
@@ -222,6 +228,7 @@ struct PackedLayout {
     size_t w_cc_kv, d_cc_kv;      // [2][1024,1024] f16, [2][1024] f32
     size_t w_cc_q;                // [1024,1024] f16
     size_t w_qt_cc;               // per-head transposes of Wc'_k (absorbed schedule)
+    size_t w_cc_v2;               // [8][128][2 E] f16: the rows of Wc'_v twice side by side — the per-head V GEMM over u = hi | lo
     size_t w_r_kv, c_r_kv;        // [2][1024,1024] f16 (zeros below the diagonal), [2][1024] f32
     size_t w_r_q;                 // [1024,1024] f16
     size_t wbar;                  // pack scratch: [3][1025] f32 column means of W2 (k, v, q) and the mean of b2 behind each
@@ -244,6 +251,7 @@ PackedLayout packed_layout(int D);
 struct SchedulePlan {
     bool train;
     bool absorb, absorb_raw;       // K/V in-projections absorbed into the query side (scale_factor >= 3); on the fused LayerNorm chain
+    bool u_split;                  // absorbed + centred chain: u travels as hi | lo fp16 halves [B M, 8, 2 E] — its rounding drops out
     bool fuse_ln;                  // plain schedule on the fused LayerNorm chain: H2 for its row statistics only
     bool fuse_q;                   // query side on the fused chain: Q1pre for its row statistics only
     bool region_major, fuse_attn;  // scale_factor 2: region-major K/V rows; attention inside the in-projections' epilogues
@@ -259,8 +267,7 @@ struct WorkspaceLayout {
     size_t status;                // 256 B at offset 0: int32[0] = sticky fp16-saturation bits (bit k: stage k - 1 of tp_forward_staged, bit 0: query side)
     size_t q0, hkv, h2, stats_kv, mr_kv, kv, q1pre, stats_q, mr_q, q, o, a1, a2;
     size_t attn_aux;              // logits [8][B*N] fp32 (attention in the in-projection epilogues) | (e/a, a) [8][B*M][2] (absorbed, RAW)
-    size_t counters;              // zeroed once per forward: tile-queue heads of the persistent GEMM launches + stream-K flags
-    size_t sk_slabs;              // stream-K partial accumulators, kStreamKSlabBytes
+    size_t counters;              // zeroed once per forward: tile-queue heads of the persistent GEMM launches
     size_t splitk;                // small batches: fp32 partial results of a K-split GEMM (TP_TUNE_SPLIT_K), kSplitKBytes
     size_t z1, z2;                // training forward only: fp16 pre-GELU activations [B*N, 2048], [B*M, D]
     size_t total;

@@ -233,7 +233,7 @@ region_attention_absorbed_kernel(const f16_t* __restrict__ qt, const f16_t* __re
                                  const float* __restrict__ mr_k, const float* __restrict__ mr_v, f16_t* __restrict__ u,
                                  int B, int g, int s, float scale, const float* __restrict__ mask, int mask_mode,
                                  int ld, const f16_t* __restrict__ q, const float* __restrict__ d_k,
-                                 const float* __restrict__ c_k, float* __restrict__ mr_u) {
+                                 const float* __restrict__ c_k, float* __restrict__ mr_u, const int u_ld) {
     constexpr int E = kEmbed, H = kHeads;
     __shared__ float logit_lds[4][kAbsorbMaxKeys * H];
     __shared__ float ab_lds[4][2 * H];
@@ -391,14 +391,20 @@ region_attention_absorbed_kernel(const f16_t* __restrict__ qt, const f16_t* __re
             for (int e = 0; e < 8; ++e) { ua[h][e] *= inv; ub[h][e] *= inv; }
             if (lane == h) *(float2*)(mr_u + ((long long)h * B * M + qi) * 2) = make_float2(e_h[h] * inv, a_h[h]);
         }
-        store8(u + (qi * H + h) * E + ea, ua[h]);
-        store8(u + (qi * H + h) * E + eb, ub[h]);
+        store8(u + (qi * H + h) * u_ld + ea, ua[h]);
+        store8(u + (qi * H + h) * u_ld + eb, ub[h]);
+        if (u_ld == 2 * E) {                               // hi | lo: the residual of the fp16 rounding rides behind it
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ua[h][e] -= (float)(f16_t)ua[h][e]; ub[h][e] -= (float)(f16_t)ub[h][e]; }
+            store8(u + (qi * H + h) * u_ld + E + ea, ua[h]);
+            store8(u + (qi * H + h) * u_ld + E + eb, ub[h]);
+        }
     }
 }
 
 int region_attention_absorbed_launch(const void* qt, const void* h2k, const void* h2v, const float* mr_k, const float* mr_v,
                                      void* u, int B, int grid, int s, hipStream_t stream, const float* mask, int mask_mode,
-                                     int ld, const void* q, const float* d_k, const float* c_k, float* mr_u) {
+                                     int ld, const void* q, const float* d_k, const float* c_k, float* mr_u, bool u_split) {
     if (s * s > kAbsorbMaxKeys) { set_error("absorbed region attention: s*s = %d keys > %d", s * s, kAbsorbMaxKeys); return TP_ERR_INVALID_ARG; }
     const int G = grid / s, M = G * G;
     const long long nq = (long long)B * M;
@@ -406,11 +412,11 @@ int region_attention_absorbed_launch(const void* qt, const void* h2k, const void
     if (q)          // RAW: rows of Hkv, the second K/V layer in the pre-multiplied weights
         hipLaunchKernelGGL(region_attention_absorbed_kernel<true>, dim3(blocks), dim3(256), 0, stream, (const f16_t*)qt,
                            (const f16_t*)h2k, (const f16_t*)h2v, mr_k, mr_v, (f16_t*)u, B, grid, s, 0.08838834764831845f, mask,
-                           mask_mode, ld, (const f16_t*)q, d_k, c_k, mr_u);
+                           mask_mode, ld, (const f16_t*)q, d_k, c_k, mr_u, u_split ? 2 * kEmbed : kEmbed);
     else
         hipLaunchKernelGGL(region_attention_absorbed_kernel<false>, dim3(blocks), dim3(256), 0, stream, (const f16_t*)qt,
                            (const f16_t*)h2k, (const f16_t*)h2v, mr_k, mr_v, (f16_t*)u, B, grid, s, 0.08838834764831845f, mask,
-                           mask_mode, kEmbed, nullptr, nullptr, nullptr, nullptr);
+                           mask_mode, kEmbed, nullptr, nullptr, nullptr, nullptr, kEmbed);
     return check_launch("region_attention_absorbed_kernel");
 }
 
@@ -821,6 +827,45 @@ pack_ln_fold_kernel(const T* __restrict__ w, const T* __restrict__ bias, const T
         colsum[n] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
         bias_out[n] = red[1][0] + red[1][1] + red[1][2] + red[1][3] + (float)bias[n];
     }
+}
+
+// The part of the folded weight its fp16 rounding drops.  W'_nk = W_nk·gamma_k is EXACT in fp32 (a product of two 16-bit floats);
+// pack_ln_fold stores hi = fp16(W'); this kernel writes lo = fp16(W' − hi) (the residual to ~2^-22), c_exact[n] = Σ_k W'_nk and,
+// with v, d_exact[n] = Σ_k W'_nk v_k — what the pre-multiplied chain weights of the centred LayerNorm chain are built from
+// (tp_pack_weights: Wcc = (hi + lo)·W2 − c_exact ⊗ w̄), so that the fold's own rounding no longer sits in series with theirs.
+template <typename T>
+__global__ void __launch_bounds__(256)
+pack_ln_fold_residual_kernel(const T* __restrict__ w, const T* __restrict__ gamma, const float* __restrict__ v,
+                             f16_t* __restrict__ lo, float* __restrict__ c_exact, float* __restrict__ d_exact, int n_in) {
+    const int n = blockIdx.x;
+    float cs = 0.f, ds = 0.f;
+    for (int kk = threadIdx.x; kk < n_in; kk += blockDim.x) {
+        const float we = (float)w[(long long)n * n_in + kk] * (float)gamma[kk];
+        const float hi = (float)(f16_t)fminf(fmaxf(we, -65504.f), 65504.f);
+        lo[(long long)n * n_in + kk] = (f16_t)(we - hi);
+        cs += we;
+        if (v) ds = fmaf(we, v[kk], ds);
+    }
+    __shared__ float red[2][4];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { cs += __shfl_xor(cs, off); ds += __shfl_xor(ds, off); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = cs; red[1][threadIdx.x >> 6] = ds; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c_exact[n] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        if (d_exact) d_exact[n] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
+int pack_ln_fold_residual_launch(int dtype, const void* w, const void* gamma, const float* v, void* lo_f16, float* c_exact,
+                                 float* d_exact, int n_out, int n_in, hipStream_t stream) {
+    if (dtype == TP_BF16)
+        hipLaunchKernelGGL(pack_ln_fold_residual_kernel<bf16_t>, dim3(n_out), dim3(256), 0, stream, (const bf16_t*)w,
+                           (const bf16_t*)gamma, v, (f16_t*)lo_f16, c_exact, d_exact, n_in);
+    else
+        hipLaunchKernelGGL(pack_ln_fold_residual_kernel<f16_t>, dim3(n_out), dim3(256), 0, stream, (const f16_t*)w,
+                           (const f16_t*)gamma, v, (f16_t*)lo_f16, c_exact, d_exact, n_in);
+    return check_launch("pack_ln_fold_residual_kernel");
 }
 
 int pack_ln_fold_launch(int dtype, const void* w, const void* bias, const void* gamma,

@@ -104,14 +104,17 @@ qr_extract_kernel(const double* __restrict__ A, f16_t* __restrict__ r16, float* 
     if (threadIdx.x == 0 && ctil) ctil[n] = (float)A[(long long)n * QP + QE];
 }
 
-// P[n][k] (fp32 product W'·W2) -> fp16( P[n][k] - c[n] wbar[k] ) = W'·W2c;  d_out[n] = d[n] - c[n] bbar   (d may be NULL: no bias)
+// P[n][k] (fp32 product W'·W2; P2: the product of the fold's residual, added when given) -> fp16( P[n][k] - c[n] wbar[k] ) = W'·W2c;
+// d_out[n] = d[n] - c[n] bbar   (d may be NULL: no bias)
 __global__ void __launch_bounds__(256)
-center_product_kernel(const float* __restrict__ P, const float* __restrict__ c, const float* __restrict__ wbar,
+center_product_kernel(const float* __restrict__ P, const float* __restrict__ P2, const float* __restrict__ c, const float* __restrict__ wbar,
                       f16_t* __restrict__ out, const float* __restrict__ d, float* __restrict__ d_out, int* __restrict__ sat) {
     const int n = blockIdx.x;
     const float cn = c[n];
     for (int k = threadIdx.x; k < QE; k += blockDim.x) {
-        float v = fmaf(-cn, wbar[k], P[(long long)n * QE + k]);
+        float pv = P[(long long)n * QE + k];
+        if (P2) pv += P2[(long long)n * QE + k];
+        float v = fmaf(-cn, wbar[k], pv);
         if (!(fabsf(v) <= 65504.f)) { if (sat) atomicAdd(sat, 1); v = fminf(fmaxf(v, -65504.f), 65504.f); }
         out[(long long)n * QE + k] = (f16_t)v;
     }
@@ -147,8 +150,8 @@ int pack_qr_extract_launch(const void* scratch, int m, void* r_f16, float* ctil,
 }
 
 int pack_center_product_launch(const float* P, const float* c, const float* wbar, void* out_f16, const float* d, float* d_out,
-                               hipStream_t stream, int* sat) {
-    hipLaunchKernelGGL(center_product_kernel, dim3(QE), dim3(256), 0, stream, P, c, wbar, (f16_t*)out_f16, d, d_out, sat);
+                               hipStream_t stream, int* sat, const float* P2) {
+    hipLaunchKernelGGL(center_product_kernel, dim3(QE), dim3(256), 0, stream, P, P2, c, wbar, (f16_t*)out_f16, d, d_out, sat);
     return check_launch("center_product_kernel");
 }
 

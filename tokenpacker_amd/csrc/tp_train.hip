@@ -195,11 +195,13 @@ int tp_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, int x_rows
 }
 
 size_t tp_train_workspace_bytes(const tp_desc* desc) {
+    tp::TuningScope tuning_scope(desc);
     if (validate_desc(desc) != TP_OK) return 0;
     return workspace_layout(desc->batch, desc->raw_grid, desc->scale_factor, desc->hidden_size, true).total;
 }
 
 size_t tp_backward_workspace_bytes(const tp_desc* desc) {
+    tp::TuningScope tuning_scope(desc);
     if (validate_desc(desc) != TP_OK) return 0;
     return bw_layout(desc->batch, desc->raw_grid, desc->scale_factor, desc->hidden_size).total;
 }
@@ -222,6 +224,7 @@ int tp_forward_train_parts(const tp_desc* desc, const void* x, const int64_t x_s
 static int backward_impl(const tp_desc* desc, const void* x_multi, const void* const* xm_parts, const int64_t xm_strides[3],
                          const tp_weights* raw, const void* packed_weights, const void* train_workspace, const void* dy,
                          const tp_grads* grads, void* bw_workspace, size_t bw_workspace_bytes, void* stream_) {
+    tp::TuningScope tuning_scope(desc);
     TP_TRY(validate_desc(desc));
     if (xm_parts) {
         for (int i = 0; i < 4; ++i) if (!xm_parts[i]) { set_error("tp_backward: x_multi part %d is NULL", i); return TP_ERR_INVALID_ARG; }

@@ -100,6 +100,10 @@ class TokenPacker(nn.Module):
         #: dtype to compute in (torch.float16 / torch.bfloat16): operands are rounded to it, the result comes back
         #: as fp32 from the last GEMM's accumulators (within 1e-3 of the fp32 reference, not bit-comparable to it).
         self.fp32_compute_dtype: Optional[torch.dtype] = None
+        #: a ``_capi.TuningContext`` this module's calls read their knobs from (``tp_desc.tuning``): a serving worker that runs
+        #: several model instances / threads gives each its own, and nobody's ``set_tuning`` can change another's schedule or
+        #: low bits.  None (default): the library's process-wide table.  Not copied by deepcopy / pickle.
+        self.tuning = None
         self._packed: Optional[torch.Tensor] = None
         self._packed_key = None
         self._packed_event = None
@@ -110,7 +114,7 @@ class TokenPacker(nn.Module):
         self._sat_warned, self._sat_pending, self._sat_count = False, None, 0
 
     # ------------------------------------------------------------------------------------------
-    _CACHE_DEFAULTS = {"_packed": None, "_packed_key": None, "_packed_event": None, "_packed_stream": None,
+    _CACHE_DEFAULTS = {"tuning": None, "_packed": None, "_packed_key": None, "_packed_event": None, "_packed_stream": None,
                        "_overflow_checked": False, "_last_launch": None, "_sat_warned": False, "_sat_pending": None,
                        "_sat_count": 0}
 
@@ -181,7 +185,7 @@ class TokenPacker(nn.Module):
                                 f"the reference does, or run under torch.autocast")
         lib = _capi.load_library()
         desc = _capi.make_desc(1, self.raw_grid, self.scale_factor, self.hidden_size, _DTYPES[dtype],
-                               ln_eps=self._ln_eps(), flags=_capi.TP_DESC_TRAIN_PACK if force else 0)
+                               ln_eps=self._ln_eps(), flags=_capi.TP_DESC_TRAIN_PACK if force else 0, tuning=self.tuning)
         nbytes = lib.tp_packed_weight_bytes(ctypes.byref(desc))
         if nbytes == 0:
             raise RuntimeError(f"tp_packed_weight_bytes: {_capi.last_error()}")
@@ -353,7 +357,7 @@ class TokenPacker(nn.Module):
             fp32_out = fp32_out or self.output_fp32
             out_dtype = torch.float32 if fp32_out else x.dtype
             desc = _capi.make_desc(B, self.raw_grid, self.scale_factor, self.hidden_size, _DTYPES[x.dtype],
-                                   _capi.TP_F32 if fp32_out else _DTYPES[x.dtype], self._ln_eps())
+                                   _capi.TP_F32 if fp32_out else _DTYPES[x.dtype], self._ln_eps(), tuning=self.tuning)
             if out is None:
                 out = torch.empty(B, self.num_queries, self.hidden_size, dtype=out_dtype, device=device)
             elif tuple(out.shape) != (B, self.num_queries, self.hidden_size) or out.dtype != out_dtype \

@@ -27,14 +27,16 @@ def main():
         C = torch.empty(M, N, device="cuda", dtype=torch.float16)
         stats = torch.empty(8 * M * 2, device="cuda")
         for fname, flags in (("plain", 0), ("stats", S), ("lnfold", F), ("gelu", G)):
-            for vname, kern in (("persistent", 0), ("onetile", 2)):
+            for vname, tile_knob in (("full_tiles", 0), ("half_tiles", 2)):
                 a = _capi.tp_linear_args()
                 a.M, a.N, a.K, a.flags = M, N, K, flags
                 a.dtype, a.out_dtype = _capi.TP_F16, _capi.TP_F16
-                a.lda, a.ldc, a.tile = K, N, 256
+                a.lda, a.ldc, a.tile = K, N, (256 if tile_knob == 0 else 0)
                 a.A, a.W, a.C, a.bias = A.data_ptr(), W.data_ptr(), C.data_ptr(), bias.data_ptr()
                 a.row_stats_out, a.row_mean_rstd, a.colsum = stats.data_ptr(), mr.data_ptr(), colsum.data_ptr()
-                _capi.set_tuning(_capi.TP_TUNE_GEMM_KERNEL, kern)
+                _capi.set_tuning(_capi.TP_TUNE_GEMM_TILE, tile_knob)
+                if tile_knob == 2 and K < 128:
+                    continue
                 ts = []
                 for r in range(6):
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -48,7 +50,7 @@ def main():
                 tiles = (M // 256) * (N // 256)
                 print(f"K={K:4d} {fname:7s} {vname:10s} {ms * 1e3:8.1f} us  = {ms * 1e3 / (tiles / 256):6.2f} us per tile-round "
                       f"(write {M * N * 2 / ms / 1e6:7.1f} GB/s)", flush=True)
-    _capi.set_tuning(_capi.TP_TUNE_GEMM_KERNEL, 0)
+    _capi.set_tuning(_capi.TP_TUNE_GEMM_TILE, 0)
 
 
 if __name__ == "__main__":

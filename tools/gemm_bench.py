@@ -19,8 +19,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tokenpacker_amd import _capi  # noqa: E402
 
 G, S, F = _capi.TP_LINEAR_GELU, _capi.TP_LINEAR_ROW_STATS, _capi.TP_LINEAR_LN_FOLD
-# (name, forced tile, TP_TUNE_GEMM_KERNEL, TP_TUNE_PAIR_GEMM, TP_TUNE_PAIR_STAGGER)
-VARIANTS = [("tile128", 128, 0, 1, 100), ("pp_persistent", 256, 0, 1, 100), ("pair", 0, 0, 2, 100), ("pair_nostagger", 0, 0, 2, 0)]
+# (name, forced tile, TP_TUNE_PAIR_GEMM, TP_TUNE_PAIR_STAGGER)
+VARIANTS = [("tile128", 128, 1, 100), ("pp_persistent", 256, 1, 100), ("pair", 0, 2, 100), ("pair_nostagger", 0, 2, 0)]
 
 
 def shapes(B, s, D):
@@ -57,7 +57,7 @@ def main():
         stats = torch.empty(8 * M * 2, device="cuda")
         fl = 2.0 * M * N * K
 
-        def make(tile, kern, pair, stagger):
+        def make(tile, pair, stagger):
             a = _capi.tp_linear_args()
             a.M, a.N, a.K, a.flags = M, N, K, flags
             a.dtype = _capi.TP_BF16 if dt == torch.bfloat16 else _capi.TP_F16
@@ -67,14 +67,13 @@ def main():
             a.row_stats_out, a.row_mean_rstd, a.colsum = stats.data_ptr(), mr.data_ptr(), colsum.data_ptr()
 
             def run():
-                _capi.set_tuning(_capi.TP_TUNE_GEMM_KERNEL, kern)
                 _capi.set_tuning(_capi.TP_TUNE_PAIR_GEMM, pair)
                 _capi.set_tuning(_capi.TP_TUNE_PAIR_STAGGER, stagger)
                 rc = lib.tp_linear(ctypes.byref(a), st)
                 assert rc == 0, _capi.last_error()
             return run
 
-        runs = [(v, make(t, k, pr, sg)) for v, t, k, pr, sg in VARIANTS if t == 0 or N % t == 0]
+        runs = [(v, make(t, pr, sg)) for v, t, pr, sg in VARIANTS if t == 0 or N % t == 0]
         runs.append(("torch.matmul", lambda: torch.matmul(A, W.t())))
         times = {v: [] for v, _ in runs}
         for v, fn in runs:                       # warm-up
@@ -95,7 +94,6 @@ def main():
                        tflops=round(fl / ms / 1e9, 1))
             results.append(rec)
             print(rec, flush=True)
-        _capi.set_tuning(_capi.TP_TUNE_GEMM_KERNEL, 0)
         _capi.set_tuning(_capi.TP_TUNE_PAIR_GEMM, 0)
         _capi.set_tuning(_capi.TP_TUNE_PAIR_STAGGER, 100)
         del A, W, C, mr, stats

@@ -115,21 +115,6 @@ if has pmc; then
   python tools/make_traffic.py $OUT/pmc_summary.json $TAG && cp profiles/traffic.json $OUT/traffic.json
   find $OUT -name "*kernel_trace.csv" -size +20M -delete
 fi
-if has skpmc; then
-  echo "== stream-K under PMC: FETCH_SIZE of the first K/V layer at B = 100, off vs on =="
-  for SK in 0 2; do
-    mkdir -p $OUT/sk$SK
-    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$OUT/sk$SK/pmc_FETCH_SIZE -o pmc -- python $R/bench.py --batch 100 --steps 3 --warmup 2 --no-cpu-baseline --no-extras --min-seconds 0 --tune STREAM_K=$SK > $R/$OUT/sk$SK/pmc.log 2>&1 ); echo "skpmc STREAM_K=$SK exit $?"
-    python tools/pmc_summary.py $OUT/sk$SK > $OUT/pmc_summary_streamk$SK.json 2>> $OUT/pmc_summary.err
-    python - "$OUT/pmc_summary_streamk$SK.json" <<'PY'
-import json,sys
-d=json.load(open(sys.argv[1]))
-for k,v in d.items():
-    if "gemm8_kernel" in k and ("Li1ELb1ELb0ELb0ELi0E" in k): print(k[-60:], {x: v.get(x) for x in ("dispatches","duration_ns","hbm_read_bytes_corrected")})
-PY
-  done
-  find $OUT -name "*kernel_trace.csv" -size +20M -delete
-fi
 if has gemmpmc; then
   echo "== GEMM variants under PMC (two passes) =="
   i=0

@@ -17,8 +17,9 @@ G, S, F = _capi.TP_LINEAR_GELU, _capi.TP_LINEAR_ROW_STATS, _capi.TP_LINEAR_LN_FO
 def main():
     args = dict(a.split("=", 1) for a in sys.argv[1:])           # lib=<path to a probe build> for A/B runs on one box
     lib = _capi.load_library(args["lib"]) if "lib" in args else _capi.load_library()
-    if "kernel" in args:                                             # TP_TUNE_GEMM_KERNEL (3: half tiles)
-        _capi.set_tuning(_capi.TP_TUNE_GEMM_KERNEL, int(args["kernel"]))
+    half = args.get("tiles") == "half"                                # tiles=half: TP_TUNE_GEMM_TILE = 2 (128 x 256 half tiles)
+    if half:
+        _capi.set_tuning(_capi.TP_TUNE_GEMM_TILE, 2)
     print("args", args)
     st = torch.cuda.current_stream().cuda_stream
     M, N = 147456, 1024
@@ -36,7 +37,7 @@ def main():
             a = _capi.tp_linear_args()
             a.M, a.N, a.K, a.flags = M, N, K, flags
             a.dtype, a.out_dtype = _capi.TP_F16, _capi.TP_F16
-            a.lda, a.ldc, a.tile = K, N, 256
+            a.lda, a.ldc, a.tile = K, N, (0 if half else 256)
             a.A, a.W, a.C, a.bias = A.data_ptr(), W.data_ptr(), C.data_ptr(), bias.data_ptr()
             a.row_stats_out, a.row_mean_rstd, a.colsum = stats.data_ptr(), mr.data_ptr(), colsum.data_ptr()
             ts = []
