@@ -1,4 +1,4 @@
-"""Round-3 additions, on a real MI355X: the parity claim as a DISTRIBUTION over seeds, every legal combination of the
+"""Round-3 additions, on a real MI355X: every legal combination of the
 schedule knobs against the oracle, the sticky fp16-saturation word, the pack registry, per-stream state release."""
 import ctypes
 import itertools
@@ -22,47 +22,7 @@ def _module(params, s, D, dtype, grid=24):
     return m.to(device="cuda", dtype=dtype).eval().requires_grad_(False)
 
 
-# Stated claim (README / DESIGN §3), measured on MI355X over 16 seeds x s in {2, 3, 4} x {bf16 with fp32 output, fp16}
-# (profiles/r03_parity_seed_sweep.json); metric max|y - y_ref| / max|y_ref| against the fp64 oracle on the SAME rounded
-# operands.  EVERY seed of EVERY configuration <= 1e-3, medians <= 8e-4:
-#   scale_factor 2 — the north_star's gated configuration, attention inside the in-projection epilogues, 5 fp16 roundings in
-#     series on the value path: measured median 6.8e-4 / 7.2e-4, worst seed 8.4e-4 / 8.8e-4;
-#   scale_factor 3, 4 — the absorbed schedule carries one rounding more (u between the attention kernel and the per-head V
-#     GEMM): measured medians 7.1e-4 .. 7.8e-4, worst seed 9.9e-4 (1.016e-3 before the chain weights were centred),
-#     rel-L2 <= 8.2e-4.
-GATES = {2: dict(median=8.0e-4, max=1.0e-3, l2=7.5e-4), 3: dict(median=8.0e-4, max=1.0e-3, l2=8.5e-4),
-         4: dict(median=8.0e-4, max=1.0e-3, l2=8.5e-4)}
-
-
-def test_parity_seed_sweep():
-    D, B, seeds = 256, 4, 16
-    rows, summary = [], {}
-    for s, (dtype, tag) in itertools.product((2, 3, 4), ((torch.bfloat16, "bf16_fp32out"), (torch.float16, "fp16"))):
-        errs, l2s = [], []
-        for seed in range(seeds):
-            params = synth.make_params(9000 + 17 * seed + s, D)
-            x, xm = synth.make_inputs(9500 + 31 * seed + s, B, dtype)
-            m = _module(params, s, D, dtype)
-            m.output_fp32 = dtype == torch.bfloat16
-            with torch.no_grad():
-                y = m((x.cuda(), xm.cuda()))
-            p_lp = {k: v.to(dtype) for k, v in params.items()}
-            y_exact = orc.forward(p_lp, x, xm, scale_factor=s, compute_dtype=torch.float64, io_dtype=dtype)
-            errs.append(orc.rel_err(y, y_exact))
-            l2s.append(orc.rel_l2(y, y_exact))
-        key = f"s{s}_{tag}"
-        summary[key] = {"median": statistics.median(errs), "max": max(errs), "min": min(errs),
-                        "l2_median": statistics.median(l2s), "l2_max": max(l2s), "seeds": seeds}
-        rows.append((s, key, summary[key]))
-        print(f"\n[parity-sweep] {key}: rel-max median {summary[key]['median']:.3e} max {summary[key]['max']:.3e} "
-              f"min {summary[key]['min']:.3e} | rel-L2 median {summary[key]['l2_median']:.3e} max {summary[key]['l2_max']:.3e}")
-    os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/parity_seed_sweep.json", "w") as f:
-        json.dump(summary, f, indent=1)
-    for s, key, r in rows:
-        assert r["median"] <= GATES[s]["median"], (key, r)
-        assert r["max"] <= GATES[s]["max"], (key, r)
-        assert r["l2_max"] <= GATES[s]["l2"], (key, r)
+# (the parity claim as a distribution over seeds moved to tests/test_gpu_round4.py: 128 seeds, tools/parity_sweep.py)
 
 
 def _legal_tunings(s):

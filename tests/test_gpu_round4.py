@@ -1,0 +1,117 @@
+"""Round-4 additions, on a real MI355X: the parity claim as a distribution over many seeds (gated on the WORST seed), tuning
+contexts (tp_desc.tuning: a forward's knobs are its own, whatever other threads do to the process-wide table)."""
+import json
+import os
+import sys
+import threading
+
+import pytest
+import torch
+
+from tokenpacker_amd import _capi, synth
+from tests.test_gpu_forward import _module
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# Stated claim (README / DESIGN §3), metric max|y - y_ref| / max|y_ref| against the fp64 oracle on the SAME rounded operands
+# (SURVEY.md §8c): EVERY seed of EVERY configuration <= 1e-3.  profiles/r04_parity_seed_sweep.json holds the 128-seed run of
+# tools/parity_sweep.py; this test runs TP_PARITY_SEEDS of them (default 48: ~3 minutes of oracle time) with the same gates.
+# Round 4 removed two of the fp16 roundings that sat in series on the value path: the LayerNorm fold inside the pre-multiplied
+# chain weights (built from the unrounded fold, hi + lo) and, on the absorbed schedule (s >= 3), `u` (carried as hi | lo).
+GATE_WORST, GATE_MEDIAN = 1.0e-3, 7.6e-4
+
+
+def test_parity_seed_sweep_gated_on_the_worst_seed():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import parity_sweep
+    seeds = int(os.environ.get("TP_PARITY_SEEDS", "48"))
+    summary = parity_sweep.sweep(seeds, log=lambda m: print("\n" + m))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_seed_sweep_test.json", "w") as f:
+        json.dump(summary, f, indent=1)
+    for key, r in summary.items():
+        assert r["max"] <= GATE_WORST, (key, r["max"], r["rel_max_per_seed"].index(max(r["rel_max_per_seed"])))
+        assert r["median"] <= GATE_MEDIAN, (key, r["median"])
+
+
+def _inputs(B, dtype, seed=77):
+    x, xm = synth.make_inputs(seed, B, dtype)
+    return x.cuda(), xm.cuda()
+
+
+def test_a_module_with_its_own_tuning_context_ignores_the_process_wide_table():
+    """The module's context selects the schedule (here: the separate attention kernel instead of attention in the in-projection
+    epilogues — different low bits); flipping the process-wide table afterwards, or meanwhile, changes nothing for it; a module
+    without a context follows the table as before."""
+    dtype, D, s, B = torch.float16, 256, 2, 9
+    params = synth.make_params(411, D)
+    x, xm = _inputs(B, dtype)
+    plain = _module(params, s, D, dtype)
+    own = _module(params, s, D, dtype)
+    own.tuning = _capi.TuningContext(fuse_attn=1)
+    with torch.no_grad():
+        y_default = plain((x, xm))
+        _capi.set_tuning(_capi.TP_TUNE_FUSE_ATTN, 1)
+        try:
+            y_table1 = plain((x, xm))
+        finally:
+            _capi.set_tuning(_capi.TP_TUNE_FUSE_ATTN, 0)
+        y_own = own((x, xm))
+        assert not torch.equal(y_default, y_table1)            # the knob really changes the result's low bits
+        assert torch.equal(y_own, y_table1)                    # the context selected that schedule ...
+        _capi.set_tuning(_capi.TP_TUNE_FUSE_ATTN, 2)
+        _capi.set_tuning(_capi.TP_TUNE_TRI_STATS, 1)
+        try:
+            assert torch.equal(own((x, xm)), y_own)            # ... and the table cannot reach it
+            assert not torch.equal(plain((x, xm)), y_default)
+        finally:
+            _capi.set_tuning(_capi.TP_TUNE_FUSE_ATTN, 0)
+            _capi.set_tuning(_capi.TP_TUNE_TRI_STATS, 0)
+        assert torch.equal(plain((x, xm)), y_default)
+        own.tuning.set(_capi.TP_TUNE_FUSE_ATTN, 0)             # the context is live: the next forward follows it
+        assert torch.equal(own((x, xm)), y_default)
+
+
+def test_concurrent_forwards_with_different_contexts_do_not_see_each_other():
+    """Two host threads, one module each, different contexts, own streams (the serving situation: model_worker.py runs `generate` on
+    a thread per request) while the main thread keeps flipping the process-wide table: every result equals the thread's serial
+    reference bit for bit."""
+    dtype, D, s, B = torch.float16, 256, 2, 5
+    params = synth.make_params(412, D)
+    x, xm = _inputs(B, dtype, 78)
+    mods = [_module(params, s, D, dtype) for _ in range(2)]
+    mods[0].tuning = _capi.TuningContext(fuse_attn=0)
+    mods[1].tuning = _capi.TuningContext(fuse_attn=1, tri_stats=1)
+    with torch.no_grad():
+        refs = [m((x, xm)).clone() for m in mods]
+    assert not torch.equal(refs[0], refs[1])
+    errors, stop = [], threading.Event()
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.no_grad(), torch.cuda.stream(st):
+                for _ in range(40):
+                    y = mods[i]((x, xm))
+                    st.synchronize()
+                    if not torch.equal(y, refs[i]):
+                        errors.append(f"thread {i}: result changed")
+                        return
+        except Exception as exc:     # noqa
+            errors.append(f"thread {i}: {exc!r}")
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    flips = 0
+    while any(t.is_alive() for t in threads):
+        _capi.set_tuning(_capi.TP_TUNE_FUSE_ATTN, flips % 3)
+        _capi.set_tuning(_capi.TP_TUNE_TRI_STATS, flips % 2)
+        flips += 1
+    for t in threads:
+        t.join()
+    for k, v in _capi._TUNING_DEFAULTS.items():
+        _capi.set_tuning(k, v)
+    assert not errors, errors
+    assert flips > 10
