@@ -25,7 +25,8 @@ Other workloads (each prints the same one-line JSON):
   --hd    BASELINE configs[3], TokenPacker-HD: 32 images x 9 crops = 288 crops sharded over the ranks (ragged when
           288 % N != 0), ONE all-gather of b_max-row slots, then the HD token assembly (tp_hd_assemble) reading the
           gathered buffer in place.
-  --e2e   BASELINE configs[4], encode_images() end to end: random-init CLIP-ViT-L/14-336 forward (HF transformers on
+  --e2e   BASELINE configs[4], encode_images() end to end (N > 1: `python bench.py --e2e --gpus N` starts its own ranks like the
+          projector bench; the line also carries `reference_leg` / `vs_reference`: the same run with the reference's projector): random-init CLIP-ViT-L/14-336 forward (HF transformers on
           PyTorch-ROCm — the producer, not our code) -> HIP projector on the four hidden-state slices (no torch.cat)
           -> Vicuna-7B-shaped prefill (32 Llama layers of GEMMs + SDPA on PyTorch-ROCm — the consumer, not our code),
           B=64 split over the ranks DDP-style; tokens/s plus the split into tower / projector / prefill time.
@@ -51,6 +52,7 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
   stages_ms    — per-kernel breakdown of one forward.
   clocks       — the device's current sclk / mclk / fclk levels (sysfs pp_dpm_*) and average socket power right before and right after
                  the timed region, so that a slow run can be tied to an actual clock / power state.
+  pack_ms      — N=1: the one-time weight packing the timed region excludes, inference image and training image.
   memory_side  — mlp0_gelu / kv_layer2_stats: a launch that stores 128 KiB per 23-us tile over one that stores nothing; tells a
                  run in the node's slow memory-side power state (mid-sized batches, profiles/r03u_mid_batch_anomaly.txt) from a
                  normal one.
@@ -265,6 +267,28 @@ def gpu_extras(args, model, x, xm, dtype, device, images_per_s):
             sweep[f"s{s2}_B{B}"] = {"ms_per_step": round(ms, 4), "images_per_s": round(B / ms * 1e3, 1)}
             del m2
         out["sweep"] = sweep
+        # Weight packing is excluded from the timed region (one-time per weight set) but REPORTED: the inference
+        # image (every folded / pre-multiplied weight + the pack-time QR of the triangular statistics) is rebuilt after every
+        # parameter update that an eval forward follows; the training image (TP_DESC_TRAIN_PACK) is rebuilt every training step.
+        def pack_ms(train):
+            stream_ptr = torch.cuda.current_stream(device).cuda_stream
+            ts = []
+            for _ in range(4):
+                model._packed_key = None                     # forces a re-pack (what a parameter update does)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                model._ensure_packed(dtype, device, stream_ptr, force=train)
+                e1.record()
+                torch.cuda.synchronize(device)
+                ts.append(e0.elapsed_time(e1))
+            return round(sorted(ts[1:])[1], 3)
+        try:
+            out["pack_ms"] = {"inference": pack_ms(False), "train_pack": pack_ms(True),
+                              "note": "one-time per weight set, outside the timed region (median of 3 re-packs, HIP events)"}
+            model._packed_key = None                         # (leave an inference image behind for what follows)
+            model((x[:1], xm[:1]))
+        except Exception as exc:         # noqa
+            out["pack_ms"] = {"error": repr(exc)[:200]}
         try:
             ms = _time_forward(lambda: eager_forward(model, x, xm), device, 10, 30)
             out["eager_rocm_baseline"] = {"ms_per_step": round(ms, 3), "value": round(B / ms * 1e3, 1), "unit": "images/s",
@@ -361,6 +385,8 @@ def run_e2e(args, world, rank, device, dtype, dist):
         return h
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    use_reference = {"on": False}          # the reference leg (after the timed region): the reference's own projector + feature_select
+    eager_forward = _reference_op_sequence() if not args.no_extras else None
 
     def step(timed=False):
         if timed:
@@ -368,8 +394,14 @@ def run_e2e(args, world, rank, device, dtype, dist):
         hs = clip(images, output_hidden_states=True).hidden_states          # the tower (clip_encoder.py:46-62)
         if timed:
             ev[1].record()
-        x, parts = tower.select_features(hs)                                 # [:, 1:] views, no torch.cat
-        tok = model((x, parts))                                              # the hot path (llava_arch.py:97)
+        if use_reference["on"]:
+            # what the reference does here: feature_select concatenates hidden states 12, 16, 22, 23 (clip_encoder.py:28-44),
+            # then its projector's torch op sequence (builder.py:107-137) under PyTorch-ROCm eager
+            x_ref, xm_ref = tower.concat_reference(hs)
+            tok = eager_forward(model, x_ref, xm_ref)
+        else:
+            x, parts = tower.select_features(hs)                             # [:, 1:] views, no torch.cat
+            tok = model((x, parts))                                          # the hot path (llava_arch.py:97)
         if timed:
             ev[2].record()
         out = prefill(torch.cat([tok, text], dim=1))                         # visual tokens ahead of the text
@@ -407,11 +439,28 @@ def run_e2e(args, world, rank, device, dtype, dist):
         y, elapsed = timed_region()               # (no collective on this path: every rank prefills its own samples)
         step(timed=True)
         torch.cuda.synchronize(device)
+        split = [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
+        # The reference leg — BASELINE configs[4] asks for tokens/s "vs reference": the SAME tower, prefill, inputs and protocol with
+        # the reference's projector (its torch op sequence on PyTorch-ROCm eager, fed by its torch.cat feature_select) in place of
+        # the HIP one.  After the timed region, never inside it; skipped with --no-extras.
+        ref_elapsed, ref_split, ref_err = 0.0, None, None
+        if eager_forward is not None:
+            try:
+                use_reference["on"] = True
+                y_ref, ref_elapsed = timed_region()
+                step(timed=True)
+                torch.cuda.synchronize(device)
+                ref_split = [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
+                del y_ref
+            except Exception as exc:     # noqa: an OOM of the eager leg must not cost the line
+                ref_err, ref_elapsed = repr(exc)[:200], 0.0
+            finally:
+                use_reference["on"] = False
     assert y.shape == (b, T, D) and torch.isfinite(y[:1].float()).all()
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed, ref_elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t[0].item())
+    elapsed, ref_elapsed = float(t[0].item()), float(t[1].item())
     if rank != 0:
         return
     tokens = args.e2e_batch * T
@@ -424,10 +473,22 @@ def run_e2e(args, world, rank, device, dtype, dist):
                                   f"tokens per sample",
                       "global_batch": args.e2e_batch, "per_gpu_batch": b, "parallelism": f"DDP-style batch shard x{world}, no collective",
                       "tokens_per_step": tokens},
-           "split_ms": {"tower": round(ev[0].elapsed_time(ev[1]), 3), "projector_hip": round(ev[1].elapsed_time(ev[2]), 3),
-                        "prefill": round(ev[2].elapsed_time(ev[3]), 3)},
+           "split_ms": {"tower": round(split[0], 3), "projector_hip": round(split[1], 3), "prefill": round(split[2], 3)},
+           "clocks": clocks,
            "note": "tower and prefill are PyTorch-ROCm library code around the path (producer / consumer), timed to place the "
                    "projector inside encode_images(); only projector_hip is this repository's kernels"}
+    if ref_elapsed > 0:
+        ref_value = tokens * args.steps / ref_elapsed
+        out["reference_leg"] = {"value": round(ref_value, 1), "unit": "tokens/s", "ms_per_step": round(1e3 * ref_elapsed / args.steps, 3),
+                                "split_ms": {"tower": round(ref_split[0], 3), "feature_select_cat_plus_projector_eager": round(ref_split[1], 3),
+                                             "prefill": round(ref_split[2], 3)},
+                                "what": "same tower, prefill, inputs, W + K protocol; the projector is the reference's torch op sequence "
+                                        f"(builder.py:107-137) under PyTorch-ROCm {torch.__version__} eager behind its torch.cat "
+                                        "feature_select (clip_encoder.py:28-44); measured AFTER the timed region"}
+        out["vs_reference"] = round(out["value"] / ref_value, 4)
+        out["projector_speedup_in_place"] = round(ref_split[1] / split[1], 2) if split[1] > 0 else None
+    elif ref_err:
+        out["reference_leg"] = {"error": ref_err}
     print(json.dumps(out), flush=True)
 
 

@@ -46,7 +46,7 @@ def test_sizes_and_descriptor_validation():
     #   centred layer-2 weights (6 MiB) and the fp64 scratch of their pack-time Householder QR (3 x [1024][1025] + vectors)
     fold = 4096 * 1024 * 2 + 1024 * 1024 * 2 + 4096 * 1024 * 4 + 1024 * 1024 * 2 + 3 * 1024 * 1024 * 2 + 1024 * 1024 * 2   # (+ w_qt_c)
     # + the rows of the centred V chain weight twice side by side ([8][128][2048] fp16, 4 MiB: the absorbed schedule's u = hi | lo)
-    fold += 7 * 1024 * 1024 * 2 + 3 * (1024 * 1025 * 8 + 1024 * 8) + 2 * 1024 * 1024 * 2
+    fold += 7 * 1024 * 1024 * 2 + 3 * (1024 * 1025 * 8 + 16 * 1024 * 8 + 16 * 8) + 2 * 1024 * 1024 * 2
     assert 36_722_688 * 2 + fold <= packed < 36_722_688 * 2 + fold + 300_000
     ws = lib.tp_workspace_bytes(ctypes.byref(d))
     assert 1.0e9 < ws < 1.3e9            # schedule-aware: the s = 2 default writes neither H2 nor K | V nor Q1pre
@@ -134,7 +134,7 @@ def test_train_hd_and_parts_entry_points_reject_bad_arguments():
     assert lib.tp_hd_slice(None, 100, 100, 1, 1, 336, 336, 0, 0, None, 336, None) == E
     assert lib.tp_test_occupy_cus(0, 1, None, None) == E
     assert lib.tp_test_pack_qr(None, None, None, None, None, None, None) == E          # (test hook of the pack-time QR)
-    assert lib.tp_test_pack_qr_scratch_bytes() == 1024 * 1025 * 8 + 1024 * 8 + 256
+    assert lib.tp_test_pack_qr_scratch_bytes() == 1024 * 1025 * 8 + 16 * 1024 * 8 + 16 * 8 + 256
     # the weight-gradient contraction on its own
     assert lib.tp_wgrad_workspace_bytes(1024, 4096) == 16 * 1024 * 4096 * 4
     assert lib.tp_wgrad_workspace_bytes(0, 4096) == 0

@@ -77,3 +77,5 @@ def test_e2e_line_single_rank():
     assert len(lines) == 1, res.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["unit"] == "tokens/s" and d["value"] > 0 and d["split_ms"]["projector_hip"] > 0
+    # BASELINE configs[4] is quoted "vs reference": the same run with the reference's projector, after the timed region
+    assert d["reference_leg"]["value"] > 0 and d["vs_reference"] > 0 and d["projector_speedup_in_place"] > 0
