@@ -121,8 +121,10 @@ size_t tp_workspace_bytes(const tp_desc* desc);
  *             forward that clamps anything ORs bit k into this word (k = 1 + index of the stage in tp_forward_staged's list,
  *             bit 0 = the query side).  The library never clears it: read it back whenever convenient (a 4-byte copy),
  *             nonzero = some forward since the last clear differs from what the reference would have computed.
- *             (Training forwards are not tracked — their epilogues have no register to spare; scan them with
- *             tp_debug_count_saturated.) */
+ *             Covered: every fp16 epilogue of the GEMM kernels and the K-split reduction of small batches (ABI 4).  NOT covered: a
+ *             NaN inside a GEMM epilogue (the running max that tracks |v| is a v_max3, which drops NaN operands; the K-split
+ *             reduction does report NaN), and training forwards (their epilogues have no register to spare) — scan those
+ *             with tp_debug_count_saturated, which counts values at the bound AND NaNs. */
 #define TP_WORKSPACE_STATUS_BYTES 256
 
 /* ---- one-time weight preparation -------------------------------------------------------------
@@ -133,6 +135,10 @@ size_t tp_workspace_bytes(const tp_desc* desc);
  * mlp[0] (W = Wm0·Wout, b = Wm0·bout + bm0), biases widened to fp32.  Must be re-run whenever a parameter changes.  `packed` needs tp_packed_weight_bytes(). */
 int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, size_t packed_bytes,
                     void* stream);
+/* The library keeps a HOST-side note of what tp_pack_weights wrote at an address (hidden size, dtype, TP_DESC_TRAIN_PACK) and
+ * refuses a forward the image cannot serve.  The note describes the address, not the bytes: before the memory of an image is
+ * freed / reused for anything but a re-pack in place, drop it with tp_pack_forget (an unknown address is accepted unchecked). */
+int tp_pack_forget(const void* packed);
 
 /* ---- the hot path ------------------------------------------------------------------------------
  * Replaces `TokenPacker.forward((x, x_multi))` (builder.py:107-137).

@@ -34,7 +34,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 # every symbol include/tokenpacker.h declares
 EXPORTED_SYMBOLS = (
     "tp_version", "tp_last_error", "tp_packed_weight_bytes", "tp_workspace_bytes",
-    "tp_pack_weights", "tp_forward", "tp_forward_staged", "tp_point_queries", "tp_region_attention", "tp_linear",
+    "tp_pack_weights", "tp_pack_forget", "tp_forward", "tp_forward_staged", "tp_point_queries", "tp_region_attention", "tp_linear",
     "tp_ln_finalize", "tp_linear_stats_parts", "tp_set_tuning", "tp_hd_rows", "tp_hd_assemble",
     "tp_train_workspace_bytes", "tp_backward_workspace_bytes", "tp_forward_train", "tp_backward",
     "tp_forward_parts", "tp_forward_train_parts", "tp_backward_parts", "tp_test_occupy_cus", "tp_hd_slice",
@@ -126,6 +126,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.tp_debug_count_saturated.argtypes = [POINTER(tp_desc), c_void_p, c_size_t, c_void_p, c_void_p]
     lib.tp_pack_weights.restype = c_int
     lib.tp_pack_weights.argtypes = [POINTER(tp_desc), POINTER(tp_weights), c_void_p, c_size_t, c_void_p]
+    lib.tp_pack_forget.restype = c_int
+    lib.tp_pack_forget.argtypes = [c_void_p]
     lib.tp_forward.restype = c_int
     lib.tp_forward.argtypes = [POINTER(tp_desc), c_void_p, POINTER(c_int64), c_void_p, POINTER(c_int64),
                                c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]

@@ -211,7 +211,9 @@ bool fold_out_proj(const tp_desc* d, bool train) { return plan_schedule(d, train
 // memory, and a forward must not synchronise to read a header back).  The forward entry points refuse an image that cannot
 // serve them — a TRAIN_PACK image handed to an inference entry point, or an image packed for another hidden size / dtype —
 // instead of multiplying by weights that were never written.  An address the registry has not seen (an image the caller
-// copied elsewhere) is accepted unchecked.  256 entries, least recently packed first out.
+// copied elsewhere) is accepted unchecked.  256 entries, least recently packed first out.  The record describes an ADDRESS: a
+// caller that frees an image and lets its allocator hand the address to something else (another image memcpy'd there) tells the
+// library with tp_pack_forget — the torch binding does so whenever it drops an image — or the stale record answers for it.
 struct PackRec { int dev; const void* ptr; int train_pack, D, dtype; unsigned long long stamp; };
 static std::mutex g_pack_mu;
 static std::vector<PackRec> g_pack_reg;
@@ -228,6 +230,13 @@ void pack_registry_put(const void* packed, const tp_desc* d, bool train_pack) {
         g_pack_reg.erase(g_pack_reg.begin() + (long)lru);
     }
     g_pack_reg.push_back(PackRec{dev, packed, train_pack ? 1 : 0, d->hidden_size, d->dtype, ++g_pack_clock});
+}
+void pack_registry_forget(const void* packed) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lock(g_pack_mu);
+    for (size_t i = 0; i < g_pack_reg.size(); ++i)
+        if (g_pack_reg[i].dev == dev && g_pack_reg[i].ptr == packed) { g_pack_reg.erase(g_pack_reg.begin() + (long)i); return; }
 }
 int pack_registry_check(const void* packed, const tp_desc* d, bool train) {
     int dev = 0;
@@ -661,49 +670,89 @@ namespace tp {
 // persistent GEMMs instead of running alone at 2.25 CU rounds.  One side stream + event pair per caller stream,
 // created on first use (the only state the library keeps besides the tuning table and the error string).
 struct SideCtx { hipStream_t s; hipEvent_t fork, join; };
-struct SideEntry { int dev; hipStream_t main; SideCtx ctx; unsigned long long stamp; };
+// `pins`: forwards between their fork and the enqueue of their join on this entry; `doomed`: released while pinned — destroyed by
+// the last unpin.  A pinned entry is never evicted and never destroyed under a forward that still records / waits on its events.
+struct SideEntry { int dev; hipStream_t main; SideCtx ctx; unsigned long long stamp; int pins; bool doomed; };
 static std::mutex g_side_mu;
 static std::vector<SideEntry> g_side_cache;
 static unsigned long long g_side_clock = 0;
-static void side_entry_destroy(SideEntry& e) {      // (called with the lock held)
-    (void)hipStreamSynchronize(e.ctx.s);            // whatever was forked onto it has been joined by its forward; be sure anyway
-    (void)hipEventDestroy(e.ctx.fork);
-    (void)hipEventDestroy(e.ctx.join);
-    (void)hipStreamDestroy(e.ctx.s);
+static void side_ctx_destroy(const SideCtx& c) {    // OUTSIDE the lock: the synchronize may block, and must not stall other forwards' lookups
+    (void)hipStreamSynchronize(c.s);                // whatever was forked onto it has been joined by its forward; be sure anyway
+    (void)hipEventDestroy(c.fork);
+    (void)hipEventDestroy(c.join);
+    (void)hipStreamDestroy(c.s);
 }
-// The side stream of (device, caller stream), created on first use; at most 64 per process, least recently used first out.
-// Returned BY VALUE: an entry evicted or released by another thread does not leave this forward with a dangling pointer
-// (HIP defers the destruction of a stream / event that still has work queued).
+// The side stream of (device, caller stream), created on first use and PINNED until side_unpin(); at most 64 per process, the
+// least recently used UNPINNED one first out (none unpinned: this forward runs its query side on the caller's stream).
 static bool side_ctx_for(hipStream_t main, SideCtx* out) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
-    std::lock_guard<std::mutex> lock(g_side_mu);
-    for (auto& e : g_side_cache)
-        if (e.dev == dev && e.main == main) { e.stamp = ++g_side_clock; *out = e.ctx; return true; }
-    if (g_side_cache.size() >= 64) {
-        size_t lru = 0;
-        for (size_t i = 1; i < g_side_cache.size(); ++i) if (g_side_cache[i].stamp < g_side_cache[lru].stamp) lru = i;
-        side_entry_destroy(g_side_cache[lru]);
-        g_side_cache.erase(g_side_cache.begin() + (long)lru);
+    SideCtx victim{};
+    bool have_victim = false, ok = false;
+    {
+        std::lock_guard<std::mutex> lock(g_side_mu);
+        for (auto& e : g_side_cache)
+            if (e.dev == dev && e.main == main && !e.doomed) { e.stamp = ++g_side_clock; ++e.pins; *out = e.ctx; return true; }
+        bool room = g_side_cache.size() < 64;
+        if (!room) {
+            long lru = -1;
+            for (size_t i = 0; i < g_side_cache.size(); ++i)
+                if (g_side_cache[i].pins == 0 && (lru < 0 || g_side_cache[i].stamp < g_side_cache[(size_t)lru].stamp)) lru = (long)i;
+            if (lru >= 0) {
+                victim = g_side_cache[(size_t)lru].ctx; have_victim = true;
+                g_side_cache.erase(g_side_cache.begin() + lru);
+                room = true;
+            }
+        }
+        if (room) {
+            SideCtx c{};
+            if (hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking) == hipSuccess) {
+                if (hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess) (void)hipStreamDestroy(c.s);
+                else if (hipEventCreateWithFlags(&c.join, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(c.fork); (void)hipStreamDestroy(c.s); }
+                else { g_side_cache.push_back(SideEntry{dev, main, c, ++g_side_clock, 1, false}); *out = c; ok = true; }
+            }
+        }
     }
-    SideCtx c{};
-    if (hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking) != hipSuccess) return false;
-    if (hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(c.s); return false; }
-    if (hipEventCreateWithFlags(&c.join, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(c.fork); (void)hipStreamDestroy(c.s); return false; }
-    g_side_cache.push_back(SideEntry{dev, main, c, ++g_side_clock});
-    *out = c;
-    return true;
+    if (have_victim) side_ctx_destroy(victim);
+    return ok;
 }
+static void side_unpin(hipStream_t main, const SideCtx& ctx) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    SideCtx victim{};
+    bool have_victim = false;
+    {
+        std::lock_guard<std::mutex> lock(g_side_mu);
+        for (size_t i = 0; i < g_side_cache.size(); ++i) {
+            SideEntry& e = g_side_cache[i];
+            if (e.dev == dev && e.main == main && e.ctx.s == ctx.s) {
+                if (e.pins > 0) --e.pins;
+                if (e.doomed && e.pins == 0) { victim = e.ctx; have_victim = true; g_side_cache.erase(g_side_cache.begin() + (long)i); }
+                break;
+            }
+        }
+    }
+    if (have_victim) side_ctx_destroy(victim);
+}
+struct SidePin {                                    // unpins when the forward leaves (its join has been enqueued, or it failed)
+    hipStream_t main; SideCtx ctx; bool held;
+    ~SidePin() { if (held) side_unpin(main, ctx); }
+};
 int release_stream_state(hipStream_t main) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { set_error("tp_release_stream: hipGetDevice failed"); return TP_ERR_LAUNCH; }
-    std::lock_guard<std::mutex> lock(g_side_mu);
-    for (size_t i = 0; i < g_side_cache.size(); ++i)
-        if (g_side_cache[i].dev == dev && g_side_cache[i].main == main) {
-            side_entry_destroy(g_side_cache[i]);
-            g_side_cache.erase(g_side_cache.begin() + (long)i);
-            break;
-        }
+    SideCtx victim{};
+    bool have_victim = false;
+    {
+        std::lock_guard<std::mutex> lock(g_side_mu);
+        for (size_t i = 0; i < g_side_cache.size(); ++i)
+            if (g_side_cache[i].dev == dev && g_side_cache[i].main == main && !g_side_cache[i].doomed) {
+                if (g_side_cache[i].pins > 0) g_side_cache[i].doomed = true;       // a forward of another thread is inside: its unpin destroys
+                else { victim = g_side_cache[i].ctx; have_victim = true; g_side_cache.erase(g_side_cache.begin() + (long)i); }
+                break;
+            }
+    }
+    if (have_victim) side_ctx_destroy(victim);
     return TP_OK;
 }
 int side_cache_size() { std::lock_guard<std::mutex> lock(g_side_mu); return (int)g_side_cache.size(); }
@@ -821,11 +870,13 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         p.bias = nullptr; p.flags = 0; p.tile = 128; p.c_split_cols = 0;
         TP_TRY(launch(in_dt, TP_F32, p, st));
         return splitk_reduce_launch((const float*)slab(W.splitk), S, a.M, a.N, a.bias, (a.flags & TP_LINEAR_GELU) ? 1 : 0, a.C, a.ldc,
-                                    out_dt, st, a.c_split_cols, a.c_split_stride_bytes / (out_dt == TP_F32 ? 4 : 2));
+                                    out_dt, st, a.c_split_cols, a.c_split_stride_bytes / (out_dt == TP_F32 ? 4 : 2),
+                                    (int*)(ws + W.status), 1 << stage_idx);
     };
     // query side on a side stream (not when the caller wants per-stage events: those need one stream)
     SideCtx side_storage{};
     SideCtx* side = (tuning(TP_TUNE_Q_SIDE_STREAM) && !stage_events && side_ctx_for(stream, &side_storage)) ? &side_storage : nullptr;
+    SidePin side_pin{stream, side_storage, side != nullptr};   // pinned until this call returns: nobody destroys its events under it
     const int parts_q = gemm_stats_parts(E);
     // (fused LayerNorm chain, inference: Q1pre is computed for its row statistics only; the in-projection reads q0)
     const bool fuse_q = plan.fuse_q;
@@ -1087,6 +1138,12 @@ int tp_forward_staged(const tp_desc* desc, const void* x, const int64_t x_stride
 }
 
 int tp_release_stream(void* stream) { return release_stream_state((hipStream_t)stream); }
+
+int tp_pack_forget(const void* packed) {
+    if (!packed) { set_error("tp_pack_forget: NULL"); return TP_ERR_INVALID_ARG; }
+    pack_registry_forget(packed);
+    return TP_OK;
+}
 
 int tp_test_side_cache_size(void) { return side_cache_size(); }
 

@@ -282,7 +282,8 @@ WorkspaceLayout workspace_layout(int B, int grid, int s, int D, bool train = fal
 constexpr size_t kSplitKBytes = (size_t)512 * 128 * 128 * 4;
 // out[m, n] = epilogue(sum over the S partials [S][M][N] fp32, in split order): + bias, optional erf GELU, cast to out_dtype
 int splitk_reduce_launch(const float* partials, int S, int M, int N, const float* bias, int gelu, void* out, long long ldc,
-                         int out_dtype, hipStream_t stream, int split_cols = 0, long long split_stride_elems = 0);
+                         int out_dtype, hipStream_t stream, int split_cols = 0, long long split_stride_elems = 0,
+                         int* sat_flag = nullptr, int sat_bit = 0);       // fp16 output: the sticky saturation report (GemmArgs::sat_flag)
 
 // ---- backward helpers (tp_bwd.hip) -------------------------------------------------------------
 int bw_transpose_launch(int src_dtype, int dst_dtype, const void* src, long long ld, int rows_per_batch,
@@ -319,6 +320,7 @@ int bw_region_attention_launch(int gdtype, const void* q, const void* k, const v
 int validate_desc(const tp_desc* d);
 void pack_registry_put(const void* packed, const tp_desc* d, bool train_pack);      // tp_api.hip: what an image was packed for
 int pack_registry_check(const void* packed, const tp_desc* d, bool train);
+void pack_registry_forget(const void* packed);
 GemmArgs plain_gemm(const void* A, long long lda_elems, const void* W, void* C, long long ldc, int M, int N, int K,
                     const float* bias, int flags);
 long long max_images_per_launch(const tp_desc* desc);

@@ -645,7 +645,8 @@ namespace tp {
 template <typename TO>
 __global__ void __launch_bounds__(256)
 splitk_reduce_kernel(const float* __restrict__ part, int S, long long MN, int N, const float* __restrict__ bias, int gelu,
-                     TO* __restrict__ out, long long ldc, int split_cols, long long split_stride) {
+                     TO* __restrict__ out, long long ldc, int split_cols, long long split_stride, int* __restrict__ sat_flag,
+                     int sat_bit) {
     const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i4 >= MN) return;
     const long long m = i4 / N;
@@ -666,8 +667,16 @@ splitk_reduce_kernel(const float* __restrict__ part, int S, long long MN, int N,
         *(f32x4*)o = acc;
     } else {
         if constexpr (std::is_same<TO, f16_t>::value) {
+            // the sticky fp16-saturation report of the GEMM epilogues (GemmArgs::sat_flag), for the K-split route as well: a value
+            // the reference's fp16 arithmetic would have turned into inf — or a NaN (`!(|v| < 65520)` is true for it) — ORs the
+            // stage's bit.  (This kernel is memory-bound and runs for batches of <= 8 images: the test per element is free.)
+            bool sat = false;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = __builtin_amdgcn_fmed3f(acc[r], -65504.f, 65504.f);
+            for (int r = 0; r < 4; ++r) {
+                sat |= !(fabsf(acc[r]) < 65520.f);
+                acc[r] = __builtin_amdgcn_fmed3f(acc[r], -65504.f, 65504.f);
+            }
+            if (sat_flag && sat) __hip_atomic_fetch_or(sat_flag, sat_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         using O4 = typename Vec<TO>::x4;
         *(O4*)o = __builtin_convertvector(acc, O4);
@@ -675,15 +684,15 @@ splitk_reduce_kernel(const float* __restrict__ part, int S, long long MN, int N,
 }
 
 int splitk_reduce_launch(const float* partials, int S, int M, int N, const float* bias, int gelu, void* out, long long ldc,
-                         int out_dtype, hipStream_t stream, int split_cols, long long split_stride) {
+                         int out_dtype, hipStream_t stream, int split_cols, long long split_stride, int* sat_flag, int sat_bit) {
     const long long MN = (long long)M * N;
     const unsigned blocks = (unsigned)((MN / 4 + 255) / 256);
     if (out_dtype == TP_F16)
-        hipLaunchKernelGGL(splitk_reduce_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream, partials, S, MN, N, bias, gelu, (f16_t*)out, ldc, split_cols, split_stride);
+        hipLaunchKernelGGL(splitk_reduce_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream, partials, S, MN, N, bias, gelu, (f16_t*)out, ldc, split_cols, split_stride, sat_flag, sat_bit);
     else if (out_dtype == TP_BF16)
-        hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, partials, S, MN, N, bias, gelu, (bf16_t*)out, ldc, split_cols, split_stride);
+        hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, partials, S, MN, N, bias, gelu, (bf16_t*)out, ldc, split_cols, split_stride, nullptr, 0);
     else
-        hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, partials, S, MN, N, bias, gelu, (float*)out, ldc, split_cols, split_stride);
+        hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, partials, S, MN, N, bias, gelu, (float*)out, ldc, split_cols, split_stride, nullptr, 0);
     return check_launch("splitk_reduce_kernel");
 }
 

@@ -22,6 +22,7 @@ fallback: CPU tensors, unsupported dtypes or a missing library raise.
 from __future__ import annotations
 
 import ctypes
+import weakref
 from functools import partial
 from typing import Dict, Optional, Tuple
 
@@ -52,6 +53,13 @@ class _ProjectFn(torch.autograd.Function):
         xm, params = rest[:ctx.n_parts], rest[ctx.n_parts:]
         grads = ctx.module._launch_backward(ctx.desc, xm[0] if ctx.n_parts == 1 else xm, train_ws, packed, params, dy)
         return (None, None, None) + (None,) * ctx.n_parts + tuple(grads)
+
+
+def _forget_packed(ptr: int) -> None:
+    try:
+        _capi.load_library().tp_pack_forget(ptr)
+    except Exception:                # noqa: interpreter shutdown
+        pass
 
 
 class TokenPacker(nn.Module):
@@ -190,6 +198,9 @@ class TokenPacker(nn.Module):
         if nbytes == 0:
             raise RuntimeError(f"tp_packed_weight_bytes: {_capi.last_error()}")
         packed = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        # the library keeps a host-side note per image ADDRESS; when this tensor dies its address goes back to the caching
+        # allocator, so the note goes too (tp_pack_forget) — a later tensor at the same address is not judged by it
+        weakref.finalize(packed, _forget_packed, packed.data_ptr())
         # fp32 master weights (autocast / fp32_compute_dtype) are rounded to the compute dtype here, like autocast does
         contiguous = [w.detach().to(dtype).contiguous() for w in weights]      # keeps temporaries alive until enqueued
         raw = _capi.tp_weights(*[t.data_ptr() for t in contiguous])

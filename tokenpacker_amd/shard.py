@@ -208,6 +208,10 @@ class DirectGather:
         from . import _capi
         if depth < 2:
             raise ValueError("DirectGather needs depth >= 2 (a buffer is being filled while the previous one is read)")
+        if depth > 6:
+            # the sequence numbers travel through an 8-slot cell ring (cell seq % 8): a peer stream's 4-byte flag copy of step i may
+            # still be pending `depth` steps later, and with depth >= 8 its cell would hold step i + 8 by then
+            raise ValueError("DirectGather: depth <= 6 (the sequence cells are an 8-slot ring)")
         self._capi, self._ct = _capi, ctypes
         self.lib = _capi.load_library()
         self.group, self.depth, self.use_cus, self.timeout_ms = group, depth, int(bool(use_cus)), int(timeout_ms)
@@ -232,6 +236,11 @@ class DirectGather:
                 if self.lib.tp_gather_alloc_flags(ctypes.byref(fp), 64 * 4) == _capi.TP_OK:
                     self._flags_ptr, self._flags_owned, self._flags_keep = int(fp.value), True, None
                 else:
+                    import warnings
+                    warnings.warn("DirectGather: the runtime refused fine-grained memory for the sequence flags; falling back to ordinary "
+                                  "device memory, which is only guaranteed coherent for flags written by OTHER devices' copy engines at "
+                                  "kernel boundaries — fine between processes on one device, on a multi-GPU node expect stale flags "
+                                  "(timeouts): use the rccl gather there", RuntimeWarning)
                     self._flags_keep = torch.zeros(64, dtype=torch.int32, device=self.device)
                     self._flags_ptr, self._flags_owned = self._flags_keep.data_ptr(), False
                 self.cells = torch.zeros(8, dtype=torch.int32, device=self.device)
