@@ -854,7 +854,7 @@ def main():
                        "parallelism": f"batch-shard x{world}" + ((" + all_gather(tokens)" + (
                            ", gather of step i overlapped with forward of step i+1" if ((chosen == "rccl" and pipe is not None) or (chosen == "sdma" and not args.sync_gather)) else "")) if gather else ""),
                        "weights": "random init (reference distribution), synthetic unit-normal CLIP features",
-                       "tuning": {k: _capi.get_tuning(getattr(_capi, k)) for k in dir(_capi) if k.startswith("TP_TUNE_")}},
+                       "tuning": {k: _capi.get_tuning(getattr(_capi, k)) for k in dir(_capi) if k.startswith("TP_TUNE_") and k != "TP_TUNE_COUNT"}},
             "whole_path": {"achieved_tflops": round(fl_img * total / (ms_per_step * 1e-3) / 1e12, 1),
                            "frac_of_mfma_peak": round(fl_img * total / (ms_per_step * 1e-3) / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),
                            "algorithmic_gflop_per_image": round(fl_img / 1e9, 3),

@@ -76,7 +76,7 @@ PackedLayout packed_layout(int D) {
     L.w_c_q = take(E * E * 2);
     L.w_cc_kv = take(2 * E * E * 2);     L.d_cc_kv = take(2 * E * 4);
     L.w_cc_q = take(E * E * 2);          L.w_qt_cc = take(E * E * 2);
-    L.w_cc_v2 = take(2 * E * E * 2);
+    L.w_cc_v3 = take(3 * E * E * 2);
     L.w_r_kv = take(2 * E * E * 2);      L.c_r_kv = take(2 * E * 4);
     L.w_r_q = take(E * E * 2);
     L.wbar = take(3 * (E + 1) * 4);      L.scratch_qr = take(pack_qr_scratch_bytes(3));
@@ -452,18 +452,12 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
             GemmArgs a2 = plain_gemm(lo16, E, P + L.scratch_t, (char*)P2, E, (int)E, (int)E, (int)E, nullptr, 0);
             a2.tile = 128;
             TP_TRY(gemm_launch(TP_F16, TP_F32, a2, stream));
+            // (g = 1, the V side: also as rows [hi | hi | lo] for the absorbed schedule's per-head V GEMM)
             TP_TRY(pack_center_product_launch((const float*)(P + L.scratch_p), c_ex, wbar + g * (E + 1),
                                               P + L.w_cc_kv + (size_t)g * E * E * 2, d_ex,
-                                              (float*)(P + L.d_cc_kv) + g * E, stream, sat, P2));
+                                              (float*)(P + L.d_cc_kv) + g * E, stream, sat, P2, g == 1 ? P + L.w_cc_v3 : nullptr));
         }
         TP_TRY(pack_head_transpose_launch(P + L.w_cc_kv, P + L.w_qt_cc, stream));
-        {   // Wc'_v with every row twice side by side: the absorbed schedule's per-head V GEMM contracts u = hi | lo (2 E wide)
-            const char* src = P + L.w_cc_kv + E * E * 2;
-            for (int half = 0; half < 2; ++half) {
-                hipError_t e2 = hipMemcpy2DAsync(P + L.w_cc_v2 + half * E * 2, 2 * E * 2, src, E * 2, E * 2, E, hipMemcpyDeviceToDevice, stream);
-                if (e2 != hipSuccess) { set_error("tp_pack_weights: hipMemcpy2DAsync: %s", hipGetErrorString(e2)); return TP_ERR_LAUNCH; }
-            }
-        }
         // (the absorbed schedule on this chain: qt = per-head Q_h·Wc_k,h — the per-head transposes of the ROUNDED Wc_k)
         TP_TRY(pack_head_transpose_launch(P + L.w_c_kv, P + L.w_qt_c, stream));
         {   // query side: Q = rstd·(q0·Wcq^T − mu·c_q) + b'_q,  Wcq = W'q·Wq1  (q_proj_1 has no bias)
@@ -1057,12 +1051,14 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
                                                     (const float*)(ws + W.mr_kv) + (size_t)rows_kv * 2, uu, B, g, s, stream, attn_mask, mask_mode));
         // O[:, h*128:(h+1)*128] = u[:, h, :] · W'v[h*128:(h+1)*128, :]^T + b'v   (eight N = 128 groups)
         // RAW: a_h (u_h · Wc_v,h^T + d_v,h - (e_h / a_h) c_v,h) + b'v,h — a LayerNorm-fold epilogue with (mean, rstd) := mr_u
-        // u_split: the contraction runs over hi | lo (K = 2 E) against Wc'_v's rows written twice — u's fp16 rounding drops out
-        const int uK = u_split ? 2 * E : E;
-        GemmArgs a = plain_gemm(uu, 8 * uK, u_split ? pw + P.w_cc_v2
-                                                    : (absorb_raw ? (tri ? pw + P.w_cc_kv : pw + P.w_c_kv) : pw + P.w_in_kv) + (size_t)E * E * 2,
+        // u_split: the contraction runs over (u_hi | u_lo | u_hi) against Wc'_v's rows as [hi | hi | lo] (K = 3 E; the operand's three
+        // K ranges are two views of u, GemmArgs::A_parts) — neither u's nor the pre-multiplied weight's fp16 rounding survives
+        const int uK = u_split ? 3 * E : E, uld = u_split ? 2 * E : E;
+        GemmArgs a = plain_gemm(uu, 8 * uld, u_split ? pw + P.w_cc_v3
+                                                     : (absorb_raw ? (tri ? pw + P.w_cc_kv : pw + P.w_c_kv) : pw + P.w_in_kv) + (size_t)E * E * 2,
                                 ws + W.o, E, rows_q, kHeadDim, uK, (const float*)(pw + P.b_in_kv) + E, absorb_raw ? TP_LINEAR_LN_FOLD : 0);
-        a.groups = kHeads; a.a_gs = uK * 2; a.w_gs = (long long)kHeadDim * uK * 2; a.c_gs = kHeadDim * 2; a.bias_gs = kHeadDim;
+        a.groups = kHeads; a.a_gs = uld * 2; a.w_gs = (long long)kHeadDim * uK * 2; a.c_gs = kHeadDim * 2; a.bias_gs = kHeadDim;
+        if (u_split) { a.A_parts[0] = uu; a.A_parts[1] = uu + (size_t)E * 2; a.A_parts[2] = uu; a.A_parts[3] = uu; a.k_part = E; }
         if (absorb_raw) {
             a.acc_init = (const float*)(tri ? pw + P.d_cc_kv : pw + P.d_in_kv) + E; a.acc_init_gs = kHeadDim;
             a.colsum = (const float*)(pw + P.c_in_kv) + E; a.colsum_gs = kHeadDim;

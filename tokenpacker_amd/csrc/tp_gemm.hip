@@ -264,10 +264,12 @@ static int launch_types(const GemmArgs& a, hipStream_t stream) {
     const bool train_epi = (a.flags & (TP_LINEAR_SAVE_PRE | TP_LINEAR_GELU_BWD)) != 0;
     if ((a.flags & TP_LINEAR_NO_STORE) || a.acc_init) {     // the two GEMMs of the fused LayerNorm chain (128-tile form)
         if constexpr (std::is_same<TI, f16_t>::value && std::is_same<TO, f16_t>::value) {
-            if (strided || train_epi || a.A_parts[0] || ((a.flags & TP_LINEAR_NO_STORE) && a.acc_init)) {
+            if (strided || train_epi || ((a.flags & TP_LINEAR_NO_STORE) && a.acc_init) || (a.A_parts[0] && (!a.acc_init || a.attn_mode))) {
                 set_error("tp gemm: NO_STORE / acc_init take a contiguous A, no training epilogue, and not both at once");
                 return TP_ERR_INVALID_ARG;
             }
+            // (acc_init with K split over source tensors: the absorbed schedule's per-head V GEMM over u = hi | lo | hi)
+            if (a.A_parts[0]) return launch_cfg<TI, TO, 128, 128, 64, 64, 2, false, 2>(a, stream);
             if (a.attn_mode)                                 // (validated by gemm_launch)
                 return a.attn_mode == 1 ? launch_cfg<TI, TO, 128, 128, 64, 64, 0, false, 3>(a, stream)
                                         : launch_cfg<TI, TO, 128, 128, 64, 64, 0, false, 4>(a, stream);

@@ -187,7 +187,7 @@ int pack_qr_center_launch(const void* w2_f16, const float* b2, void* scratch, in
 int pack_qr_factor_launch(void* scratch, int nmat, hipStream_t stream);
 int pack_qr_extract_launch(const void* scratch, int m, void* r_f16, float* ctil, hipStream_t stream, int* sat);
 int pack_center_product_launch(const float* P, const float* c, const float* wbar, void* out_f16, const float* d, float* d_out,
-                               hipStream_t stream, int* sat, const float* P2 = nullptr);
+                               hipStream_t stream, int* sat, const float* P2 = nullptr, void* out3_f16 = nullptr);   // out3: rows [hi | hi | lo]
 // lo = fp16(W' − fp16(W')), c_exact = rowsum(W'), d_exact = W'·v (v may be NULL), W' = w·diag(gamma) exact in fp32 (tp_kernels.hip)
 int pack_ln_fold_residual_launch(int dtype, const void* w, const void* gamma, const float* v, void* lo_f16, float* c_exact,
                                  float* d_exact, int n_out, int n_in, hipStream_t stream);
@@ -228,7 +228,8 @@ struct PackedLayout {
     size_t w_cc_kv, d_cc_kv;      // [2][1024,1024] f16, [2][1024] f32
     size_t w_cc_q;                // [1024,1024] f16
     size_t w_qt_cc;               // per-head transposes of Wc'_k (absorbed schedule)
-    size_t w_cc_v2;               // [8][128][2 E] f16: the rows of Wc'_v twice side by side — the per-head V GEMM over u = hi | lo
+    size_t w_cc_v3;               // [E][3 E] f16: the rows of Wc'_v as hi | hi | lo (lo = what its fp16 rounding drops) — the absorbed
+                                  // schedule's per-head V GEMM contracts (u_hi | u_lo | u_hi) with it: neither rounding survives
     size_t w_r_kv, c_r_kv;        // [2][1024,1024] f16 (zeros below the diagonal), [2][1024] f32
     size_t w_r_q;                 // [1024,1024] f16
     size_t wbar;                  // pack scratch: [3][1025] f32 column means of W2 (k, v, q) and the mean of b2 behind each

@@ -181,7 +181,8 @@ qr_extract_kernel(const double* __restrict__ A, f16_t* __restrict__ r16, float* 
 // d_out[n] = d[n] - c[n] bbar   (d may be NULL: no bias)
 __global__ void __launch_bounds__(256)
 center_product_kernel(const float* __restrict__ P, const float* __restrict__ P2, const float* __restrict__ c, const float* __restrict__ wbar,
-                      f16_t* __restrict__ out, const float* __restrict__ d, float* __restrict__ d_out, int* __restrict__ sat) {
+                      f16_t* __restrict__ out, const float* __restrict__ d, float* __restrict__ d_out, int* __restrict__ sat,
+                      f16_t* __restrict__ out3) {
     const int n = blockIdx.x;
     const float cn = c[n];
     for (int k = threadIdx.x; k < QE; k += blockDim.x) {
@@ -189,7 +190,12 @@ center_product_kernel(const float* __restrict__ P, const float* __restrict__ P2,
         if (P2) pv += P2[(long long)n * QE + k];
         float v = fmaf(-cn, wbar[k], pv);
         if (!(fabsf(v) <= 65504.f)) { if (sat) atomicAdd(sat, 1); v = fminf(fmaxf(v, -65504.f), 65504.f); }
-        out[(long long)n * QE + k] = (f16_t)v;
+        const f16_t hi = (f16_t)v;
+        out[(long long)n * QE + k] = hi;
+        if (out3) {                                            // [hi | hi | lo] rows of 3 E: the contraction over (u_hi | u_lo | u_hi)
+            f16_t* o3 = out3 + (long long)n * 3 * QE + k;
+            o3[0] = hi; o3[QE] = hi; o3[2 * QE] = (f16_t)(v - (float)hi);
+        }
     }
     if (threadIdx.x == 0 && d_out) d_out[n] = (d ? d[n] : 0.f) - cn * wbar[QE];
 }
@@ -233,8 +239,8 @@ int pack_qr_extract_launch(const void* scratch, int m, void* r_f16, float* ctil,
 }
 
 int pack_center_product_launch(const float* P, const float* c, const float* wbar, void* out_f16, const float* d, float* d_out,
-                               hipStream_t stream, int* sat, const float* P2) {
-    hipLaunchKernelGGL(center_product_kernel, dim3(QE), dim3(256), 0, stream, P, P2, c, wbar, (f16_t*)out_f16, d, d_out, sat);
+                               hipStream_t stream, int* sat, const float* P2, void* out3_f16) {
+    hipLaunchKernelGGL(center_product_kernel, dim3(QE), dim3(256), 0, stream, P, P2, c, wbar, (f16_t*)out_f16, d, d_out, sat, (f16_t*)out3_f16);
     return check_launch("center_product_kernel");
 }
 
