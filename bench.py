@@ -212,7 +212,11 @@ def read_clocks(device) -> dict:
     sysfs files; {} where the box exposes none (never an error: this is a diagnostic)."""
     import glob
     try:
-        bus = (getattr(torch.cuda.get_device_properties(device), "pci_bus_id", None) or "").lower()
+        pr = torch.cuda.get_device_properties(device)
+        bus = getattr(pr, "pci_bus_id", None)
+        if isinstance(bus, int):             # torch reports the three numbers; sysfs paths end in "dddd:bb:dd.f"
+            bus = f"{getattr(pr, 'pci_domain_id', 0):04x}:{bus:02x}:{getattr(pr, 'pci_device_id', 0):02x}.0"
+        bus = (bus or "").lower()
         cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
         pick = [c for c in cards if bus and os.path.realpath(c).lower().endswith(bus)] or \
                [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk"))]

@@ -19,9 +19,11 @@ from oracle import tokenpacker_oracle as orc            # (the checker: this too
 from tokenpacker_amd import TokenPacker, synth
 
 
-def sweep(seeds, D=256, B=4, scale_factors=(2, 3, 4), log=print):
+def sweep(seeds, D=256, B=4, scale_factors=(2, 3, 4), log=print, tags=("bf16_fp32out", "fp16")):
     summary = {}
     for s, (dtype, tag) in itertools.product(scale_factors, ((torch.bfloat16, "bf16_fp32out"), (torch.float16, "fp16"))):
+        if tag not in tags:
+            continue
         errs, l2s = [], []
         for seed in range(seeds):
             params = synth.make_params(9000 + 17 * seed + s, D)
@@ -50,8 +52,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=128)
     ap.add_argument("--out", default="gpurun_out/parity_seed_sweep.json")
+    ap.add_argument("--scale-factors", type=int, nargs="+", default=[2, 3, 4])
+    ap.add_argument("--tags", nargs="+", default=["bf16_fp32out", "fp16"])
     args = ap.parse_args()
-    summary = sweep(args.seeds)
+    summary = sweep(args.seeds, scale_factors=tuple(args.scale_factors), tags=tuple(args.tags))
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     json.dump(summary, open(args.out, "w"), indent=1)
 
