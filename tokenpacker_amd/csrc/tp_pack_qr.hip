@@ -31,7 +31,9 @@ __device__ __forceinline__ double block_sum_1024(double v, double* red) {
     return s;
 }
 
-// One block per column k (k = E: the bias column): A[n][k] = w2[n][k] - mean_n w2[n][k] in fp64; wbar[k] = that mean (fp32).
+// The factorisation's working matrix is COLUMN-major in the scratch: At[k][n], k <= E (k = E: the bias column) — a thread per row
+// then reads a column with unit stride, and a wave can own whole columns (qr_apply_kernel).
+// One block per column k: At[k][n] = w2[n][k] - mean_n w2[n][k] in fp64; wbar[k] = that mean (fp32).
 __global__ void __launch_bounds__(1024)
 qr_center_kernel(const f16_t* __restrict__ w2, const float* __restrict__ b2, double* __restrict__ A, float* __restrict__ wbar) {
     __shared__ double red[16];
@@ -40,7 +42,7 @@ qr_center_kernel(const f16_t* __restrict__ w2, const float* __restrict__ b2, dou
     if (k < QE) x = (double)(float)w2[(long long)n * QE + k];
     else x = b2 ? (double)b2[n] : 0.0;
     const double mean = block_sum_1024(x, red) / QE;
-    A[(long long)n * QP + k] = x - mean;
+    A[(long long)k * QE + n] = x - mean;
     if (n == 0) wbar[k] = (float)mean;                  // wbar[E] = mean(b2)
 }
 
@@ -49,132 +51,245 @@ qr_center_kernel(const f16_t* __restrict__ w2, const float* __restrict__ b2, dou
 // per pack, a third of all GPU time in a bench trace).  Same reflectors, same arithmetic per element — only grouped:
 //   qr_panel_kernel   one workgroup per matrix, one thread per row, the row's QB panel values in registers: for each panel column
 //                     the Householder vector (v, beta) — written to V[jj] with zeros above the diagonal — and its application to
-//                     the panel's remaining columns (all their dot products reduced in ONE block reduction per column);
-//   qr_apply_kernel   one workgroup per 16 trailing columns (the bias column E included): its 1024 x 16 block in registers,
-//                     the panel's QB reflectors staged in LDS and applied one after the other — the block is read and written
-//                     once per panel instead of once per reflection.
+//                     the panel's remaining columns.  All the column's dot products travel through ONE halving butterfly per
+//                     wave (17 shuffles for 16 sums) and one cross-wave step.
+//   qr_apply_kernel   a WAVE per two trailing columns (the bias column E included), the columns in registers, the panel's QB
+//                     reflectors staged in LDS and applied one after the other: no barrier inside, the matrix read and
+//                     written once per panel instead of once per reflection.
+// (Two earlier forms of the same blocking, kept out: the panel in LDS with one dot product per wave was LDS-bandwidth-bound —
+// 65 us per panel; sixteen independent shuffle reductions per wave per column were latency-bound — 178 us per panel.)
 constexpr int QB = 16;                 // panel width
 
-__global__ void __launch_bounds__(1024)
-qr_panel_kernel(double* __restrict__ Aall, double* __restrict__ Vall, double* __restrict__ betas, const int j0) {
-    extern __shared__ double lds_qr[];                         // the panel, column-major [QB][QE] | red[16][QB] | broadcast slot
-    double* Ap = lds_qr;
-    double* red = lds_qr + QB * QE;
-    double* s_bc = red + 16 * QB;
-    double* A = Aall + (long long)blockIdx.x * QE * QP;
-    double* V = Vall + (long long)blockIdx.x * QB * QE;
-    const int r = threadIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int c = 0; c < QB; ++c) Ap[c * QE + r] = (j0 + c < QE) ? A[(long long)r * QP + j0 + c] : 0.0;
-    // (a thread only ever touches its own row of the panel: no barrier needed around Ap)
-    for (int jj = 0; jj < QB; ++jj) {
-        const int j = j0 + jj;
-        // (columns past E - 2 carry no reflection: v = 0, beta = 0 — the arithmetic below then leaves everything as it is)
-        const bool live = j < QE - 1;
-        const double ajj = Ap[jj * QE + r];
-        const double x = (live && r >= j) ? ajj : 0.0;
-        // ---- || x ||^2 and x_j ----
-        double n2 = x * x;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) n2 += __shfl_xor(n2, off);
-        if (lane == 0) red[wv * QB] = n2;
-        if (r == j) s_bc[0] = x;
-        __syncthreads();
-        double norm2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) norm2 += red[i * QB];
-        const double xj = live ? s_bc[0] : 0.0;
-        const double alpha = xj >= 0.0 ? -sqrt(norm2) : sqrt(norm2);
-        const double vj = xj - alpha;
-        const double vtv = norm2 - xj * xj + vj * vj;
-        const double beta = (live && vtv > 0.0) ? 2.0 / vtv : 0.0;
-        const double v = !live ? 0.0 : (r == j ? vj : (r > j ? x : 0.0));
-        V[(long long)jj * QE + r] = v;
-        if (r == 0) betas[blockIdx.x * QB + jj] = beta;
-        if (live) Ap[jj * QE + r] = r == j ? alpha : (r > j ? 0.0 : ajj);
-        __syncthreads();                                       // red / s_bc are re-used below
-        // ---- the panel's remaining columns: w_c = beta v^T a_c, all of them behind ONE barrier ----
-        for (int c = jj + 1; c < QB; ++c) {
-            double pw = v * Ap[c * QE + r];
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) pw += __shfl_xor(pw, off);
-            if (lane == 0) red[wv * QB + c] = pw;
-        }
-        __syncthreads();
-        for (int c = jj + 1; c < QB; ++c) {
-            double w = 0.0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) w += red[i * QB + c];   // fixed order
-            Ap[c * QE + r] -= beta * w * v;
-        }
-        __syncthreads();
-    }
-    for (int c = 0; c < QB; ++c)
-        if (j0 + c < QE) A[(long long)r * QP + j0 + c] = Ap[c * QE + r];
+// ---- cross-lane sums without LDS traffic: DPP inside a row of 16 lanes, v_permlane{16,32}_swap (new on gfx950) across rows.
+// (__shfl_xor is ds_bpermute: with 16 waves reducing 16 values each, the LDS pipe was what both kernels waited for.) ----
+template <int CTRL>
+__device__ __forceinline__ double qr_dpp(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_SHL4 = 0x104, DPP_ROW_SHR4 = 0x114, DPP_ROW_ROR8 = 0x128;
+__device__ __forceinline__ double qr_xor1(double v) { return qr_dpp<DPP_QUAD_XOR1>(v); }
+__device__ __forceinline__ double qr_xor2(double v) { return qr_dpp<DPP_QUAD_XOR2>(v); }
+__device__ __forceinline__ double qr_xor8(double v) { return qr_dpp<DPP_ROW_ROR8>(v); }
+// lane l <- lane l ^ 4: a shift by four towards whichever side the partner sits on
+__device__ __forceinline__ double qr_xor4(double v, bool bit2) {
+    const double dn = qr_dpp<DPP_ROW_SHR4>(v), up = qr_dpp<DPP_ROW_SHL4>(v);    // lane l <- l - 4 | l + 4
+    return bit2 ? dn : up;
+}
+// lanes with bit 5 clear: a(l) + a(l ^ 32); the others: b(l ^ 32) + b(l)   (one swap per dword, no select)
+__device__ __forceinline__ double qr_halve32(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// lanes with bit 4 clear: a(l) + a(l ^ 16); the others: b(l ^ 16) + b(l)
+__device__ __forceinline__ double qr_halve16(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
 }
 
-// The panel's QB reflectors applied, in order, to 16 trailing columns (first column j0 + QB + 16 blockIdx.x; c = E: the bias column).
-// Thread (cl, rs): column cl of the block, rows rs, rs + 16, ...; the dot product of a reflector with a column is reduced over the
-// 16 row slices through LDS in a fixed order.
-__global__ void __launch_bounds__(256)
-qr_apply_kernel(double* __restrict__ Aall, const double* __restrict__ Vall, const double* __restrict__ betas, const int j0) {
-    extern __shared__ double lds_qr[];                         // V panel [QB][QE] | part[16][17]
-    double* Vs = lds_qr;
-    double (*part)[17] = (double (*)[17])(lds_qr + QB * QE);
-    double* A = Aall + (long long)blockIdx.y * QE * QP;
-    const double* V = Vall + (long long)blockIdx.y * QB * QE;
-    for (int i = threadIdx.x; i < QB * QE; i += 256) Vs[i] = V[i];
-    const int cl = threadIdx.x & 15, rs = threadIdx.x >> 4;
-    const int c = j0 + QB + blockIdx.x * 16 + cl;
-    const bool ok = c <= QE;
-    // rows below j0 are not touched by this panel (its reflectors are zero there): start at the 16-aligned row below j0
-    const int rbase = (j0 & ~15) + rs;
-    constexpr int NR = QE / 16;
-    double a[NR];
+// the sum over a wave's 64 lanes of each of 16 values: afterwards lane l holds the total of value qr_butterfly_slot(l)
+__device__ __forceinline__ int qr_butterfly_slot(int lane) {
+    return ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+}
+__device__ __forceinline__ double qr_butterfly16(const double (&p)[16], int lane) {
+    double q8[8], q4[4], q2[2];
+    const bool h3 = lane & 8, h2 = lane & 4;
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const int r = rbase + 16 * i;
-        a[i] = (ok && r < QE) ? A[(long long)r * QP + c] : 0.0;
+    for (int i = 0; i < 8; ++i) q8[i] = qr_halve32(p[i], p[i + 8]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q4[i] = qr_halve16(q8[i], q8[i + 4]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) q2[i] = (h3 ? q4[i + 2] : q4[i]) + qr_xor8(h3 ? q4[i] : q4[i + 2]);
+    double q = (h2 ? q2[1] : q2[0]) + qr_xor4(h2 ? q2[0] : q2[1], h2);
+    q += qr_xor2(q);
+    q += qr_xor1(q);
+    return q;
+}
+
+// 256 threads, thread t owns rows t + 256 i (i < 4): four waves keep the cross-lane and LDS work per column small (with a thread
+// per row, sixteen waves spent 2.7 us per column in the LDS pipe).
+constexpr int QPT = 256, QPR = QE / QPT;
+
+struct QrPanelShared {
+    double red[(QPT / 64) * QB];                               // [wave][column]: the waves' partial dot products
+    double dr[2][QB][2];                                       // [column]{x^T a_c, a_c[j]} (double-buffered: row j's entries are
+};                                                             //  written for the next column while this one's are still read)
+
+// column JJ of the panel (a template, not a loop: the compiler declines to unroll a body this size, and a rolled loop would index
+// the register block dynamically — 528 B of scratch)
+template <int JJ>
+__device__ __forceinline__ void qr_panel_step(double (&a)[QPR][QB], QrPanelShared& sh, double* __restrict__ V,
+                                              double* __restrict__ betas, const int j0) {
+    const int t = threadIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = j0 + JJ;
+    // (columns past E - 2 carry no reflection: v = 0, beta = 0 — the arithmetic below then leaves everything as it is)
+    const bool live = j < QE - 1;
+    double (*dr)[2] = sh.dr[JJ & 1];
+    double x[QPR];
+#pragma unroll
+    for (int i = 0; i < QPR; ++i) x[i] = (live && t + QPT * i >= j) ? a[i][JJ] : 0.0;
+    // With v = x - alpha e_j:  v^T a_c = x^T a_c - alpha a_c[j] — so the dot products need nothing of the Householder vector:
+    // slot JJ = x^T x, slots c > JJ = x^T a_c, all in one butterfly; row j's own entries travel beside them.
+    double p[QB];
+#pragma unroll
+    for (int c = 0; c < QB; ++c) {
+        p[c] = 0.0;
+        if (c >= JJ) {
+#pragma unroll
+            for (int i = 0; i < QPR; ++i) p[c] = fma(x[i], c == JJ ? x[i] : a[i][c], p[c]);
+        }
+    }
+    const double q = qr_butterfly16(p, lane);
+    if ((lane & 3) == 0) sh.red[wv * QB + qr_butterfly_slot(lane)] = q;
+#pragma unroll
+    for (int i = 0; i < QPR; ++i)
+        if (t + QPT * i == j) {                                // row j's owner
+#pragma unroll
+            for (int c = JJ; c < QB; ++c) dr[c][1] = a[i][c];
+        }
+    __syncthreads();
+    if (t < QB) {                                              // column t's partials, in a fixed order
+        double s = sh.red[t];
+#pragma unroll
+        for (int w = 1; w < QPT / 64; ++w) s += sh.red[w * QB + t];
+        dr[t][0] = s;
     }
     __syncthreads();
+    const double norm2 = dr[JJ][0];
+    const double xj = live ? dr[JJ][1] : 0.0;
+    const double alpha = xj >= 0.0 ? -sqrt(norm2) : sqrt(norm2);
+    const double vj = xj - alpha;
+    const double vtv = norm2 - xj * xj + vj * vj;
+    const double beta = (live && vtv > 0.0) ? 2.0 / vtv : 0.0;
+    if (t == 0) betas[JJ] = beta;
+    double bv[QPR];
+#pragma unroll
+    for (int i = 0; i < QPR; ++i) {
+        const int r = t + QPT * i;
+        const double v = !live ? 0.0 : (r == j ? vj : (r > j ? x[i] : 0.0));
+        V[(long long)JJ * QE + r] = v;
+        if (live) a[i][JJ] = r == j ? alpha : (r > j ? 0.0 : a[i][JJ]);
+        bv[i] = beta * v;
+    }
+#pragma unroll
+    for (int c = JJ + 1; c < QB; ++c) {
+        const double wc = dr[c][0] - alpha * dr[c][1];
+#pragma unroll
+        for (int i = 0; i < QPR; ++i) a[i][c] -= bv[i] * wc;
+    }
+    if constexpr (JJ + 1 < QB) qr_panel_step<JJ + 1>(a, sh, V, betas, j0);
+}
+
+__global__ void __launch_bounds__(QPT)
+qr_panel_kernel(double* __restrict__ Aall, double* __restrict__ Vall, double* __restrict__ betas, const int j0) {
+    __shared__ QrPanelShared sh;
+    double* A = Aall + (long long)blockIdx.x * QE * QP;
+    double* V = Vall + (long long)blockIdx.x * QB * QE;
+    const int t = threadIdx.x;
+    double a[QPR][QB];
+#pragma unroll
+    for (int c = 0; c < QB; ++c)
+#pragma unroll
+        for (int i = 0; i < QPR; ++i) a[i][c] = (j0 + c < QE) ? A[(long long)(j0 + c) * QE + t + QPT * i] : 0.0;
+    qr_panel_step<0>(a, sh, V, betas + blockIdx.x * QB, j0);
+#pragma unroll
+    for (int c = 0; c < QB; ++c)
+#pragma unroll
+        for (int i = 0; i < QPR; ++i)
+            if (j0 + c < QE) A[(long long)(j0 + c) * QE + t + QPT * i] = a[i][c];
+}
+
+// The panel's QB reflectors applied, in order, to the trailing columns (the first: j0 + QB; c = E: the bias column).  A WAVE owns
+// two columns — lane l holds rows l + 64 i of both in registers — so a reflector's dot products never leave the wave (no barrier,
+// no partials in LDS, the sums by DPP / permlane swaps) and each LDS read of the reflector serves two columns.  Rows above the
+// 64-row block of j0 are not touched (the panel's reflectors are zero there).  8 waves = 16 columns per workgroup — the fp64 FMAs
+// of a reflector are what a CU spends its time on, so the columns are spread over as many CUs as there are; every sum's order is fixed.
+constexpr int QAPPLY_WAVES = 8, QAPPLY_COLS = 2 * QAPPLY_WAVES;
+__global__ void __launch_bounds__(64 * QAPPLY_WAVES)
+qr_apply_kernel(double* __restrict__ Aall, const double* __restrict__ Vall, const double* __restrict__ betas, const int j0) {
+    extern __shared__ double lds_qr[];                         // V panel [QB][QE]
+    double* Vs = lds_qr;
+    double* A = Aall + (long long)blockIdx.y * QE * QP;
+    const double* V = Vall + (long long)blockIdx.y * QB * QE;
+    const int i0 = j0 >> 6;                                    // first 64-row block a reflector of this panel reaches
+    for (int i = i0 * 64 + threadIdx.x; i < QE; i += 64 * QAPPLY_WAVES) {
+#pragma unroll
+        for (int jj = 0; jj < QB; ++jj) Vs[jj * QE + i] = V[jj * QE + i];
+    }
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c0 = j0 + QB + blockIdx.x * QAPPLY_COLS + 2 * wv, c1 = c0 + 1;
+    const bool ok0 = c0 <= QE, ok1 = c1 <= QE;
+    constexpr int NR = QE / 64;
+    double a0[NR], a1[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        a0[i] = (ok0 && i >= i0) ? A[(long long)c0 * QE + lane + 64 * i] : 0.0;
+        a1[i] = (ok1 && i >= i0) ? A[(long long)c1 * QE + lane + 64 * i] : 0.0;
+    }
+    __syncthreads();
+    const bool h2 = lane & 4;
     for (int jj = 0; jj < QB; ++jj) {
         const double beta = betas[blockIdx.y * QB + jj];
-        const double* v = Vs + jj * QE;
-        double w = 0.0;
+        const double* v = Vs + jj * QE + lane;
+        double vr[NR];
+        double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) vr[i] = i >= i0 ? v[64 * i] : 0.0;
+#pragma unroll
+        for (int i = 0; i < NR; i += 2) {
+            w0 = fma(vr[i], a0[i], w0);
+            w1 = fma(vr[i], a1[i], w1);
+            w2 = fma(vr[i + 1], a0[i + 1], w2);
+            w3 = fma(vr[i + 1], a1[i + 1], w3);
+        }
+        // both sums over the wave: halve (lanes < 32 carry column 0, the others column 1), five plain steps, hand both to every lane
+        double s = qr_halve32(w0 + w2, w1 + w3);
+        s = qr_halve16(s, s);
+        s += qr_xor8(s);
+        s += qr_xor4(s, h2);
+        s += qr_xor2(s);
+        s += qr_xor1(s);
+        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(s), (unsigned)__double2loint(s), false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(s), (unsigned)__double2hiint(s), false, false);
+        const double b0 = beta * __hiloint2double((int)hi[0], (int)lo[0]);    // lanes 0..31's total, in every lane
+        const double b1 = beta * __hiloint2double((int)hi[1], (int)lo[1]);
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const int r = rbase + 16 * i;
-            if (r < QE) w = fma(v[r], a[i], w);
+            a0[i] -= b0 * vr[i];
+            a1[i] -= b1 * vr[i];
         }
-        part[rs][cl] = w;
-        __syncthreads();
-        w = 0.0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) w += part[i][cl];         // fixed order: the factor does not depend on the launch geometry
-        w *= beta;
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const int r = rbase + 16 * i;
-            if (r < QE) a[i] -= w * v[r];
-        }
-        __syncthreads();
     }
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-        const int r = rbase + 16 * i;
-        if (ok && r < QE) A[(long long)r * QP + c] = a[i];
+        if (ok0 && i >= i0) A[(long long)c0 * QE + lane + 64 * i] = a0[i];
+        if (ok1 && i >= i0) A[(long long)c1 * QE + lane + 64 * i] = a1[i];
     }
 }
 
-// R (upper triangle, fp16 — the statistics GEMM's weight, zeros below the diagonal) and c~ = the transformed bias column (fp32)
+// R (upper triangle, fp16 — the statistics GEMM's weight, row-major, zeros below the diagonal) out of the column-major factor, through a
+// 32 x 32 LDS tile; c~ = the transformed bias column (fp32).  grid (E/32, E/32), block (32, 8).
 __global__ void __launch_bounds__(256)
 qr_extract_kernel(const double* __restrict__ A, f16_t* __restrict__ r16, float* __restrict__ ctil, int* __restrict__ sat) {
-    const int n = blockIdx.x;
-    for (int k = threadIdx.x; k < QE; k += blockDim.x) {
-        float v = k >= n ? (float)A[(long long)n * QP + k] : 0.f;
+    __shared__ float tile[32][33];
+    const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32, tx = threadIdx.x, ty = threadIdx.y;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + ty + 8 * i, n = n0 + tx;
+        tile[ty + 8 * i][tx] = k >= n ? (float)A[(long long)k * QE + n] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + ty + 8 * i, k = k0 + tx;
+        float v = tile[tx][ty + 8 * i];
         if (!(fabsf(v) <= 65504.f)) { if (sat) atomicAdd(sat, 1); v = fminf(fmaxf(v, -65504.f), 65504.f); }
         r16[(long long)n * QE + k] = (f16_t)v;
     }
-    if (threadIdx.x == 0 && ctil) ctil[n] = (float)A[(long long)n * QP + QE];
+    if (blockIdx.x == 0 && ty == 0 && ctil) ctil[n0 + tx] = (float)A[(long long)QE * QE + n0 + tx];
 }
 
 // P[n][k] (fp32 product W'·W2; P2: the product of the fold's residual, added when given) -> fp16( P[n][k] - c[n] wbar[k] ) = W'·W2c;
@@ -204,7 +319,7 @@ center_product_kernel(const float* __restrict__ P, const float* __restrict__ P2,
 
 size_t pack_qr_scratch_bytes(int nmat) { return (size_t)nmat * ((size_t)QE * QP * 8 + (size_t)QB * QE * 8 + QB * 8) + 256; }
 
-// `A` of matrix m: scratch + m * E * (E + 1) doubles; behind the nmat matrices: the nmat panels of QB Householder vectors, then the betas
+// `At` of matrix m (column-major, E + 1 columns of E): scratch + m * E * (E + 1) doubles; behind the nmat matrices: the nmat panels of QB Householder vectors, then the betas
 static double* qr_mat(void* scratch, int m) { return (double*)scratch + (size_t)m * QE * QP; }
 
 int pack_qr_center_launch(const void* w2_f16, const float* b2, void* scratch, int m, float* wbar, hipStream_t stream) {
@@ -216,25 +331,21 @@ int pack_qr_factor_launch(void* scratch, int nmat, hipStream_t stream) {
     double* A = qr_mat(scratch, 0);
     double* V = A + (size_t)nmat * QE * QP;
     double* betas = V + (size_t)nmat * QB * QE;
-    constexpr int lds = (QB * QE + 16 * 17) * 8, lds_panel = (QB * QE + 16 * QB + 2) * 8;
-    static hipError_t attr_err = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(qr_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(qr_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_panel);
-        return e;
-    }();
+    constexpr int lds = QB * QE * 8;
+    static hipError_t attr_err =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(qr_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr_err != hipSuccess) { set_error("hipFuncSetAttribute(qr kernels, %d): %s", lds, hipGetErrorString(attr_err)); return TP_ERR_LAUNCH; }
     for (int j0 = 0; j0 < QE - 1; j0 += QB) {
-        hipLaunchKernelGGL(qr_panel_kernel, dim3(nmat), dim3(1024), lds_panel, stream, A, V, betas, j0);
+        hipLaunchKernelGGL(qr_panel_kernel, dim3(nmat), dim3(QPT), 0, stream, A, V, betas, j0);
         const int trailing = QE + 1 - (j0 + QB);           // columns j0 + QB .. E (the bias column included)
         if (trailing > 0)
-            hipLaunchKernelGGL(qr_apply_kernel, dim3((trailing + 15) / 16, nmat), dim3(256), lds, stream, A, V, betas, j0);
+            hipLaunchKernelGGL(qr_apply_kernel, dim3((trailing + QAPPLY_COLS - 1) / QAPPLY_COLS, nmat), dim3(64 * QAPPLY_WAVES), lds, stream, A, V, betas, j0);
     }
     return check_launch("qr_apply_kernel");
 }
 
 int pack_qr_extract_launch(const void* scratch, int m, void* r_f16, float* ctil, hipStream_t stream, int* sat) {
-    hipLaunchKernelGGL(qr_extract_kernel, dim3(QE), dim3(256), 0, stream, (const double*)qr_mat((void*)scratch, m), (f16_t*)r_f16, ctil, sat);
+    hipLaunchKernelGGL(qr_extract_kernel, dim3(QE / 32, QE / 32), dim3(32, 8), 0, stream, (const double*)qr_mat((void*)scratch, m), (f16_t*)r_f16, ctil, sat);
     return check_launch("qr_extract_kernel");
 }
 
