@@ -407,10 +407,8 @@ int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stre
         set_error("tp gemm: bad row window [%d, %d) of %d rows", a.m_begin, a.m_end, a.M);
         return TP_ERR_INVALID_ARG;
     }
-    // (TP_TUNE_PAIR_GEMM = 3, A/B: the one-wave-per-SIMD kernel wherever it is built for the launch)
-    if (tuning(TP_TUNE_PAIR_GEMM) == 3 && a.tile == 0 && tuning(TP_TUNE_GEMM_TILE) == 0 && gemm4_supports(in_dtype, out_dtype, a) &&
-        gemm_pick_tile(a.M, a.N, a.tile, a.groups) == 256)
-        return gemm4_launch(in_dtype, out_dtype, a, stream);
+    // (a third main loop — one wave per SIMD, 128 x 128 wave tiles, AGPR accumulators, one barrier per K-tile — was built,
+    // measured 8-22 % slower and removed in round 4: commit 638f1b9, profiles/r04k_solo_gemm_ab.json)
     if (gemm_takes_pair_route(in_dtype, out_dtype, a)) return gemm_pair_launch(in_dtype, out_dtype, a, stream);
     {
         long long head_rows = 0;

@@ -152,9 +152,6 @@ int gemm8_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t str
 // 256x128x64 pair kernel (tp_gemm_pair.hip): two co-resident 4-wave workgroups per CU, epilogues under the other's MFMAs
 bool gemm_pair_supports(int in_dtype, int out_dtype, const GemmArgs& a);
 int gemm_pair_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream);
-// tp_gemm4.hip: the one-wave-per-SIMD 256 x 256 kernel (128 x 128 wave tiles, one statically interleaved stream per SIMD)
-bool gemm4_supports(int in_dtype, int out_dtype, const GemmArgs& a);
-int gemm4_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream);
 long long gemm_pair_launch_count();
 int gemm_pair_occupancy();
 int gemm_pair_workgroups();                            // workgroups of a pair launch (two per CU)
