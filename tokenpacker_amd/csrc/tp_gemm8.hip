@@ -111,7 +111,10 @@ constexpr int G8_DEPTH = 3;                        // DMA groups left in flight 
 //   Both take their epilogue parameters by LDS-DMA (one 1-KiB instruction per wave, issued with the prologue, two buffers)
 //   instead of the register-carried prefetch of the other modes: nothing rides through the epilogue in registers a
 //   compiler-inserted s_waitcnt could trip over, and the count of instructions behind the queries is the same in every wave.
-template <typename TI, typename TO, int AMODE, bool TRAIN_EPI, bool HALF = false, int XMODE = 0>
+// PROBE (TP_TUNE_PAIR_DEBUG >> 4, timing probes of the K loop on fp16 -> fp16 plain launches, tools/loop_probe.py; results are
+// GARBAGE): bit 0 no b0 fragment reads (phase 0) | 1 no b1 reads (phase 1) | 2 no a0 reads (phase 0) | 3 no a1 reads (phase 2) |
+// 4 no DMA in the loop | 6 no MFMAs
+template <typename TI, typename TO, int AMODE, bool TRAIN_EPI, bool HALF = false, int XMODE = 0, int PROBE = 0>
 __global__ void __launch_bounds__(512, 2)
 gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int xcd_swizzle) {
     // (always persistent: the one-tile-per-workgroup form — 1..8 % slower, profiles/README.md — was removed in round 4)
@@ -433,8 +436,10 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         const char* sb = smem + ring_of(t) * KBUF;
         // -- memory segment ---------------------------------------------------------------------------
         const unsigned ring = (unsigned)(size_t)(lds_void*)smem + (unsigned)ring_of(t) * KBUF;   // LDS byte address
-        if constexpr (P == 0 || P == 1) {                           // W fragments of b0 (group 1) / b1 (group 2)
-            constexpr int B = P;
+        // (probe builds skip a read from the tile's second K-tile on: the registers keep the first K-tile's REAL data — zeros would
+        // lower the MFMAs' power draw and raise the clock, and the probe would measure that instead)
+        if ((P == 0 && (!(PROBE & 1) || t == 0)) || (P == 1 && (!(PROBE & 2) || t == 0))) {   // W fragments of b0 (group 1) / b1 (group 2)
+            constexpr int B = P & 1;
             if constexpr (W_KMAJOR) {
                 if constexpr (P == 0) tt_read_w(ring, I1{}, I0{}); else tt_read_w(ring, I2{}, I1{});
             } else {
@@ -442,7 +447,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
                 for (int j = 0; j < 2; ++j) { fb[B][j][0] = read_w(sb, 1 + B, j, 0); fb[B][j][1] = read_w(sb, 1 + B, j, 1); }
             }
         }
-        if constexpr (P == 0 || P == 2) {                           // A fragments of a0 (group 0) / a1 (group 3)
+        if ((P == 0 && (!(PROBE & 4) || t == 0)) || (P == 2 && (!(PROBE & 8) || t == 0))) {   // A fragments of a0 (group 0) / a1 (group 3)
             constexpr int GA = P == 0 ? 0 : 3;
             if constexpr (A_KMAJOR) {
                 if constexpr (P == 0) tt_read_a(ring, I0{}); else tt_read_a(ring, I3{});
@@ -451,7 +456,8 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
                 for (int i = 0; i < 4; ++i) { fa[i][0] = read_a(sb, GA, i, 0); fa[i][1] = read_a(sb, GA, i, 1); }
             }
         }
-        if constexpr (ISSUE && HALF) {
+        if constexpr (ISSUE && (PROBE & 16)) {
+        } else if constexpr (ISSUE && HALF) {
             if constexpr (P == 0) issue(I2{}, t + 1);
             if constexpr (P == 1) { issue(I0{}, t + 2); issue(I1{}, t + 2); }
         } else if constexpr (ISSUE) {
@@ -468,6 +474,12 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         // -- matrix segment ---------------------------------------------------------------------------
         constexpr int a = (P >= 2) ? 1 : 0, b = (P == 1 || P == 2) ? 1 : 0;
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (PROBE & 64) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(fa[i][0]), "v"(fa[i][1]));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(fb[b][j][0]), "v"(fb[b][j][1]));
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -475,6 +487,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[4 * a + i][2 * b + j] = Mma<TI>::run(fb[b][j][ks], fa[i][ks], acc[4 * a + i][2 * b + j]);
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -692,9 +705,20 @@ int gemm8_persistent_cus() {
     return (per_xcd < 1 ? 1 : per_xcd) * 8;
 }
 
-template <typename TI, typename TO, int AMODE, bool TRAIN_EPI, bool HALF = false, int XMODE = 0>
+template <typename TI, typename TO, int AMODE, bool TRAIN_EPI, bool HALF = false, int XMODE = 0, int PROBE = 0>
 static int launch8_cfg(const GemmArgs& a, hipStream_t stream) {
-    auto kern = gemm8_kernel<TI, TO, AMODE, TRAIN_EPI, HALF, XMODE>;
+    if constexpr (PROBE == 0 && AMODE == 0 && !TRAIN_EPI && !HALF && XMODE == 0 && std::is_same<TI, f16_t>::value && std::is_same<TO, f16_t>::value) {
+        const int probe = tuning(TP_TUNE_PAIR_DEBUG) >> 4;
+        if (probe == 1) return launch8_cfg<TI, TO, AMODE, TRAIN_EPI, HALF, XMODE, 1>(a, stream);
+        if (probe == 3) return launch8_cfg<TI, TO, AMODE, TRAIN_EPI, HALF, XMODE, 3>(a, stream);
+        if (probe == 15) return launch8_cfg<TI, TO, AMODE, TRAIN_EPI, HALF, XMODE, 15>(a, stream);
+        if (probe == 16) return launch8_cfg<TI, TO, AMODE, TRAIN_EPI, HALF, XMODE, 16>(a, stream);
+        if (probe == 31) return launch8_cfg<TI, TO, AMODE, TRAIN_EPI, HALF, XMODE, 31>(a, stream);
+        if (probe == 64) return launch8_cfg<TI, TO, AMODE, TRAIN_EPI, HALF, XMODE, 64>(a, stream);
+        if (probe == 79) return launch8_cfg<TI, TO, AMODE, TRAIN_EPI, HALF, XMODE, 79>(a, stream);
+        if (probe == 80) return launch8_cfg<TI, TO, AMODE, TRAIN_EPI, HALF, XMODE, 80>(a, stream);
+    }
+    auto kern = gemm8_kernel<TI, TO, AMODE, TRAIN_EPI, HALF, XMODE, PROBE>;
     constexpr int lds = g8_lds_bytes(HALF, true, XMODE);
     static_assert(lds <= 160 * 1024, "LDS budget of a CU");
     constexpr int TBM = HALF ? G8_BM / 2 : G8_BM;
