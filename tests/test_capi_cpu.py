@@ -181,8 +181,8 @@ def test_workspace_is_schedule_aware_and_an_upper_bound_for_the_tuning_at_call_t
         assert size() - base >= 2 * slab                                                 # + H2, + K | V, + Q1pre, (+ A1)
         _capi.set_tuning(_capi.TP_TUNE_FUSE_KV_LN, 1)
         assert size() == base
-        # absorbed schedule (s = 3): qt | u [2][B M, 8, 1024] instead of K | V, no H2
-        assert size(s=3) < base + 2 * 8 * B * 64 * E * 2
+        # absorbed schedule (s = 3): u (hi | lo fp16 halves) | qt (fp32) = 4 x [B M, 8, 1024] x 2 B instead of K | V, no H2, no logits
+        assert size(s=3) < base + 3 * 8 * B * 64 * E * 2
         # K-split partials: only while the knob is on (the default), only for batches of at most 8 images
         partials = 512 * 128 * 128 * 4
         on = size(b=1)

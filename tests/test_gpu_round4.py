@@ -23,8 +23,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # Round 4 removed three fp16 roundings that sat in series on the value path (the LayerNorm fold inside the pre-multiplied chain
 # weights; on the absorbed schedule `u` and the pre-multiplied V weight, both carried as hi + lo): medians -10 .. -12 %.
 # This test runs TP_PARITY_SEEDS seeds (default 48: ~3 minutes of oracle time) and gates the WORST seed, the p90 and the median.
-GATES = {2: dict(worst=1.0e-3, p90=8.2e-4, median=7.0e-4), 3: dict(worst=1.15e-3, p90=8.6e-4, median=7.4e-4),
-         4: dict(worst=1.15e-3, p90=8.6e-4, median=7.4e-4)}
+# (the absorbed schedule's query side: qt stays fp32 between the per-head query GEMM and the attention kernel — the tail of the
+# s = 3, 4 distributions was on the logit side: worst of the first 64 seeds 9.7e-4 / 1.05e-3 -> 9.0e-4 / 9.1e-4)
+GATES = {2: dict(worst=1.0e-3, p90=8.2e-4, median=7.0e-4), 3: dict(worst=1.0e-3, p90=8.2e-4, median=7.0e-4),
+         4: dict(worst=1.0e-3, p90=8.2e-4, median=7.0e-4)}
 
 
 def test_parity_seed_sweep_gated_on_the_worst_seed():

@@ -110,7 +110,8 @@ WorkspaceLayout workspace_layout(int B, int grid, int s, int D, const SchedulePl
     L.stats_kv = take(2 * (size_t)8 * rows_kv * 2 * 4);     // up to 8 slabs (tile 128) per group
     L.mr_kv = take(2 * rows_kv * 2 * 4);                    // per-row (mean, rstd), 2 groups
     // K | V [2][rows_kv, E] (training, masked / plain schedules); the absorbed schedule keeps qt | u [2][rows_q, 8, E] there
-    L.kv = take_if(P.need_kv, P.absorb ? (P.u_split ? 3 : 2) * 8 * rows_q * E * 2 : 2 * rows_kv * E * 2);   // qt | u (| u's residual)
+    // (u_split: u as hi | lo halves [rows_q, 8, 2 E] fp16 FIRST — what the saturation scan looks at —, then qt in fp32)
+    L.kv = take_if(P.need_kv, P.absorb ? (P.u_split ? 4 : 2) * 8 * rows_q * E * 2 : 2 * rows_kv * E * 2);   // qt | u, or u (hi | lo) | qt (fp32)
     L.q1pre = take_if(P.need_q1pre, rows_q * E * 2);
     L.stats_q = take((size_t)8 * rows_q * 2 * 4);
     L.mr_q = take(rows_q * 2 * 4);
@@ -555,7 +556,7 @@ int tp_debug_count_saturated(const tp_desc* desc, const void* workspace, size_t 
         {W.q0, rows_q * E}, {W.hkv, rows_kv * 2 * E},
         {W.h2, n_if(W.h2, 2 * rows_kv * E)},
         // (the absorbed schedule keeps qt | u [2][rows_q, 8, E] where K | V would be)
-        {W.kv, n_if(W.kv, plan.absorb ? (plan.u_split ? 3 : 2) * rows_q * 8 * E : 2 * rows_kv * E)},
+        {W.kv, n_if(W.kv, plan.absorb ? 2 * rows_q * 8 * E : 2 * rows_kv * E)},      // (u_split: u's two halves; qt is fp32 there)
         {W.q1pre, n_if(W.q1pre, rows_q * E)},
         {W.q, rows_q * E}, {W.o, rows_q * E}, {W.a1, n_if(W.a1, rows_q * E)}, {W.a2, rows_q * (long long)D}};
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * TP_NUM_DEBUG_BUFFERS, stream);
@@ -915,13 +916,16 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     const bool region_major = plan.region_major;
     const bool fuse_attn = plan.fuse_attn;
     char* const kv_slab = slab(W.kv);                                  // K | V, or qt | u on the absorbed schedule (NULL: neither)
-    char* const qt = kv_slab;                                          // [rows_q, 8, E] fp16 (absorbed schedule)
+    // absorbed schedule: qt [rows_q, 8, E] fp16 | u [rows_q, 8, E] fp16;  u_split (the default of s >= 3): u [rows_q, 8, 2 E] = hi | lo
+    // fp16 halves | qt [rows_q, 8, E] in FP32 — neither rounding of the attention's own intermediates survives (round 4: the 128-seed
+    // parity sweep has its tail on the logit side, where Q and qt were rounded one behind the other)
     const bool u_split = plan.u_split;
-    char* const uu = kv_slab ? kv_slab + (size_t)rows_q * 8 * E * 2 : nullptr;   // [rows_q, 8, E] fp16 (u_split: [rows_q, 8, 2 E] = hi | lo)
+    char* const uu = !kv_slab ? nullptr : (u_split ? kv_slab : kv_slab + (size_t)rows_q * 8 * E * 2);
+    char* const qt = !kv_slab ? nullptr : (u_split ? kv_slab + (size_t)rows_q * 8 * 2 * E * 2 : kv_slab);
     auto qt_gemm = [&](hipStream_t st) -> int {         // qt[m, h, :] = Q[m, h*128:(h+1)*128] · W'k[h*128:(h+1)*128, :]
         GemmArgs a = plain_gemm(ws + W.q, E, absorb_raw ? (tri ? pw + P.w_qt_cc : pw + P.w_qt_c) : pw + P.w_qt, qt, 8 * E, rows_q, E, kHeadDim, nullptr, 0);
-        a.groups = kHeads; a.a_gs = kHeadDim * 2; a.w_gs = (long long)E * kHeadDim * 2; a.c_gs = E * 2;
-        return launch(TP_F16, TP_F16, a, st);
+        a.groups = kHeads; a.a_gs = kHeadDim * 2; a.w_gs = (long long)E * kHeadDim * 2; a.c_gs = E * (u_split ? 4 : 2);
+        return launch(TP_F16, u_split ? TP_F32 : TP_F16, a, st);
     };
     if (side) {
         hipError_t e = hipEventRecord(side->fork, stream);

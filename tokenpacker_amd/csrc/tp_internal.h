@@ -20,6 +20,7 @@ using bf16x4 = __bf16 __attribute__((ext_vector_type(4)));
 using f16x8 = _Float16 __attribute__((ext_vector_type(8)));
 using f16x4 = _Float16 __attribute__((ext_vector_type(4)));
 using f32x4 = float __attribute__((ext_vector_type(4)));
+using f32x8_t = float __attribute__((ext_vector_type(8)));
 
 template <typename T> struct Vec;
 template <> struct Vec<bf16_t> { using x8 = bf16x8; using x4 = bf16x4; };

@@ -227,9 +227,10 @@ int region_attention_launch(const void* q, const void* k, const void* v, void* o
 // ([8 heads][B M][2]).  No per-element normalisation on load: two VALU operations less per element and key.
 constexpr int kAbsorbMaxKeys = 64;          // s*s <= 64 (s <= 8): logits of a region live in LDS
 
-template <bool RAW>
+// QT32 (with u_ld = 2 E: the library's own s >= 3 schedule): qt arrives in fp32 — the per-head query GEMM's accumulators, not rounded.
+template <bool RAW, bool QT32 = false>
 __global__ void __launch_bounds__(256)
-region_attention_absorbed_kernel(const f16_t* __restrict__ qt, const f16_t* __restrict__ h2k, const f16_t* __restrict__ h2v,
+region_attention_absorbed_kernel(const void* __restrict__ qt_, const f16_t* __restrict__ h2k, const f16_t* __restrict__ h2v,
                                  const float* __restrict__ mr_k, const float* __restrict__ mr_v, f16_t* __restrict__ u,
                                  int B, int g, int s, float scale, const float* __restrict__ mask, int mask_mode,
                                  int ld, const f16_t* __restrict__ q, const float* __restrict__ d_k,
@@ -271,11 +272,13 @@ region_attention_absorbed_kernel(const f16_t* __restrict__ qt, const f16_t* __re
         }
     };
     {   // ---- phase A: logits ---------------------------------------------------------------------------------
-        f16x8 qa[H], qb[H];
+        using QV = typename std::conditional<QT32, f32x8_t, f16x8>::type;
+        const typename std::conditional<QT32, float, f16_t>::type* qt = (decltype(qt))qt_;
+        QV qa[H], qb[H];
 #pragma unroll
         for (int h = 0; h < H; ++h) {
-            qa[h] = *(const f16x8*)(qt + (qi * H + h) * E + ea);
-            qb[h] = *(const f16x8*)(qt + (qi * H + h) * E + eb);
+            qa[h] = *(const QV*)(qt + (qi * H + h) * E + ea);
+            qb[h] = *(const QV*)(qt + (qi * H + h) * E + eb);
         }
         Row cur = fetch(h2k, mr_k, 0);
         // (RAW: the per-head scalars are computed while qt and the first row are in flight)
@@ -409,12 +412,16 @@ int region_attention_absorbed_launch(const void* qt, const void* h2k, const void
     const int G = grid / s, M = G * G;
     const long long nq = (long long)B * M;
     const unsigned blocks = (unsigned)((nq + 3) / 4);
-    if (q)          // RAW: rows of Hkv, the second K/V layer in the pre-multiplied weights
-        hipLaunchKernelGGL(region_attention_absorbed_kernel<true>, dim3(blocks), dim3(256), 0, stream, (const f16_t*)qt,
+    if (q && u_split)   // RAW, the default of s >= 3: qt in fp32, u as hi | lo halves
+        hipLaunchKernelGGL((region_attention_absorbed_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, qt,
                            (const f16_t*)h2k, (const f16_t*)h2v, mr_k, mr_v, (f16_t*)u, B, grid, s, 0.08838834764831845f, mask,
-                           mask_mode, ld, (const f16_t*)q, d_k, c_k, mr_u, u_split ? 2 * kEmbed : kEmbed);
+                           mask_mode, ld, (const f16_t*)q, d_k, c_k, mr_u, 2 * kEmbed);
+    else if (q)         // RAW: rows of Hkv, the second K/V layer in the pre-multiplied weights
+        hipLaunchKernelGGL(region_attention_absorbed_kernel<true>, dim3(blocks), dim3(256), 0, stream, qt,
+                           (const f16_t*)h2k, (const f16_t*)h2v, mr_k, mr_v, (f16_t*)u, B, grid, s, 0.08838834764831845f, mask,
+                           mask_mode, ld, (const f16_t*)q, d_k, c_k, mr_u, kEmbed);
     else
-        hipLaunchKernelGGL(region_attention_absorbed_kernel<false>, dim3(blocks), dim3(256), 0, stream, (const f16_t*)qt,
+        hipLaunchKernelGGL(region_attention_absorbed_kernel<false>, dim3(blocks), dim3(256), 0, stream, qt,
                            (const f16_t*)h2k, (const f16_t*)h2v, mr_k, mr_v, (f16_t*)u, B, grid, s, 0.08838834764831845f, mask,
                            mask_mode, kEmbed, nullptr, nullptr, nullptr, nullptr, kEmbed);
     return check_launch("region_attention_absorbed_kernel");
