@@ -43,7 +43,7 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
                  denominator of the north_star's ">= 5x" (``hip_over_eager``).  ``vs_baseline`` stays null: BASELINE.md
                  publishes no number for the metric.  (Both baseline legs run AFTER the timed region; they are the only
                  code that reaches into oracle/, through one import site.)
-  sweep        — N=1: scale_factor 3 and 4 at the same batch; the 8-GPU shard (B/8), B=10 and B=1 at this scale factor.
+  sweep        — N=1: scale_factor 3 and 4 at the same batch; the 2 / 4 / 8-GPU shards (B/2, B/4, B/8), B=10 and B=1 at this scale factor.
   timing       — ``long_run``: the same step loop continued in fenced blocks until >= --min-seconds have been measured
                  (mean / p10 / median / p90 ms per step); the K-step region stays the metric.
   multi_gpu    — N>1: ranks and backend as torch.distributed reports them, every rank's device (index, uuid, PCI id,
@@ -261,7 +261,8 @@ def gpu_extras(args, model, x, xm, dtype, device, images_per_s):
     B = x.shape[0]
     with torch.no_grad():
         sweep = {}
-        for b2 in sorted({max(B // 8, 1), 10, 1}, reverse=True):      # the 8-GPU shard, a typical HD crop count, one image
+        # the 2 / 4 / 8-GPU shards of this batch (what a strong-scaling run gives each rank), a typical HD crop count, one image
+        for b2 in sorted({max(B // 2, 1), max(B // 4, 1), max(B // 8, 1), 10, 1}, reverse=True):
             if b2 < B:
                 ms = _time_forward(lambda: model((x[:b2], xm[:b2])), device, 20, 100)
                 sweep[f"s{args.scale_factor}_B{b2}"] = {"ms_per_step": round(ms, 4), "images_per_s": round(b2 / ms * 1e3, 1)}
