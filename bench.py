@@ -200,7 +200,8 @@ def cpu_baseline(seconds: float, s: int, D: int, threads: int):
             el = time.perf_counter() - t0
             if el >= seconds or n >= 400:
                 break
-    return {"value": round(B * n / el, 2), "unit": "images/s", "cores": cores, "kind": "reference-op-sequence",
+    return {"value": round(B * n / el, 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "what": "oracle/reference_ops.py: the reference's own torch op sequence restated (pinned on the reference, tests/golden/)",
             "ms_per_image": round(1e3 * el / (B * n), 3),
             "sample": f"{n} forwards of B={B}, s={s}, D={D}, fp32, the reference's torch op sequence incl. "
                       f"nn.MultiheadAttention on {cores} host threads of {os.cpu_count()} logical cores, {el:.1f} s "

@@ -21,7 +21,8 @@ def main():
     import bench
     d = json.load(open(summary))
     elem = "DF16b" if dtype == "bf16" else "DF16_"
-    keys = [k for k in d if "gemm8_kernel" in k and f"I{elem}DF16_Li1ELb1ELb0ELb0" in k]
+    # gemm8_kernel<T, f16, AMODE 1 (strided A), TRAIN_EPI false, HALF false, XMODE 0, PROBE 0>
+    keys = [k for k in d if "gemm8_kernel" in k and f"I{elem}DF16_Li1ELb0ELb0ELi0ELi0E" in k]
     if len(keys) != 1:
         sys.exit(f"kv_layer0 kernel not found (or ambiguous) in {summary}: {keys}")
     r = d[keys[0]]
