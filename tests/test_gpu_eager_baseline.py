@@ -1,4 +1,4 @@
-"""The reference's op sequence on PyTorch-ROCm eager (tests/eager_port.py): sanity vs the HIP path
+"""The reference's op sequence on PyTorch-ROCm eager (oracle/reference_ops.py): sanity vs the HIP path
 and the timing that BASELINE.json's ">= 5x the reference PyTorch-ROCm projector" is measured
 against.  Writes gpurun_out/eager_rocm.json."""
 import json
@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle import tokenpacker_oracle as orc
-from tests.eager_port import eager_forward
+from oracle.reference_ops import eager_forward
 from tokenpacker_amd import TokenPacker, synth
 
 pytestmark = pytest.mark.gpu
