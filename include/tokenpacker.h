@@ -417,8 +417,9 @@ int tp_test_pack_qr(const void* w2_f16, const float* b2, void* r_f16, float* c_t
  * Everything else in this header is reentrant (state is per call, per thread (error string) or per caller stream (the
  * forked query-side stream; at most 64 distinct caller streams per device get one, later ones run the query side on the
  * caller's stream)). */
-enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail or all half tiles by CU rounds) | 128 | 256 | 2: every tile of the
-                                   ping-pong kernel a 128 x 256 half tile (tests, A/Bs) */
+enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail, all half tiles or all 192-row tiles by CU rounds) | 128 | 256 |
+                                   2: every tile of the ping-pong kernel a 128 x 256 half tile | 3: a 192 x 256 tile (plain launches) |
+                                   4: auto without 192-row tiles (tests, A/Bs; same bits whatever the tile) */
        TP_TUNE_XCD_SWIZZLE = 1, /* 1 (default) | 0 | 2 = A/B: W-half-resident blocking of an XCD's tiles (measured null) */
        TP_TUNE_FOLD_OUT_PROJ = 2, /* out_proj folded into mlp[0] (W = Wm0·Wout, one GEMM less): 0 (default) auto = on the absorbed
                                      schedule and on the scale_factor-2 schedule with attention in the in-projection epilogues

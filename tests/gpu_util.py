@@ -15,10 +15,11 @@ def stream_ptr():
 
 
 def linear(A, W, bias=None, flags=0, tile=0, rows_per_batch=0, a_batch_stride=0, lda=None, M=None,
-           mean_rstd=None, colsum=None, want_stats=False, out_dtype=None, half=False, sync=True):
+           mean_rstd=None, colsum=None, want_stats=False, out_dtype=None, half=False, t192=False, sync=True):
     """C = epilogue(A · W^T) through tp_linear.  A may be a 2-D tensor or a raw (ptr-bearing) tensor
     with explicit M / lda / batch strides.  tile: 0 auto | 128 (the 128-tile kernel, tp_gemm.hip) | 256 (the ping-pong kernel,
-    tp_gemm8.hip); half=True: every tile of the ping-pong kernel a 128 x 256 half tile (TP_TUNE_GEMM_TILE = 2)."""
+    tp_gemm8.hip); half=True: every tile of the ping-pong kernel a 128 x 256 half tile (TP_TUNE_GEMM_TILE = 2); t192=True: 192 x 256
+    tiles (TP_TUNE_GEMM_TILE = 3; plain launches)."""
     lib = _capi.load_library()
     N, K = W.shape
     if M is None:
@@ -46,13 +47,13 @@ def linear(A, W, bias=None, flags=0, tile=0, rows_per_batch=0, a_batch_stride=0,
         assert parts > 0
         stats = torch.full((parts, M, 2), float("nan"), dtype=torch.float32, device=W.device)
         args.row_stats_out = stats.data_ptr()
-    if half:
+    if half or t192:
         args.tile = 0
-        _capi.set_tuning(_capi.TP_TUNE_GEMM_TILE, 2)
+        _capi.set_tuning(_capi.TP_TUNE_GEMM_TILE, 3 if t192 else 2)
     try:
         _capi.check(lib.tp_linear(ctypes.byref(args), stream_ptr()), "tp_linear")
     finally:
-        if half:
+        if half or t192:
             _capi.set_tuning(_capi.TP_TUNE_GEMM_TILE, 0)
     if sync:
         torch.cuda.synchronize()

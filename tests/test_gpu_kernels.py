@@ -150,6 +150,39 @@ def test_pingpong_short_and_odd_k(dtype, K, half):
     assert torch.equal(C32, gu.linear(A, W, out_dtype=torch.float32, tile=128))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(700, 512, 64), (700, 512, 128), (192, 256, 192), (1000, 1024, 320), (18432, 2048, 4096), (4608, 4096, 1024),
+                                   (4609, 512, 1024), (191, 256, 256)])
+def test_pingpong_192_row_tiles(dtype, M, N, K):
+    """192 x 256 tiles (tp_gemm8.hip T192: a short a1 quadrant, one-instruction G3 group, its own counted waits) against the 128-tile
+    kernel, bit for bit: every prologue / tail form (1 .. 64 K-tiles), whole and ragged last tiles, bias + GELU, every output dtype,
+    repeated launches (a mis-counted vmcnt or a wrongly mapped G3 row shows up as a differing tile)."""
+    A = _rand((M, K), dtype, 60 + K)
+    W = _rand((N, K), dtype, 61 + K, K ** -0.5)
+    bias = _rand((N,), torch.float32, 62)
+    for out_dtype in (torch.float16, torch.bfloat16, torch.float32):
+        for flags, b in ((0, None), (_capi.TP_LINEAR_GELU, bias)):
+            ref = gu.linear(A, W, bias=b, flags=flags, out_dtype=out_dtype, tile=128)
+            for rep in range(2):
+                got = gu.linear(A, W, bias=b, flags=flags, out_dtype=out_dtype, t192=True)
+                assert torch.equal(got, ref), gu.describe_mismatch(got, ref, f"192-row tiles {dtype}->{out_dtype} {M}x{N}x{K} flags {flags} rep {rep}", 0.0)
+
+
+def test_pingpong_192_row_tiles_strided_region_major_a():
+    """The first K/V layer's operand form on 192-row tiles: rows in per-image batches with a batch stride (the tower's [:, 1:] slices)."""
+    dtype, B, T, K, N = torch.bfloat16, 32, 576, 4096, 2048
+    full = _rand((B, T + 1, K), dtype, 70)
+    A = full[:, 1:, :]
+    W = _rand((N, K), dtype, 71, K ** -0.5)
+    bias = _rand((N,), torch.float32, 72)
+    kw = dict(bias=bias, flags=_capi.TP_LINEAR_GELU, out_dtype=torch.float16, rows_per_batch=T, a_batch_stride=A.stride(0), lda=A.stride(1), M=B * T)
+    ref = gu.linear(A, W, tile=128, **kw)
+    got = gu.linear(A, W, t192=True, **kw)
+    assert torch.equal(got, ref), gu.describe_mismatch(got, ref, "192-row tiles, strided A", 0.0)
+    auto = gu.linear(A, W, **kw)                       # (the default route of a 32-image shard's first layer)
+    assert torch.equal(auto, ref)
+
+
 @pytest.mark.parametrize("M,N,K,flags", [(36864, 4096, 4096, 0), (147456, 1024, 1024, _capi.TP_LINEAR_ROW_STATS),
                                          (36864, 4096, 1024, _capi.TP_LINEAR_GELU), (20000, 2048, 4096, _capi.TP_LINEAR_GELU)])
 @pytest.mark.parametrize("half", HALVES)

@@ -213,7 +213,7 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
 // ---- host side ------------------------------------------------------------------------------------
 int gemm_pick_tile(int M, int N, int forced, int groups) {
     if (forced == 0) forced = tuning(TP_TUNE_GEMM_TILE);
-    if (forced == 2) forced = 0;                        // (half tiles: gemm_route's business)
+    if (forced == 2 || forced == 3 || forced == 4) forced = 0;      // (half / 192-row tiles and their A/B switch: gemm_route's business)
     if (forced == 128) return 128;
     if (forced == 256 && N % 256 == 0) return 256;
     if (N % 256 != 0) return 128;
@@ -310,9 +310,10 @@ static int launch_types(const GemmArgs& a, hipStream_t stream) {
 // with a half tile at 0.75 of a full tile's time (0.63 at K <= 1024; a one-round tail also pays its first tile's
 // un-hidden DMA latency) and a second launch at ~8 us (dependent-launch gap) relative to a full tile's
 // 8.4 + 1.47 K/64 us (profiles/README.md).  Same epilogue, bit-identical results whatever the shape.
-enum { ROUTE_SMALL = 0, ROUTE_G8 = 1, ROUTE_G8_HALF = 2, ROUTE_G8_SPLIT = 3 };
+enum { ROUTE_SMALL = 0, ROUTE_G8 = 1, ROUTE_G8_HALF = 2, ROUTE_G8_SPLIT = 3, ROUTE_G8_192 = 4 };
 static int gemm_route(const GemmArgs& a, long long* head_rows_out) {
-    const bool free_choice = a.tile == 0 && tuning(TP_TUNE_GEMM_TILE) == 0 &&
+    const int tile_knob = tuning(TP_TUNE_GEMM_TILE);       // 0 auto | 2 all half tiles | 3 all 192-row tiles | 4 auto without 192-row tiles (A/B)
+    const bool free_choice = a.tile == 0 && (tile_knob == 0 || tile_knob == 4) &&
                              a.m_begin == 0 && a.m_end == 0 && !a.half_tiles && !a.A_parts[0] && a.N % 256 == 0 && a.K >= 2 * BK;
     if (free_choice) {
         const int cus = gemm8_persistent_cus(), groups = a.groups > 0 ? a.groups : 1;
@@ -334,10 +335,25 @@ static int gemm_route(const GemmArgs& a, long long* head_rows_out) {
                 const long long tail_half = (long long)((a.M - head_rows + 127) / 128) * tiles_n;
                 if (head_rows < a.M) cost_b = (double)full + half * (double)rounds(tail_half) + launch;
             }
+            // (d) all 192 x 256 tiles (round 4): three quarters of a full tile's MFMA work and stores, but its two 8-MFMA phases do
+            // not cover their partner's memory segments — measured 0.85 of a full tile's time (0.87 at K <= 1024; profiles/
+            // r04t_t192_ab.json).  A 32-image shard's first layer is 2.25 rounds of full tiles and exactly 3 of these, its mlp
+            // launches 1.125 and 1.5.  Plain launches only (no training epilogue, no statistics: the kernel is built for XMODE 0).
+            const bool plain = !(a.flags & (TP_LINEAR_SAVE_PRE | TP_LINEAR_GELU_BWD | TP_LINEAR_NO_STORE | TP_LINEAR_ROW_STATS)) &&
+                               !a.acc_init && !a.attn_mode && !a.stats_parts && !a.tri;
+            const long long T192 = (long long)((a.M + 191) / 192) * tiles_n;
+            const double cost_d = plain ? (a.K <= 1024 ? 0.87 : 0.85) * (double)rounds(T192) : 1e30;
+            const double best_abc = cost_c < cost_a - 0.05 && cost_c <= cost_b && TH >= 64 ? cost_c : (cost_b < cost_a - 0.05 ? cost_b : cost_a);
+            if (tile_knob != 4 && T192 >= 64 && cost_d < best_abc - 0.05) return ROUTE_G8_192;
             if (TH >= 64 && cost_c < cost_a - 0.05 && cost_c <= cost_b) return ROUTE_G8_HALF;
             if (cost_b < cost_a - 0.05) { *head_rows_out = head_rows; return ROUTE_G8_SPLIT; }
         }
     }
+    // TP_TUNE_GEMM_TILE = 3 (tests, A/Bs): every tile of a plain launch a 192 x 256 tile
+    if (tuning(TP_TUNE_GEMM_TILE) == 3 && a.tile == 0 && !a.half_tiles && !a.A_parts[0] && a.N % 256 == 0 && a.m_begin == 0 && a.m_end == 0 &&
+        !(a.flags & (TP_LINEAR_SAVE_PRE | TP_LINEAR_GELU_BWD | TP_LINEAR_NO_STORE | TP_LINEAR_ROW_STATS)) && !a.acc_init && !a.attn_mode &&
+        !a.stats_parts && !a.tri && a.tt_rows == 0)
+        return ROUTE_G8_192;
     // TP_TUNE_GEMM_TILE = 2 (tests, A/Bs): every tile of the ping-pong kernel a 128 x 256 half tile
     if (tuning(TP_TUNE_GEMM_TILE) == 2 && a.tile == 0 && !a.half_tiles && !a.A_parts[0] && a.N % 256 == 0 && a.K >= 2 * BK &&
         a.m_begin == 0 && a.m_end == 0)
@@ -354,7 +370,7 @@ static int gemm_route(const GemmArgs& a, long long* head_rows_out) {
 // a 32 .. 64-image shard (profiles/r04b_pair_ab.json).  TP_TUNE_PAIR_GEMM: 0 that policy | 1 never | 2 wherever supported.
 static bool gemm_takes_pair_route(int in_dtype, int out_dtype, const GemmArgs& a) {
     const int mode = tuning(TP_TUNE_PAIR_GEMM);
-    if (mode == 1 || a.tile != 0 || tuning(TP_TUNE_GEMM_TILE) != 0) return false;
+    if (mode == 1 || a.tile != 0 || (tuning(TP_TUNE_GEMM_TILE) != 0 && tuning(TP_TUNE_GEMM_TILE) != 4)) return false;
     if (!gemm_pair_supports(in_dtype, out_dtype, a)) return false;
     if (mode == 2) return true;
     const long long tiles = (long long)((a.M + 255) / 256) * (a.N / 128) * (a.groups > 0 ? a.groups : 1);
@@ -416,6 +432,10 @@ int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stre
         if (a.stats_parts && route != ROUTE_SMALL) {
             set_error("tp gemm: stats_parts (in-kernel LayerNorm merge) is served by the 128-tile kernel only (see gemm_uses_small_kernel)");
             return TP_ERR_INVALID_ARG;
+        }
+        if (route == ROUTE_G8_192) {
+            GemmArgs h = a; h.tile192 = 1;
+            return gemm8_launch(in_dtype, out_dtype, h, stream);
         }
         if (route == ROUTE_G8_HALF) {
             GemmArgs h = a; h.half_tiles = 1;

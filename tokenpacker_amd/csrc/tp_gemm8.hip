@@ -47,7 +47,10 @@ namespace tp {
 namespace {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N == 0 || N == 2 || N == 4 || N == 6 || N == 8 || N == 11 || N == 12 || N == 13, "unsupported count");
+    static_assert(N == 0 || N == 1 || N == 2 || N == 3 || N == 4 || N == 5 || N == 6 || N == 8 || N == 11 || N == 12 || N == 13, "unsupported count");
+    if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -114,12 +117,19 @@ constexpr int G8_DEPTH = 3;                        // DMA groups left in flight 
 // PROBE (TP_TUNE_PAIR_DEBUG >> 4, timing probes of the K loop on fp16 -> fp16 plain launches, tools/loop_probe.py; results are
 // GARBAGE): bit 0 no b0 fragment reads (phase 0) | 1 no b1 reads (phase 1) | 2 no a0 reads (phase 0) | 3 no a1 reads (phase 2) |
 // 4 no DMA in the loop | 6 no MFMAs
-template <typename TI, typename TO, int AMODE, bool TRAIN_EPI, bool HALF = false, int XMODE = 0, int PROBE = 0>
+// T192 (round 4): 192 x 256 output tiles — the full-tile phase schedule with a SHORT a1 quadrant: wave tile 96 x 64 = four
+// fragment rows in a0 + two in a1, phases (a0,b0) (a0,b1) (a1,b1) (a1,b0) of 16 / 16 / 8 / 8 MFMAs; G3 (the a1 rows of both wave
+// rows) is 64 rows = ONE DMA instruction per wave, so the counted waits that leave the three youngest groups in flight are
+// vmcnt(6 / 5 / 5 / 5) (2+2+2, 1+2+2, 2+1+2, 2+2+1) and the tails 3 / 1.  A 32-image shard's launches are 2.25 (first layer) or
+// 1.125 (mlp) rounds of 256-row tiles and exactly 3 / 1.5 rounds of these (gemm_route).  Plain launches only (XMODE 0).
+template <typename TI, typename TO, int AMODE, bool TRAIN_EPI, bool HALF = false, int XMODE = 0, int PROBE = 0, bool T192 = false>
 __global__ void __launch_bounds__(512, 2)
 gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int xcd_swizzle) {
     // (always persistent: the one-tile-per-workgroup form — 1..8 % slower, profiles/README.md — was removed in round 4)
     using X8 = typename Vec<TI>::x8;
-    constexpr int BM = HALF ? G8_BM / 2 : G8_BM, BN = G8_BN, WM = BM / 2, WN = G8_WN;
+    constexpr int BM = HALF ? G8_BM / 2 : (T192 ? 192 : G8_BM), BN = G8_BN, WM = BM / 2, WN = G8_WN;
+    static_assert(!T192 || (!HALF && XMODE == 0 && AMODE <= 1 && !TRAIN_EPI), "192-row tiles: plain launches, K-contiguous operands");
+    constexpr int FA1 = T192 ? 2 : 4;                   // fragment rows of the a1 quadrant
     constexpr bool A_KMAJOR = (AMODE == 3 || AMODE == 4), W_KMAJOR = (AMODE == 3);
     static_assert(!HALF || !A_KMAJOR, "half tiles: K-contiguous operands");
     constexpr int FM = WM / 16, FN = WN / 16;          // 8 x 4 (HALF: 4 x 4) accumulator fragments per wave
@@ -247,6 +257,10 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
                     voff_a[sub][q] = (int)(krow * p.lda_bytes) + acol * 2;
                 } else {
                     int row = HALF ? m0 + rho : m0 + (rho >> 6) * 128 + sub * 64 + (rho & 63);
+                    if constexpr (T192) {               // wave rows are 96 apart; G3 holds 2 x 32 rows, wave w fills 8 w .. 8 w + 7 (q = 0)
+                        const int r3 = 8 * wave + (lane >> 3);
+                        row = sub == 0 ? m0 + (rho >> 6) * 96 + (rho & 63) : m0 + (r3 >> 5) * 96 + 64 + (r3 & 31);
+                    }
                     row = row < p.M ? row : p.M - 1;
                     // (contiguous rows: a 24-bit multiply on purpose — row strides < 8 MiB, checked on the host.  The plain
                     // form compiles to v_mad_u64_u32 with a don't-care high addend, for which hipcc picked the register a
@@ -318,6 +332,9 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
 #pragma unroll
             for (int q = 0; q < 2; ++q)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst + q * 1024), 16, voff_a[sub][q], so, 0, 0);
+        } else if constexpr (T192 && grp == 3) {        // the short a1 group: one 1-KiB instruction per wave (rows 8 w .. 8 w + 7)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)(smem + ring_of(kt) * KBUF + 3 * G8_GROUP + wave * 1024), 16,
+                                                     voff_a[1][0], soff, 0, 0);
         } else {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -371,6 +388,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
     // ---- fragment read offsets (swizzled; fragment rows are 16-aligned inside a group, so row & 7 == lane & 7)
     const int slot0 = (((lane >> 4)) ^ (lane & 7)) << 4, slot1 = (((4 + (lane >> 4))) ^ (lane & 7)) << 4;
     const int rd_a = (wm * 64 + (lane & 15)) * ROW_BYTES;     // + i * 2048, i = 0..3
+    const int rd_a3 = T192 ? (wm * 32 + (lane & 15)) * ROW_BYTES : rd_a;   // group G3 of a 192-row tile: 32 rows per wave row
     const int rd_w = (wn * 32 + (lane & 15)) * ROW_BYTES;     // + j * 2048, j = 0..1
 
     f32x4 acc[FM][FN];
@@ -420,7 +438,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         fb[B][1][1] = tt_read(wo, std::integral_constant<int, GRP * G8_GROUP + 1 * 128 + 1 * 8192>{});
     };
     auto read_a = [&](const char* sb, const int grp, const int i, const int kh) __attribute__((always_inline)) -> X8 {
-        return *(const X8*)(sb + grp * G8_GROUP + rd_a + i * 2048 + (kh ? slot1 : slot0));
+        return *(const X8*)(sb + grp * G8_GROUP + (grp == 3 ? rd_a3 : rd_a) + i * 2048 + (kh ? slot1 : slot0));
     };
     auto read_w = [&](const char* sb, const int grp, const int j, const int kh) __attribute__((always_inline)) -> X8 {
         return *(const X8*)(sb + grp * G8_GROUP + rd_w + j * 2048 + (kh ? slot1 : slot0));
@@ -453,7 +471,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
                 if constexpr (P == 0) tt_read_a(ring, I0{}); else tt_read_a(ring, I3{});
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { fa[i][0] = read_a(sb, GA, i, 0); fa[i][1] = read_a(sb, GA, i, 1); }
+                for (int i = 0; i < (P == 0 ? 4 : FA1); ++i) { fa[i][0] = read_a(sb, GA, i, 0); fa[i][1] = read_a(sb, GA, i, 1); }
             }
         }
         if constexpr (ISSUE && (PROBE & 16)) {
@@ -483,7 +501,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < (a == 0 ? 4 : FA1); ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[4 * a + i][2 * b + j] = Mma<TI>::run(fb[b][j][ks], fa[i][ks], acc[4 * a + i][2 * b + j]);
@@ -496,8 +514,10 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
     using T_ = std::true_type; using F_ = std::false_type;
     // vmcnt left in flight: steady state 2*DEPTH; the tail counts shrink as fewer groups remain to be issued
     using WS_ = std::integral_constant<int, 2 * G8_DEPTH>;                 // steady
-    using WA_ = std::integral_constant<int, 2 * (G8_DEPTH - 1)>;           // tile nk-2, phase 2
-    using WB_ = std::integral_constant<int, 2 * (G8_DEPTH - 2)>;           // tile nk-2, phase 3
+    using WS1_ = std::integral_constant<int, T192 ? 5 : 2 * G8_DEPTH>;     // steady, phases 1..3 (192-row tiles: G3 is ONE instruction)
+    using WA_ = std::integral_constant<int, T192 ? 3 : 2 * (G8_DEPTH - 1)>;    // tile nk-2, phase 2: G2(nk-1), G3(nk-1) stay in flight
+    using WB_ = std::integral_constant<int, T192 ? 1 : 2 * (G8_DEPTH - 2)>;    // tile nk-2, phase 3: G3(nk-1)
+    static_assert(G8_DEPTH == 3 || !T192, "192-row tiles: wait counts derived for DEPTH = 3");
     using WC_ = std::integral_constant<int, G8_DEPTH == 4 ? 2 : 0>;        // tile nk-1, phase 0
     using WD_ = std::integral_constant<int, G8_DEPTH == 4 ? 0 : -1>;       // tile nk-1, phase 1
     using WN_ = std::integral_constant<int, -1>;
@@ -534,13 +554,13 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         }
         for (; t < nk - 2; ++t) {                           // steady state: every phase issues, 3 groups stay in flight
             phase(I0{}, T_{}, WS_{}, t);
-            phase(I1{}, T_{}, WS_{}, t);
-            phase(I2{}, T_{}, WS_{}, t);
-            phase(I3{}, T_{}, WS_{}, t);
+            phase(I1{}, T_{}, WS1_{}, t);
+            phase(I2{}, T_{}, WS1_{}, t);
+            phase(I3{}, T_{}, WS1_{}, t);
         }
         if (nk >= 2) {                                      // tile nk-2: nothing beyond tile nk-1 to fetch
             phase(I0{}, T_{}, WS_{}, t);
-            phase(I1{}, T_{}, WS_{}, t);
+            phase(I1{}, T_{}, WS1_{}, t);
             phase(I2{}, F_{}, WA_{}, t);
             phase(I3{}, F_{}, WB_{}, t);
             ++t;
@@ -705,7 +725,7 @@ int gemm8_persistent_cus() {
     return (per_xcd < 1 ? 1 : per_xcd) * 8;
 }
 
-template <typename TI, typename TO, int AMODE, bool TRAIN_EPI, bool HALF = false, int XMODE = 0, int PROBE = 0>
+template <typename TI, typename TO, int AMODE, bool TRAIN_EPI, bool HALF = false, int XMODE = 0, int PROBE = 0, bool T192 = false>
 static int launch8_cfg(const GemmArgs& a, hipStream_t stream) {
     if constexpr (PROBE == 0 && AMODE == 0 && !TRAIN_EPI && !HALF && XMODE == 0 && std::is_same<TI, f16_t>::value && std::is_same<TO, f16_t>::value) {
         const int probe = tuning(TP_TUNE_PAIR_DEBUG) >> 4;
@@ -718,10 +738,10 @@ static int launch8_cfg(const GemmArgs& a, hipStream_t stream) {
         if (probe == 79) return launch8_cfg<TI, TO, AMODE, TRAIN_EPI, HALF, XMODE, 79>(a, stream);
         if (probe == 80) return launch8_cfg<TI, TO, AMODE, TRAIN_EPI, HALF, XMODE, 80>(a, stream);
     }
-    auto kern = gemm8_kernel<TI, TO, AMODE, TRAIN_EPI, HALF, XMODE, PROBE>;
+    auto kern = gemm8_kernel<TI, TO, AMODE, TRAIN_EPI, HALF, XMODE, PROBE, T192>;
     constexpr int lds = g8_lds_bytes(HALF, true, XMODE);
     static_assert(lds <= 160 * 1024, "LDS budget of a CU");
-    constexpr int TBM = HALF ? G8_BM / 2 : G8_BM;
+    constexpr int TBM = HALF ? G8_BM / 2 : (T192 ? 192 : G8_BM);
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [&] {
@@ -762,6 +782,14 @@ static int launch8_types(const GemmArgs& a, hipStream_t stream) {
         return TP_ERR_INVALID_ARG;
     }
     const bool half = a.half_tiles != 0;
+    if (a.tile192) {                                    // 192 x 256 tiles: plain launches (gemm_route)
+        if (half || train_epi || (a.flags & TP_LINEAR_NO_STORE) || a.acc_init || a.attn_mode || a.m_begin != 0 || a.m_end != 0) {
+            set_error("tp gemm8: 192-row tiles serve plain launches over all rows only");
+            return TP_ERR_INVALID_ARG;
+        }
+        return strided_a ? launch8_cfg<TI, TO, 1, false, false, 0, 0, true>(a, stream)
+                         : launch8_cfg<TI, TO, 0, false, false, 0, 0, true>(a, stream);
+    }
     if ((a.flags & TP_LINEAR_NO_STORE) || a.acc_init) {       // the two GEMMs of the fused LayerNorm chain
         if constexpr (std::is_same<TI, f16_t>::value && std::is_same<TO, f16_t>::value) {
             if (strided_a || train_epi || ((a.flags & TP_LINEAR_NO_STORE) && a.acc_init) || (half && a.K < 2 * BK)) {

@@ -89,6 +89,7 @@ struct GemmArgs {
     int m_begin, m_end;               // ping-pong kernel: tiles cover rows [m_begin, m_end) (m_end 0: M); row indices, the
                                       // bound M and every per-row array stay those of the whole problem
     int half_tiles;                   // ping-pong kernel: 128 x 256 tiles (tp_gemm8.hip HALF) instead of 256 x 256
+    int tile192;                      // ping-pong kernel: 192 x 256 tiles (tp_gemm8.hip T192; plain launches over all rows)
     int rows_per_batch;
     int a_region_g, a_region_s;       // a_region_s > 0: the M rows are the fine tokens in REGION-MAJOR order (image, region in
                                       // raster order of the (g/s)^2 regions, key a*s + c inside the region): row r of the result
