@@ -397,6 +397,10 @@ long long tp_test_pair_launch_count(void);
 /* ---- test hook: workgroups of the pair kernel the runtime admits per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor;
  * the design needs 2); negative on error */
 int tp_test_pair_occupancy(void);
+/* ---- test hook (host logic only, no GPU needed): where tp_linear would send a plain fp16 launch of this shape under the tuning
+ * of the moment — 0 the 128-tile kernel | 1 full 256 x 256 tiles | 2 all 128 x 256 half tiles | 3 full rounds + a half-tile tail
+ * launch | 4 192 x 256 tiles | 5 the pair kernel; -1: bad shape.  (256 CUs are assumed when no device is visible.) */
+int tp_test_gemm_route(int M, int N, int K, int flags, int groups);
 /* ---- test hook: the pack-time factorisation behind TP_TUNE_TRI_STATS on ONE layer.  w2 [1024][1024] fp16 and b2 [1024] fp32
  * (or NULL) in; r [1024][1024] fp16 (upper triangular), c_tilde [1024] fp32 and wbar [1025] fp32 (column means of w2, then
  * mean(b2)) out, with  sum_n ((w2 h + b2)_n - mean)^2 = || r h + c_tilde ||^2  for every h.  scratch: device memory of
@@ -469,7 +473,9 @@ enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail, all half 
        TP_TUNE_PAIR_STAGGER = 14, /* percent (default 100) of half a tile period by which the second workgroup of each CU starts late in
                                      a pair-kernel launch (0: both start together — their epilogues then coincide for ever) */
        TP_TUNE_PAIR_DEBUG = 15,   /* timing probes of the pair kernel (fp16 -> fp16 plain launches; results are GARBAGE with 1..4): low 3 bits 1 no
-                                     DMA in the K loop | 2 no fragment reads | 3 no barriers | 4 no MFMAs; + 8: one workgroup per CU */
+                                     DMA in the K loop | 2 no fragment reads | 3 no barriers | 4 no MFMAs; + 8: one workgroup per CU;
+                                     bits 4.. (value >> 4): the same kind of probe of the ping-pong kernel's K loop (tools/loop_probe.py:
+                                     1 / 3 / 15 no b0 / W / any fragment reads, 16 no DMA, 31 neither, 64 no MFMAs, 79, 80) */
        TP_TUNE_COUNT_ = 16 };
 int tp_set_tuning(int key, int value);
 int tp_get_tuning(int key);                  /* the library's current value (not a binding's shadow copy); -1: bad key */

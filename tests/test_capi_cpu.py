@@ -252,3 +252,40 @@ def test_tuning_contexts_are_private_copies():
         assert lib.tp_tuning_set(None, 0, 0) == _capi.TP_ERR_INVALID_ARG and lib.tp_tuning_get(None, 0) == -1
     finally:
         a.close(); b.close()
+
+
+def test_gemm_routing_policy_is_host_logic_and_pinned():
+    """Where tp_linear sends a launch is decided on the host by counting CU rounds (tp_gemm.hip: gemm_route / gemm_takes_pair_route);
+    tp_test_gemm_route exposes the decision (256 CUs are assumed without a device).  The B = 256 forward runs full 256 x 256 tiles
+    (its query-side GEMMs the pair kernel); a 32-image shard's first layer and mlp launches take the 192 x 256 tiles that make them
+    whole rounds; one image runs on the 128-tile kernel; statistics-only launches never take the 192-row tiles (not built for them)."""
+    lib = _capi.load_library()
+    G, S, NS = _capi.TP_LINEAR_GELU, _capi.TP_LINEAR_ROW_STATS, _capi.TP_LINEAR_NO_STORE
+    SMALL, FULL, HALF, SPLIT, T192, PAIR = range(6)
+    r = lambda M, N, K, flags=0, groups=1: lib.tp_test_gemm_route(M, N, K, flags, groups)  # noqa: E731
+    assert r(0, 256, 256) == -1 and r(256, 100, 256) == -1
+    # B = 256 (147456 key rows, 36864 query rows)
+    assert r(147456, 2048, 4096, G) == FULL and r(36864, 4096, 4096) == FULL and r(36864, 4096, 1024, G) == FULL
+    assert r(147456, 1024, 1024, S | NS, 2) == FULL
+    assert r(36864, 1024, 1024) == PAIR
+    # the 8-GPU shard: 32 images
+    assert r(18432, 2048, 4096, G) == T192 and r(4608, 4096, 4096) == T192 and r(4608, 4096, 1024, G) == T192
+    assert r(18432, 1024, 1024, S | NS, 2) != T192
+    # one image
+    assert r(576, 2048, 4096, G) == SMALL and r(144, 4096, 4096) == SMALL
+    # the A/B switches
+    _capi.set_tuning(_capi.TP_TUNE_GEMM_TILE, 4)
+    try:
+        assert r(18432, 2048, 4096, G) == SPLIT and r(4608, 4096, 4096) in (SPLIT, HALF)
+    finally:
+        _capi.set_tuning(_capi.TP_TUNE_GEMM_TILE, 0)
+    _capi.set_tuning(_capi.TP_TUNE_PAIR_GEMM, 1)
+    try:
+        assert r(36864, 1024, 1024) != PAIR
+    finally:
+        _capi.set_tuning(_capi.TP_TUNE_PAIR_GEMM, 0)
+    _capi.set_tuning(_capi.TP_TUNE_GEMM_TILE, 3)
+    try:
+        assert r(147456, 2048, 4096, G) == T192 and r(147456, 1024, 1024, S | NS, 2) != T192
+    finally:
+        _capi.set_tuning(_capi.TP_TUNE_GEMM_TILE, 0)

@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = (
     "tp_forward_parts", "tp_forward_train_parts", "tp_backward_parts", "tp_test_occupy_cus", "tp_hd_slice",
     "tp_wgrad", "tp_wgrad_workspace_bytes", "tp_packed_status_offset", "tp_debug_count_saturated",
     "tp_region_attention_absorbed", "tp_forward_masked",
-    "tp_get_tuning", "tp_release_stream", "tp_test_side_cache_size", "tp_test_pair_launch_count", "tp_test_pair_occupancy", "tp_test_pack_qr", "tp_test_pack_qr_scratch_bytes",
+    "tp_get_tuning", "tp_release_stream", "tp_test_side_cache_size", "tp_test_pair_launch_count", "tp_test_pair_occupancy", "tp_test_gemm_route", "tp_test_pack_qr", "tp_test_pack_qr_scratch_bytes",
     "tp_tuning_create", "tp_tuning_destroy", "tp_tuning_set", "tp_tuning_get", "tp_gather_alloc_flags", "tp_gather_free_flags", "tp_gather_export", "tp_gather_open", "tp_gather_close", "tp_gather_push", "tp_gather_sync",
 )
 
@@ -168,6 +168,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.tp_test_pair_launch_count.argtypes = []
     lib.tp_test_pair_occupancy.restype = c_int
     lib.tp_test_pair_occupancy.argtypes = []
+    lib.tp_test_gemm_route.restype = c_int
+    lib.tp_test_gemm_route.argtypes = [c_int, c_int, c_int, c_int, c_int]
     lib.tp_test_pack_qr_scratch_bytes.restype = c_size_t
     lib.tp_test_pack_qr_scratch_bytes.argtypes = []
     lib.tp_test_pack_qr.restype = c_int

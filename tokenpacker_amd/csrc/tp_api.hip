@@ -1149,6 +1149,12 @@ int tp_test_side_cache_size(void) { return side_cache_size(); }
 
 long long tp_test_pair_launch_count(void) { return gemm_pair_launch_count(); }
 int tp_test_pair_occupancy(void) { return gemm_pair_occupancy(); }
+int tp_test_gemm_route(int M, int N, int K, int flags, int groups) {
+    if (M <= 0 || N <= 0 || K <= 0 || N % 128 != 0 || K % BK_ELEMS != 0) { set_error("tp_test_gemm_route: bad shape"); return -1; }
+    GemmArgs a = plain_gemm(nullptr, K, nullptr, nullptr, N, M, N, K, nullptr, flags);
+    a.groups = groups > 0 ? groups : 1;
+    return gemm_route_of(TP_F16, TP_F16, a);
+}
 
 size_t tp_test_pack_qr_scratch_bytes(void) { return pack_qr_scratch_bytes(1); }
 

@@ -378,6 +378,15 @@ static bool gemm_takes_pair_route(int in_dtype, int out_dtype, const GemmArgs& a
     return a.K <= 1024 && tiles * 2 >= 3 * wgs && tiles * 2 < 5 * wgs;
 }
 
+// Where gemm_launch would send a plain K-contiguous launch of this shape under the tuning of the moment (test hook: the routing
+// POLICY is host logic and is pinned by CPU tests): 0 128-tile kernel | 1 full 256 x 256 tiles | 2 all half tiles | 3 full rounds
+// + a half-tile tail launch | 4 192 x 256 tiles | 5 the pair kernel
+int gemm_route_of(int in_dtype, int out_dtype, const GemmArgs& a) {
+    if (gemm_takes_pair_route(in_dtype, out_dtype, a)) return 5;
+    long long h = 0;
+    return gemm_route(a, &h);
+}
+
 bool gemm_uses_small_kernel(const GemmArgs& a) {
     long long h = 0;
     // (the LayerNorm-fold launches that ask are fp16 in / fp16 out)

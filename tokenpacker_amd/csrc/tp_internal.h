@@ -119,6 +119,7 @@ struct GemmArgs {
     int* sat_flag; int sat_bit;
 };
 int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream);
+int gemm_route_of(int in_dtype, int out_dtype, const GemmArgs& a);   // test hook: 0 small | 1 full | 2 half | 3 split | 4 192-row | 5 pair
 bool gemm_uses_small_kernel(const GemmArgs& a);        // whether gemm_launch would run `a` on the 128-tile kernel (tp_gemm.hip)
 
 // LayerNorm statistics of one row from the producing GEMM's NPARTS (mean, M2) slabs of 128 columns each ([NPARTS][M][2];
