@@ -495,6 +495,10 @@ def run_e2e(args, world, rank, device, dtype, dist):
         out["projector_speedup_in_place"] = round(ref_split[1] / split[1], 2) if split[1] > 0 else None
     elif ref_err:
         out["reference_leg"] = {"error": ref_err}
+    if world > 1:
+        out["multi_gpu"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "per_rank_batches": shard.shard_sizes(args.e2e_batch, world),
+                            "collective_self_check": dict(COLLECTIVE_CHECK),
+                            "note": "DDP-style: the only collectives of this line are the start-up self-check and the MAX-reduction of the clock"}
     print(json.dumps(out), flush=True)
 
 
@@ -571,6 +575,52 @@ def run_sdma_leg(args, world) -> None:
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+COLLECTIVE_CHECK = {}
+
+
+def collective_self_check(dist, world: int, rank: int, device, backend: str, timeout_s: float = 60.0) -> dict:
+    """N > 1, BEFORE anything is warmed up or timed: one tiny ``all_gather_into_tensor`` (the very collective of the data path,
+    SURVEY.md §8e) whose result every rank checks element for element, then a MIN-reduced verdict — so that a mis-configured
+    collective library (RCCL transport selection, IPC mode, a rank on the wrong device) ends the run HERE with a message that says
+    so, on every rank together, instead of as a hang or garbage inside the timed region.  Bounded: the wait polls the work handle's
+    completion for ``timeout_s`` and aborts the process group's run with a diagnostic instead of blocking forever."""
+    t0 = time.perf_counter()
+    n = 1024
+    src = torch.arange(n, device=device, dtype=torch.float32) + 1000.0 * (rank + 1)
+    if os.environ.get("TP_BENCH_INJECT_COLLECTIVE_FAULT") and rank == world - 1:
+        src += 1.0                                            # (tests: what a mis-routed / corrupted gather looks like to every rank)
+    dst = torch.zeros(world * n, device=device, dtype=torch.float32)
+    try:
+        work = dist.all_gather_into_tensor(dst, src, async_op=True)
+        deadline = time.perf_counter() + timeout_s
+        while not work.is_completed():
+            if time.perf_counter() > deadline:
+                raise TimeoutError(f"all_gather_into_tensor of {n * 4} bytes per rank did not complete within {timeout_s:.0f} s")
+            time.sleep(0.002)
+        work.wait()
+        torch.cuda.synchronize(device)
+        want = torch.cat([torch.arange(n, device=device, dtype=torch.float32) + 1000.0 * (r + 1) for r in range(world)])
+        ok = bool(torch.equal(dst, want))
+        note = None if ok else f"rank {rank}: gathered values differ from what the ranks sent (first bad index {int((dst != want).nonzero()[0])})"
+    except Exception as exc:     # noqa: every failure mode gets the same message below
+        ok, note = False, f"rank {rank}: {exc!r}"
+    if not ok:
+        # no second collective on a library that just failed one: say what to look at and leave with a distinct exit code
+        env = {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_DEBUG", "RCCL_MSCCL_ENABLE", "HSA_ENABLE_IPC_MODE_LEGACY",
+                                              "HSA_ENABLE_SDMA", "MASTER_ADDR", "MASTER_PORT") if os.environ.get(k) is not None}
+        sys.stderr.write(f"bench.py: the collective self-check FAILED before the warm-up ({backend}, world {world}): {note}\n"
+                         f"  device {device} = {torch.cuda.get_device_name(device)}; env {env}\n"
+                         f"  (HSA_ENABLE_IPC_MODE_LEGACY=0 is required on this pool; rerun with NCCL_DEBUG=INFO for the transport RCCL chose; "
+                         f"--backend gloo --single-device runs the same code path without RCCL)\n")
+        sys.stderr.flush()
+        os._exit(17)
+    verdict = torch.ones(1, device=device, dtype=torch.float32)
+    dist.all_reduce(verdict, op=dist.ReduceOp.MIN)           # (a second, different collective: reductions work as well)
+    torch.cuda.synchronize(device)
+    return {"all_gather_into_tensor": "ok", "bytes_per_rank": n * 4, "all_reduce_min": float(verdict.item()),
+            "seconds": round(time.perf_counter() - t0, 3), "when": "before the warm-up"}
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -594,6 +644,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        COLLECTIVE_CHECK.update(collective_self_check(dist, world, rank, device, args.backend))
 
     from tokenpacker_amd import _capi, hd, shard
 
@@ -897,6 +948,7 @@ def main():
                                 "pipelined": bool((chosen == "rccl" and pipe is not None) or (chosen == "sdma" and not args.sync_gather)),
                                 "gather_bytes_received_per_rank": int((total - B) * M * D * 2),
                                 "ranks": dist.get_world_size(), "backend": dist.get_backend(), "rank_devices": rank_info,
+                                "collective_self_check": dict(COLLECTIVE_CHECK),
                                 "env": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS",
                                                                         "RCCL_MSCCL_ENABLE", "HSA_ENABLE_IPC_MODE_LEGACY", "HSA_ENABLE_SDMA")
                                         if os.environ.get(k) is not None}}

@@ -19,11 +19,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(extra, nproc=2):
+def _run(extra, nproc=2, env=None, expect_rc=0):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1",
            "--backend", "gloo", "--single-device", "--no-cpu-baseline"] + extra
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, **(env or {})))
+    if expect_rc != 0:
+        assert res.returncode != 0, res.stdout[-2000:]
+        return res
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
@@ -44,6 +47,8 @@ def test_two_rank_bench_line(extra):
         mg = d["multi_gpu"]
         assert mg["forward_only_ms"] > 0 and mg["gather_only_ms"] > 0
         assert mg["gather_bytes_received_per_rank"] == 4 * 144 * 4096 * 2
+        # the start-up self-check ran (one tiny all_gather_into_tensor compared on every rank, before the warm-up)
+        assert mg["collective_self_check"]["all_gather_into_tensor"] == "ok" and mg["collective_self_check"]["all_reduce_min"] == 1.0
 
 
 def test_two_rank_weak_scaling_line():
@@ -79,3 +84,22 @@ def test_e2e_line_single_rank():
     assert d["unit"] == "tokens/s" and d["value"] > 0 and d["split_ms"]["projector_hip"] > 0
     # BASELINE configs[4] is quoted "vs reference": the same run with the reference's projector, after the timed region
     assert d["reference_leg"]["value"] > 0 and d["vs_reference"] > 0 and d["projector_speedup_in_place"] > 0
+
+
+def test_e2e_line_two_ranks_ragged():
+    """BASELINE configs[4] is a DDP run: `--e2e` with MORE than one rank (3 samples over 2 ranks: 2 + 1), the reference leg
+    included — the multi-rank branch of run_e2e (shard bounds, per-rank seeds, MAX-reduced clocks of both legs, rank-0 line)
+    had never executed anywhere."""
+    d = _run(["--e2e", "--e2e-batch", "3", "--e2e-layers", "2"])
+    assert d["unit"] == "tokens/s" and d["n_gpus"] == 2 and d["value"] > 0
+    assert d["config"]["global_batch"] == 3 and d["config"]["per_gpu_batch"] == 2
+    assert d["multi_gpu"]["per_rank_batches"] == [2, 1] and d["multi_gpu"]["collective_self_check"]["all_gather_into_tensor"] == "ok"
+    assert d["reference_leg"]["value"] > 0 and d["vs_reference"] > 0
+
+
+def test_collective_self_check_fails_fast_with_a_message():
+    """A gather that delivers something else than the ranks sent (here: injected on the last rank) ends the run BEFORE the warm-up, on
+    every rank, with a message that names the collective — not as garbage or a hang inside the timed region."""
+    res = _run(["--batch", "4", "--no-extras"], env={"TP_BENCH_INJECT_COLLECTIVE_FAULT": "1"}, expect_rc=17)
+    assert "collective self-check FAILED before the warm-up" in res.stderr
+    assert not [l for l in res.stdout.splitlines() if l.startswith("{")]

@@ -31,7 +31,14 @@ def _legal_tunings(s):
     keys = (_capi.TP_TUNE_FUSE_KV_LN, _capi.TP_TUNE_FUSE_ATTN, _capi.TP_TUNE_ABSORB_KV, _capi.TP_TUNE_FOLD_OUT_PROJ,
             _capi.TP_TUNE_Q_SIDE_STREAM, _capi.TP_TUNE_LN_MERGE, _capi.TP_TUNE_TRI_STATS)
     ranges = ((0, 1), (0, 1, 2) if s == 2 else (0,), (0, 1, 2), (0, 1, 2), (0, 1), (0, 1), (0, 1))
-    for combo in itertools.product(*ranges):
+    combos = list(itertools.product(*ranges))
+    # Round 5: the full enumeration (1584 forwards over the five parametrisations) runs with TP_ALL_SCHEDULES=1 (tools/gpu_round.sh
+    # `schedules`); the default collection takes a deterministic sample that still covers every VALUE of every knob and every PAIR of
+    # values of any two knobs at least once (stride 5 is coprime to every range length, so the mixed-radix digits decorrelate; the
+    # all-defaults-off and all-max corners are always included).
+    if os.environ.get("TP_ALL_SCHEDULES", "0") != "1":
+        combos = sorted(set(combos[::5] + [combos[0], combos[-1]]))
+    for combo in combos:
         yield dict(zip(keys, combo))
 
 

@@ -251,7 +251,12 @@ TP_WORKSPACE_STATUS_BYTES = 256
 def make_desc(batch: int, raw_grid: int, scale_factor: int, hidden_size: int, dtype: int,
               out_dtype: int | None = None, ln_eps: float = 1e-6, flags: int = 0, tuning=None) -> tp_desc:
     """`tuning`: a TuningContext (or its raw handle) the call reads its knobs from; None = the process-wide table."""
-    handle = getattr(tuning, "handle", tuning)
+    handle = tuning
+    if isinstance(tuning, TuningContext):
+        handle = tuning.handle
+        if not handle:
+            # a closed context must not silently fall back to the process-wide table (ADVICE r4): the caller asked for ITS knobs
+            raise ValueError("make_desc: the TuningContext has been closed")
     return tp_desc(batch, raw_grid, scale_factor, hidden_size, dtype,
                    dtype if out_dtype is None else out_dtype, ln_eps, flags, handle)
 
@@ -259,7 +264,11 @@ def make_desc(batch: int, raw_grid: int, scale_factor: int, hidden_size: int, dt
 class TuningContext:
     """A private copy of the library's tuning table (``tp_tuning_create``).  Calls whose descriptor names it read their knobs
     from it and from nothing else: another thread's ``set_tuning`` (the process-wide table) or another context cannot change
-    the schedule or the low bits of a forward that runs on this one (include/tokenpacker.h, "tuning knobs")."""
+    the schedule or the low bits of a forward that runs on this one (include/tokenpacker.h, "tuning knobs").
+
+    Threading contract: ``set`` writes a plain int array that in-flight calls read without a lock — mutate a context only while
+    no call that names it is being ENQUEUED on another thread (a forward reads its knobs while it is enqueued, not while its
+    kernels run); give each serving thread its own context instead of sharing one that is being tuned."""
 
     def __init__(self, **knobs):
         self.handle = load_library().tp_tuning_create()

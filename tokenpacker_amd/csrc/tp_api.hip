@@ -233,11 +233,12 @@ void pack_registry_put(const void* packed, const tp_desc* d, bool train_pack) {
     g_pack_reg.push_back(PackRec{dev, packed, train_pack ? 1 : 0, d->hidden_size, d->dtype, ++g_pack_clock});
 }
 void pack_registry_forget(const void* packed) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return;
+    // Matched on the POINTER alone (device pointers are unique in the process's unified address space): the caller is typically a
+    // finalizer that runs wherever the tensor happens to die — the autograd thread, another device current — and a device test here
+    // would silently leave the stale record behind.
     std::lock_guard<std::mutex> lock(g_pack_mu);
-    for (size_t i = 0; i < g_pack_reg.size(); ++i)
-        if (g_pack_reg[i].dev == dev && g_pack_reg[i].ptr == packed) { g_pack_reg.erase(g_pack_reg.begin() + (long)i); return; }
+    for (size_t i = 0; i < g_pack_reg.size();)
+        if (g_pack_reg[i].ptr == packed) g_pack_reg.erase(g_pack_reg.begin() + (long)i); else ++i;
 }
 int pack_registry_check(const void* packed, const tp_desc* d, bool train) {
     int dev = 0;

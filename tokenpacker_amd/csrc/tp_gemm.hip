@@ -240,12 +240,8 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     constexpr int lds = gemm_lds_bytes<BM, BN, NST>();
     constexpr int threads = (BM / WM) * (BN / WN) * 64;
     auto kern = gemm_kernel<TI, TO, BM, BN, WM, WN, AMODE, TRAIN_EPI, XMODE, NST>;
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    });
+    static DynLdsAttr attr;                             // (per device, a failure is not cached: tp_internal.h)
+    const hipError_t attr_err = attr.ensure(reinterpret_cast<const void*>(kern), lds);
     if (attr_err != hipSuccess) {
         set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", lds, hipGetErrorString(attr_err));
         return TP_ERR_LAUNCH;
@@ -340,7 +336,7 @@ static int gemm_route(const GemmArgs& a, long long* head_rows_out) {
             // r04t_t192_ab.json).  A 32-image shard's first layer is 2.25 rounds of full tiles and exactly 3 of these, its mlp
             // launches 1.125 and 1.5.  Plain launches only (no training epilogue, no statistics: the kernel is built for XMODE 0).
             const bool plain = !(a.flags & (TP_LINEAR_SAVE_PRE | TP_LINEAR_GELU_BWD | TP_LINEAR_NO_STORE | TP_LINEAR_ROW_STATS)) &&
-                               !a.acc_init && !a.attn_mode && !a.stats_parts && !a.tri;
+                               !a.acc_init && !a.attn_mode && !a.stats_parts && !a.tri && a.tt_rows == 0;   // (K-major launches: never)
             const long long T192 = (long long)((a.M + 191) / 192) * tiles_n;
             const double cost_d = plain ? (a.K <= 1024 ? 0.87 : 0.85) * (double)rounds(T192) : 1e30;
             const double best_abc = cost_c < cost_a - 0.05 && cost_c <= cost_b && TH >= 64 ? cost_c : (cost_b < cost_a - 0.05 ? cost_b : cost_a);

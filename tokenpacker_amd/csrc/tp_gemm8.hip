@@ -742,12 +742,8 @@ static int launch8_cfg(const GemmArgs& a, hipStream_t stream) {
     constexpr int lds = g8_lds_bytes(HALF, true, XMODE);
     static_assert(lds <= 160 * 1024, "LDS budget of a CU");
     constexpr int TBM = HALF ? G8_BM / 2 : (T192 ? 192 : G8_BM);
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    });
+    static DynLdsAttr attr;                             // (per device, a failure is not cached: tp_internal.h)
+    const hipError_t attr_err = attr.ensure(reinterpret_cast<const void*>(kern), lds);
     if (attr_err != hipSuccess) {
         set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", lds, hipGetErrorString(attr_err));
         return TP_ERR_LAUNCH;
@@ -768,6 +764,7 @@ static int launch8_types(const GemmArgs& a, hipStream_t stream) {
     constexpr bool HALF_OUT = !std::is_same<TO, float>::value;
     const bool train_epi = (a.flags & (TP_LINEAR_SAVE_PRE | TP_LINEAR_GELU_BWD)) != 0;
     if (a.tt_rows > 0) {                                // K-major operands (weight gradients): fp32 partials only
+        if (a.tile192) { set_error("tp gemm8: 192-row tiles do not take K-major operands"); return TP_ERR_INVALID_ARG; }
         if constexpr (std::is_same<TO, float>::value)
             return a.tt_w_kcontig ? launch8_cfg<TI, TO, 4, false>(a, stream) : launch8_cfg<TI, TO, 3, false>(a, stream);
         set_error("tp gemm8: K-major operands are supported with fp32 output only");

@@ -494,11 +494,8 @@ static int launch_pair_cfg(const GemmArgs& a, hipStream_t stream) {
     }
     auto kern = gemm_pair_kernel<TI, TO, AMODE, XMODE, DBG>;
     constexpr int lds = GP_LDS_BYTES;
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    });
+    static DynLdsAttr attr;                             // (per device, a failure is not cached: tp_internal.h)
+    const hipError_t attr_err = attr.ensure(reinterpret_cast<const void*>(kern), lds);
     if (attr_err != hipSuccess) {
         set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", lds, hipGetErrorString(attr_err));
         return TP_ERR_LAUNCH;

@@ -30,6 +30,25 @@ template <> struct Vec<f16_t> { using x8 = f16x8; using x4 = f16x4; };
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);      // hipGetLastError -> TP_ERR_LAUNCH
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: a process that drives several GPUs must set it on
+// each of them, and a transient failure must not be remembered (a function-local `static` / std::call_once set it on the
+// first device only and cached a first failure for the life of the process).  One of these per kernel instantiation, as a function-local
+// static: a bit per device ordinal (0 .. 127; beyond that the attribute is simply set before every launch — the call is cheap), set only
+// after the runtime accepted the attribute there.  Two threads racing on a fresh device both set it — harmless.
+struct DynLdsAttr {
+    unsigned long long done[2] = {0ull, 0ull};
+    hipError_t ensure(const void* kern, int lds_bytes) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+        const bool tracked = dev >= 0 && dev < 128;
+        const unsigned long long bit = tracked ? 1ull << (dev & 63) : 0ull;
+        if (tracked && (__atomic_load_n(&done[dev >> 6], __ATOMIC_ACQUIRE) & bit)) return hipSuccess;
+        const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e == hipSuccess && tracked) __atomic_fetch_or(&done[dev >> 6], bit, __ATOMIC_RELEASE);
+        return e;
+    }
+};
+
 // ---- tuning: the context of the call in progress on this thread, else the process-wide table (tp_api.hip) ----------------
 int tuning(int key);
 // Opened by every entry point that takes a tp_desc: tuning() reads desc->tuning (NULL: the process-wide table) until it closes.

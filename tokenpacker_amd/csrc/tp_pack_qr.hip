@@ -332,8 +332,8 @@ int pack_qr_factor_launch(void* scratch, int nmat, hipStream_t stream) {
     double* V = A + (size_t)nmat * QE * QP;
     double* betas = V + (size_t)nmat * QB * QE;
     constexpr int lds = QB * QE * 8;
-    static hipError_t attr_err =
-        hipFuncSetAttribute(reinterpret_cast<const void*>(qr_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    static DynLdsAttr attr;                             // (per device, a failure is not cached: tp_internal.h)
+    const hipError_t attr_err = attr.ensure(reinterpret_cast<const void*>(qr_apply_kernel), lds);
     if (attr_err != hipSuccess) { set_error("hipFuncSetAttribute(qr kernels, %d): %s", lds, hipGetErrorString(attr_err)); return TP_ERR_LAUNCH; }
     for (int j0 = 0; j0 < QE - 1; j0 += QB) {
         hipLaunchKernelGGL(qr_panel_kernel, dim3(nmat), dim3(QPT), 0, stream, A, V, betas, j0);

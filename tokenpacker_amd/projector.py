@@ -200,7 +200,7 @@ class TokenPacker(nn.Module):
         packed = torch.empty(nbytes, dtype=torch.uint8, device=device)
         # the library keeps a host-side note per image ADDRESS; when this tensor dies its address goes back to the caching
         # allocator, so the note goes too (tp_pack_forget) — a later tensor at the same address is not judged by it
-        weakref.finalize(packed, _forget_packed, packed.data_ptr())
+        weakref.finalize(packed, _forget_packed, packed.data_ptr()).atexit = False    # (never during interpreter teardown)
         # fp32 master weights (autocast / fp32_compute_dtype) are rounded to the compute dtype here, like autocast does
         contiguous = [w.detach().to(dtype).contiguous() for w in weights]      # keeps temporaries alive until enqueued
         raw = _capi.tp_weights(*[t.data_ptr() for t in contiguous])

@@ -210,8 +210,10 @@ class DirectGather:
             raise ValueError("DirectGather needs depth >= 2 (a buffer is being filled while the previous one is read)")
         if depth > 6:
             # the sequence numbers travel through an 8-slot cell ring (cell seq % 8): a peer stream's 4-byte flag copy of step i may
-            # still be pending `depth` steps later, and with depth >= 8 its cell would hold step i + 8 by then
-            raise ValueError("DirectGather: depth <= 6 (the sequence cells are an 8-slot ring)")
+            # still be pending `depth` steps later; the cell of step i is re-written by step i + 8, so depth 8 is where a pending
+            # copy would collide — depth 7 is the last that cannot, and the bound is kept one further below that (<= 6) as margin
+            # for the poll of step i - 1 that a rank performs while its own step i + depth - 1 copies are already queued
+            raise ValueError("DirectGather: depth <= 6 (the sequence cells are an 8-slot ring; 8 collides, 7 has no margin)")
         self._capi, self._ct = _capi, ctypes
         self.lib = _capi.load_library()
         self.group, self.depth, self.use_cus, self.timeout_ms = group, depth, int(bool(use_cus)), int(timeout_ms)
