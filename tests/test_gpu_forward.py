@@ -538,6 +538,21 @@ def test_full_size_properties_B256_absorbed_schedule(s):
         from tests.gpu_util import batch_invariant
         with batch_invariant():                          # (a batch of 4 may split mlp[2] over K by default; B = 256 never does)
             y4 = m((x4.cuda(), xm4.cuda()))
+        # round 5: at this size the per-head V GEMM (K = 3 E over u's hi | lo halves) runs on the pair kernel with a cyclic A
+        # operand (GemmArgs::a_k_wrap); with the pair kernel switched off it is the A_parts form on the 128-tile kernel — same bits
+        from tokenpacker_amd import _capi
+        lib = _capi.load_library()
+        n0 = lib.tp_test_pair_launch_count()
+        m((x, xm))
+        pair_launches = lib.tp_test_pair_launch_count() - n0
+        _capi.set_tuning(_capi.TP_TUNE_PAIR_GEMM, 1)
+        try:
+            n1 = lib.tp_test_pair_launch_count()
+            y_nopair = m((x, xm))
+            assert lib.tp_test_pair_launch_count() == n1
+        finally:
+            _capi.set_tuning(_capi.TP_TUNE_PAIR_GEMM, 0)
+        assert pair_launches >= 1 and torch.equal(y_nopair, y)
     torch.cuda.synchronize()
     M = (24 // s) ** 2
     assert y.shape == (B, M, D) and torch.isfinite(y.float()).all() and torch.equal(y, y_again)

@@ -28,7 +28,9 @@ DEBUG_BUFFER_NAMES = ("q0", "Hkv", "H2", "KV", "Q1pre", "Q", "O", "A1", "A2")
 STAGE_NAMES = ("point_queries", "kv_layer0_gelu", "kv_layer2_stats", "kv_inproj_lnfold", "q_proj_1_stats",
                "q_inproj_lnfold", "region_attention", "out_proj", "mlp0_gelu", "mlp2")
 
-LIB_NAME = "libtokenpacker_hip.so"
+# (TP_LIB_VARIANT=<name>: an A/B build of the same sources made by `make -C tokenpacker_amd/csrc variant NAME=<name> DEFS=...` —
+# bench.py / the tools under one build or the other on the same box; unset: the product library)
+LIB_NAME = f"libtokenpacker_{os.environ['TP_LIB_VARIANT']}.so" if os.environ.get("TP_LIB_VARIANT") else "libtokenpacker_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 # every symbol include/tokenpacker.h declares

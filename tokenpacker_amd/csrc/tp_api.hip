@@ -1063,7 +1063,13 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
                                                      : (absorb_raw ? (tri ? pw + P.w_cc_kv : pw + P.w_c_kv) : pw + P.w_in_kv) + (size_t)E * E * 2,
                                 ws + W.o, E, rows_q, kHeadDim, uK, (const float*)(pw + P.b_in_kv) + E, absorb_raw ? TP_LINEAR_LN_FOLD : 0);
         a.groups = kHeads; a.a_gs = uld * 2; a.w_gs = (long long)kHeadDim * uK * 2; a.c_gs = kHeadDim * 2; a.bias_gs = kHeadDim;
-        if (u_split) { a.A_parts[0] = uu; a.A_parts[1] = uu + (size_t)E * 2; a.A_parts[2] = uu; a.A_parts[3] = uu; a.k_part = E; }
+        // Round 5: on the 128-tile kernel this K = 3 E contraction ran at 0.47 PFLOP/s (221 us at B = 256, s = 3: a third of the
+        // round-4 s = 3 / 4 regression).  The pair kernel's 256 x 128 tile fits N = 128 per head: its A operand is the
+        // stored [hi | lo] row read cyclically (GemmArgs::a_k_wrap = 2 E: K-tiles 32 .. 47 re-read hi) — same K order, same epilogue, same
+        // bits as the A_parts form, which stays for launches of less than half a round of pair tiles and for TP_TUNE_PAIR_GEMM = 1.
+        const long long pair_tiles = (long long)((rows_q + 255) / 256) * kHeads;
+        if (u_split && tuning(TP_TUNE_PAIR_GEMM) != 1 && pair_tiles * 2 >= gemm_pair_workgroups()) a.a_k_wrap = 2 * E;
+        else if (u_split) { a.A_parts[0] = uu; a.A_parts[1] = uu + (size_t)E * 2; a.A_parts[2] = uu; a.A_parts[3] = uu; a.k_part = E; }
         if (absorb_raw) {
             a.acc_init = (const float*)(tri ? pw + P.d_cc_kv : pw + P.d_in_kv) + E; a.acc_init_gs = kHeadDim;
             a.colsum = (const float*)(pw + P.c_in_kv) + E; a.colsum_gs = kHeadDim;

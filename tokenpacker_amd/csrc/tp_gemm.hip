@@ -366,6 +366,7 @@ static int gemm_route(const GemmArgs& a, long long* head_rows_out) {
 // a 32 .. 64-image shard (profiles/r04b_pair_ab.json).  TP_TUNE_PAIR_GEMM: 0 that policy | 1 never | 2 wherever supported.
 static bool gemm_takes_pair_route(int in_dtype, int out_dtype, const GemmArgs& a) {
     const int mode = tuning(TP_TUNE_PAIR_GEMM);
+    if (a.a_k_wrap) return gemm_pair_supports(in_dtype, out_dtype, a);      // (only the pair kernel wraps A's K index; the caller chose)
     if (mode == 1 || a.tile != 0 || (tuning(TP_TUNE_GEMM_TILE) != 0 && tuning(TP_TUNE_GEMM_TILE) != 4)) return false;
     if (!gemm_pair_supports(in_dtype, out_dtype, a)) return false;
     if (mode == 2) return true;
@@ -431,6 +432,7 @@ int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stre
     // (a third main loop — one wave per SIMD, 128 x 128 wave tiles, AGPR accumulators, one barrier per K-tile — was built,
     // measured 8-22 % slower and removed in round 4: commit 638f1b9, profiles/r04k_solo_gemm_ab.json)
     if (gemm_takes_pair_route(in_dtype, out_dtype, a)) return gemm_pair_launch(in_dtype, out_dtype, a, stream);
+    if (a.a_k_wrap) { set_error("tp gemm: a_k_wrap is served by the pair kernel only, which does not take this launch"); return TP_ERR_INVALID_ARG; }
     {
         long long head_rows = 0;
         const int route = gemm_route(a, &head_rows);

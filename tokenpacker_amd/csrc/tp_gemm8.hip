@@ -47,7 +47,8 @@ namespace tp {
 namespace {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N == 0 || N == 1 || N == 2 || N == 3 || N == 4 || N == 5 || N == 6 || N == 8 || N == 11 || N == 12 || N == 13, "unsupported count");
+    static_assert(N == 0 || N == 1 || N == 2 || N == 3 || N == 4 || N == 5 || N == 6 || N == 8 || N == 10 || N == 11 || N == 12 || N == 13, "unsupported count");
+    if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
@@ -77,8 +78,36 @@ constexpr int g8_lds_bytes(bool half, bool persist, int xmode) {
     return half ? 9 * 16384 + g8_par_bytes(true, xmode) + g8_red_bytes(true, xmode) + 256
                 : (persist ? 8 * 16384 + g8_par_bytes(false, xmode) + g8_red_bytes(false, xmode) + 256 : 8 * 16384);
 }
-constexpr int G8_DEPTH = 3;                        // DMA groups left in flight by the in-loop wait (3 or 4 are legal;
+#ifndef TP_G8_DEPTH
+#define TP_G8_DEPTH 3
+#endif
+constexpr int G8_DEPTH = TP_G8_DEPTH;              // schedule 1: DMA groups left in flight by the in-loop wait (3 or 4 are legal;
                                                    // 4 = the latest legal wait placement measured no faster: r01u)
+// Schedule 2 (round 5; full 256-row tiles — HALF and T192 keep schedule 1) — BUILT, BIT-IDENTICAL, MEASURED SLOWER, NOT THE DEFAULT
+// (profiles/r05b_lib_ab_s2_vs_s1.json, two builds dlopen'ed side by side, arms interleaved: kv_layer0 +1.2 %, mlp2 +1.1 %, mlp0 +2.7 %,
+// K = 1024 plain +2.7 %; whole forward 4.222 -> 4.256 ms; schedule 1 with DEPTH = 4: +-0, r05b_lib_ab_s1d4_vs_s1.json).  More operand
+// bytes in flight and a lighter phase 0 do not help: the operand fetch is not latency-bound, and four DMA
+// instructions back to back in one memory segment stall their wave at issue longer than two here and two there.  Kept behind
+// -DTP_G8_SCHED=2 (`make variant`) as the A/B partner.  The round-4 probes (profiles/r04m_loop_probe.json) put the
+// loop's two memory-side costs in the memory segment the partner wave's 16 MFMAs (256 cycles) must cover: phase 0 carries 12 fragment
+// reads AND two DMA issues (~300 cycles), phase 3 no read at all; and the operand fetch runs at what 48 KiB in flight per CU deliver.
+// Schedule 2 moves phase 0's DMA issue into phase 3 of the previous K-tile and waits only where a group is first read:
+//     phase p of K-tile t issues   p=0: -   p=1: G3(t+1)   p=2: G0(t+2)   p=3: G1(t+2), G2(t+2)
+//     (re-target distances 3 / 2 / 3, 2 phases: G3 of buffer (t+1)&1 last read in p2(t-1); G0, G1 of buffer t&1 in p0(t); G2 in p1(t))
+//     waits (instructions left in flight; issue order ... G0(t) | G1(t) G2(t) | G3(t) | G0(t+1) | G1(t+1) G2(t+1) | G3(t+1) ...):
+//       p0(t): G2(t) is read in p1  -> younger: G3(t) G0(t+1) G1(t+1) G2(t+1)                = vmcnt(8)
+//       p1(t): G3(t) is read in p2  -> younger: G0(t+1) G1(t+1) G2(t+1) G3(t+1)              = vmcnt(8)
+//       p2(t): nothing new is read in p3                                                     = no wait
+//       p3(t): G0(t+1), G1(t+1) are read in p0(t+1) -> younger: G2(t+1) G3(t+1) G0(t+2) G1(t+2) G2(t+2) = vmcnt(10)
+//     i.e. four to five 16-KiB groups in flight (64 - 80 KiB per CU instead of 48) and memory segments of 12 reads | 4 reads + 2 DMA |
+//     8 reads + 2 DMA | 4 DMA instead of 12 + 2 | 4 + 2 | 8 + 2 | 0 + 2.  Tails: K-tile nk-2 issues G3(nk-1) only (waits 8 / 8 / - / 4),
+//     K-tile nk-1 nothing (2 / 0 / - / -).  The prologue carries G2(1) as well (7 groups) — except in the K launch (XMODE 3), whose queries
+//     ride in that very region of the ring: there K-tile 0 issues G2(1) in its phase 0, as in schedule 1, and every later count is
+//     the same (G2(1) is older than G3(1), as G2(t) is older than G3(t) in the steady state).  Same MFMA order, same bits.
+#ifndef TP_G8_SCHED
+#define TP_G8_SCHED 1
+#endif
+constexpr int G8_SCHED = TP_G8_SCHED;
 
 }  // namespace
 
@@ -141,6 +170,8 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
     constexpr int L_PAR = RING, L_RED = RING + g8_par_bytes(HALF, XMODE), L_NEXT = L_RED + g8_red_bytes(HALF, XMODE);
     static_assert(L_NEXT + 256 == g8_lds_bytes(HALF, true, XMODE), "LDS layout");
     static_assert(XMODE < 3 || (AMODE == 0 && !TRAIN_EPI), "attention epilogues: contiguous A");
+    constexpr bool S2 = G8_SCHED == 2 && !HALF && !T192;          // DMA schedule 2 (G8_SCHED)
+    constexpr bool PRO_G2 = S2 && XMODE != 3;                     // ... with G2(1) in the tile's prologue
     int ring_base = 0;                                  // XMODE 3, full tiles: parity of the buffer K-tile 0 of this tile uses
     int par_buf = 0;                                    // XMODE 3 / 4: the parameter buffer of the tile being computed
     auto ring_of = [&](const int kt) __attribute__((always_inline)) -> int {
@@ -353,7 +384,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
             issue(I0{}, 0); issue(I1{}, 0); issue(I2{}, 0); issue(I0{}, 1); issue(I1{}, 1);
         } else {
             issue(I0{}, 0); issue(I1{}, 0); issue(I2{}, 0); issue(I3{}, 0);
-            if (nk >= 2) { issue(I0{}, 1); issue(I1{}, 1); }
+            if (nk >= 2) { issue(I0{}, 1); issue(I1{}, 1); if constexpr (PRO_G2) issue(I2{}, 1); }
         }
     };
 
@@ -449,7 +480,8 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
     // (-1: no wait).  The DMA target of phase P in tile t is fixed by the schedule in the file header.
     auto phase = [&](auto P_, auto ISSUE_, auto WAIT_, const int t) __attribute__((always_inline)) {
         constexpr int P = decltype(P_)::value;
-        constexpr bool ISSUE = decltype(ISSUE_)::value;
+        constexpr int ISSUE_CODE = (int)decltype(ISSUE_)::value;  // 0 nothing | 1 the phase's groups | 2 schedule 2, K-tile 0 without G2(1) in the prologue
+        constexpr bool ISSUE = ISSUE_CODE != 0;
         constexpr int WAIT = decltype(WAIT_)::value;
         const char* sb = smem + ring_of(t) * KBUF;
         // -- memory segment ---------------------------------------------------------------------------
@@ -478,6 +510,11 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         } else if constexpr (ISSUE && HALF) {
             if constexpr (P == 0) issue(I2{}, t + 1);
             if constexpr (P == 1) { issue(I0{}, t + 2); issue(I1{}, t + 2); }
+        } else if constexpr (ISSUE && S2) {
+            if constexpr (P == 0 && ISSUE_CODE == 2) issue(I2{}, t + 1);
+            if constexpr (P == 1) issue(I3{}, t + 1);
+            if constexpr (P == 2) issue(I0{}, t + 2);
+            if constexpr (P == 3) { issue(I1{}, t + 2); issue(I2{}, t + 2); }
         } else if constexpr (ISSUE) {
             if constexpr (P == 0) issue(I2{}, t + 1);
             if constexpr (P == 1) issue(I3{}, t + 1);
@@ -513,13 +550,14 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
     };
     using T_ = std::true_type; using F_ = std::false_type;
     // vmcnt left in flight: steady state 2*DEPTH; the tail counts shrink as fewer groups remain to be issued
-    using WS_ = std::integral_constant<int, 2 * G8_DEPTH>;                 // steady
-    using WS1_ = std::integral_constant<int, T192 ? 5 : 2 * G8_DEPTH>;     // steady, phases 1..3 (192-row tiles: G3 is ONE instruction)
-    using WA_ = std::integral_constant<int, T192 ? 3 : 2 * (G8_DEPTH - 1)>;    // tile nk-2, phase 2: G2(nk-1), G3(nk-1) stay in flight
-    using WB_ = std::integral_constant<int, T192 ? 1 : 2 * (G8_DEPTH - 2)>;    // tile nk-2, phase 3: G3(nk-1)
-    static_assert(G8_DEPTH == 3 || !T192, "192-row tiles: wait counts derived for DEPTH = 3");
-    using WC_ = std::integral_constant<int, G8_DEPTH == 4 ? 2 : 0>;        // tile nk-1, phase 0
-    using WD_ = std::integral_constant<int, G8_DEPTH == 4 ? 0 : -1>;       // tile nk-1, phase 1
+    constexpr int DEPTH_ = (T192 || XMODE == 3) ? 3 : G8_DEPTH;     // (those two derive their counts for 3 groups in flight)
+    using WS_ = std::integral_constant<int, 2 * DEPTH_>;                 // steady
+    using WS1_ = std::integral_constant<int, T192 ? 5 : 2 * DEPTH_>;     // steady, phases 1..3 (192-row tiles: G3 is ONE instruction)
+    using WA_ = std::integral_constant<int, T192 ? 3 : 2 * (DEPTH_ - 1)>;    // tile nk-2, phase 2: G2(nk-1), G3(nk-1) stay in flight
+    using WB_ = std::integral_constant<int, T192 ? 1 : 2 * (DEPTH_ - 2)>;    // tile nk-2, phase 3: G3(nk-1)
+    static_assert(DEPTH_ == 3 || !T192, "192-row tiles: wait counts derived for DEPTH = 3");
+    using WC_ = std::integral_constant<int, DEPTH_ == 4 ? 2 : 0>;        // tile nk-1, phase 0
+    using WD_ = std::integral_constant<int, DEPTH_ == 4 ? 0 : -1>;       // tile nk-1, phase 1
     using WN_ = std::integral_constant<int, -1>;
 
     // The K loop of one output tile.  On entry: the tile's DMA prologue has been issued, G0(0) and G1(0) have
@@ -552,6 +590,34 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
             __builtin_amdgcn_sched_barrier(0);
             return;
         }
+        if constexpr (S2) {                                 // schedule 2 (G8_SCHED): waits 8 / 8 / - / 10, tails 8 / 8 / - / 4 and 2 / 0 / - / -
+            using X0 = std::integral_constant<int, 0>; using X1 = std::integral_constant<int, 1>; using X2 = std::integral_constant<int, 2>;
+            using W10_ = std::integral_constant<int, 10>; using W8_ = std::integral_constant<int, 8>; using W4_ = std::integral_constant<int, 4>;
+            using W2_ = std::integral_constant<int, 2>; using W0_ = std::integral_constant<int, 0>;
+            if constexpr (!PRO_G2) {                        // the K launch (nk = 16): K-tile 0 issues G2(1) itself
+                phase(I0{}, X2{}, W8_{}, t); phase(I1{}, X1{}, W8_{}, t); phase(I2{}, X1{}, WN_{}, t); phase(I3{}, X1{}, W10_{}, t);
+                ++t;
+            }
+            for (; t < nk - 2; ++t) {
+                phase(I0{}, X0{}, W8_{}, t); phase(I1{}, X1{}, W8_{}, t); phase(I2{}, X1{}, WN_{}, t); phase(I3{}, X1{}, W10_{}, t);
+            }
+            if (nk >= 2) {                                  // K-tile nk-2: G3(nk-1) is the last group there is to fetch
+                phase(I0{}, X0{}, W8_{}, t); phase(I1{}, X1{}, W8_{}, t); phase(I2{}, X0{}, WN_{}, t); phase(I3{}, X0{}, W4_{}, t);
+                ++t;
+            }
+            if constexpr (XMODE == 3) {                     // K-tile nk-1: the queries go out behind G2 / G3(nk-1) and stay in flight
+                issue_q(I0{}); phase(I0{}, X0{}, W4_{}, t);
+                issue_q(I1{}); phase(I1{}, X0{}, W4_{}, t);
+            } else {
+                phase(I0{}, X0{}, W2_{}, t);
+                phase(I1{}, X0{}, W0_{}, t);
+            }
+            phase(I2{}, X0{}, WN_{}, t);
+            phase(I3{}, X0{}, WN_{}, t);
+            if (wm == 0) __builtin_amdgcn_s_barrier();     // re-join: equal barrier counts for both halves
+            __builtin_amdgcn_sched_barrier(0);
+            return;
+        }
         for (; t < nk - 2; ++t) {                           // steady state: every phase issues, 3 groups stay in flight
             phase(I0{}, T_{}, WS_{}, t);
             phase(I1{}, T_{}, WS1_{}, t);
@@ -566,7 +632,7 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
             ++t;
         }
         if constexpr (XMODE == 3) {                         // tile nk-1: drain; the queries go out and stay in flight
-            static_assert(G8_DEPTH == 3, "tail wait counts");
+            static_assert(DEPTH_ == 3, "tail wait counts");
             issue_q(I0{}); phase(I0{}, F_{}, std::integral_constant<int, 2>{}, t);
             issue_q(I1{}); phase(I1{}, F_{}, WN_{}, t);
         } else {

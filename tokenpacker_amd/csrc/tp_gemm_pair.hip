@@ -189,7 +189,10 @@ gemm_pair_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const i
     // vector ALU instructions per K-tile beside its 64 MFMAs, and a wave issues one instruction per ~4 cycles: the memory
     // segments were issue-bound (measured: 1.80 instead of 1.45 us per K-tile and 256 x 256 tile).
     // K advances through the DMA instructions' scalar offset: soff_k = byte offset of K-tile u + 1 (pieces of tile u + 2: + 128).
-    int soff_k = 0;
+    // The A operand's own K offsets for the pieces one / two K-tiles ahead (D = 1 / 2): equal to soff_k, soff_k + 128 unless
+    // GemmArgs::a_k_wrap makes A's K index cyclic (three SALU instructions per K-tile in advance()).
+    int soff_k = 0, soff_a1 = 0, soff_a2 = 0;
+    const int a_wrap_bytes = p.a_k_wrap > 0 ? p.a_k_wrap * 2 : 0x7fffffff;
     int a_p0 = 0, a_p2 = 0, w_p0 = 0, w_p1 = 0;
     auto next_a = [&](const int off) __attribute__((always_inline)) -> int { return off == 2 * GP_AGRP ? 0 : off + GP_AGRP; };
     auto next_w = [&](const int off) __attribute__((always_inline)) -> int { return off == 2 * GP_WGRP ? 0 : off + GP_WGRP; };
@@ -198,7 +201,7 @@ gemm_pair_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const i
     auto issue_a = [&](auto SUB_, auto Q_, const int slot_off, auto D_) __attribute__((always_inline)) {
         constexpr int sub = decltype(SUB_)::value, q = decltype(Q_)::value, D = decltype(D_)::value;
         char* dst = smem + slot_off + (wave * 4 + q) * 1024;
-        const int soff = soff_k + (D - 1) * ROW_BYTES;
+        const int soff = D == 0 ? soff_k - ROW_BYTES : (D == 1 ? soff_a1 : soff_a2);      // (D = 0: K-tile 0 of the prologue)
         if constexpr (AMODE == 2) {
             // the K-tile lives in source ktg / tpp: pick that source's base with scalar selects and rebuild the descriptor
             const int ktg = soff / ROW_BYTES;
@@ -224,6 +227,7 @@ gemm_pair_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const i
     // the epilogue's scratch while this prologue is in flight; b0(1) follows in phase 0 of K-tile 0.
     auto issue_prologue = [&]() __attribute__((always_inline)) {
         soff_k = (kt_base + 1) * ROW_BYTES;                 // (K-tile 0 = "D = 0", K-tile 1 = D = 1)
+        soff_a1 = soff_k; soff_a2 = soff_k + ROW_BYTES;     // (a_k_wrap >= 3 K-tiles and kt_base = 0 with it: checked on the host)
         // sequence indices 0, 1, 2 -> slots 0, 1, 2:  a0(0) b0(0) | b1(0) a1(0) | a0(1)
         issue_a(I0{}, I0{}, 0, I0{}); issue_a(I0{}, I1{}, 0, I0{}); issue_a(I0{}, I2{}, 0, I0{}); issue_a(I0{}, I3{}, 0, I0{});
         issue_w(I0{}, I0{}, 0, I0{}); issue_w(I0{}, I1{}, 0, I0{});
@@ -350,6 +354,8 @@ gemm_pair_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const i
             a_p2 = a_p0; w_p1 = w_p0;                       // a1(u+1) took a0(u)'s slot, b1(u+1) b0(u)'s
             a_p0 = a0n; w_p0 = w0n;
             soff_k += ROW_BYTES;
+            soff_a1 = soff_a2;
+            soff_a2 = soff_a2 + ROW_BYTES == a_wrap_bytes ? 0 : soff_a2 + ROW_BYTES;
         };
         // K-tile kinds: steady (every phase issues), last but one (nothing beyond K-tile nk - 1 to fetch), last (drain)
         // K-tile 0: a0(1) came whole with the prologue; b0(1) goes out in its phase 0
@@ -467,6 +473,7 @@ bool gemm_pair_supports(int in_dtype, int out_dtype, const GemmArgs& a) {
         if (a.attn_mode && a.groups != 1) return false;
     }
     if (a.A_parts[0] && out_dtype != TP_F16) return false;
+    if (a.a_k_wrap && (a.a_k_wrap % BK != 0 || a.a_k_wrap < 3 * BK || a.a_k_wrap > a.K || strided_a || a.A_parts[0] || a.tri)) return false;
     if ((a.flags & TP_LINEAR_ROW_STATS) && out_dtype == TP_F32) return false;
     return in_dtype == TP_BF16 || in_dtype == TP_F16;
 }

@@ -85,6 +85,10 @@ struct GemmArgs {
     long long ldw_bytes;              // between rows of W (0: K * 2 — a contiguous [N, K] weight)
     const char* A_parts[4];           // K split over 4 source tensors of k_part columns each (NULL: A alone)
     int k_part;
+    int a_k_wrap;                     // pair kernel, contiguous A: the A operand's K index wraps to 0 after a_k_wrap elements (a multiple of 64,
+                                      // >= 192) while W's runs on to K — A = [u_hi | u_lo] against W rows [hi | hi | lo] contracts
+                                      // (u_hi | u_lo | u_hi) with K = 3 E from ONE stored [.., 2 E] operand (the absorbed schedule's per-head
+                                      // V GEMM; same K order as the A_parts form of the 128-tile kernel -> same bits).  0: no wrap
     int parts_k_groups;               // A_parts + groups over K (128-tile kernel): group g covers K-tiles g*K/64 .. of the sources
     int tri;                          // statistics-only launches (NO_STORE): W is UPPER TRIANGULAR (W[n][k] = 0 for k < n): the output
                                       // tile at column n0 starts its K loop at K-tile n0 / 64 (tp_pack_qr.hip)

@@ -50,10 +50,11 @@ def make_args(A, W, bias, C, flags, tile):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--old", required=True)
+    ap.add_argument("--new", default=_capi.LIB_PATH, help="the other build (default: the in-tree library)")
     ap.add_argument("--out", default="gpurun_out/lib_ab.json")
     ap.add_argument("--rounds", type=int, default=9)
     a = ap.parse_args()
-    libs = {"old": open_lib(os.path.abspath(a.old)), "new": open_lib(_capi.LIB_PATH)}
+    libs = {"old": open_lib(os.path.abspath(a.old)), "new": open_lib(os.path.abspath(a.new))}
     stream = torch.cuda.current_stream().cuda_stream
     shapes = [("kv_layer0", 147456, 2048, 4096, torch.bfloat16, torch.float16, G), ("mlp2", 36864, 4096, 4096, torch.float16, torch.bfloat16, 0),
               ("mlp0", 36864, 4096, 1024, torch.float16, torch.float16, G), ("k1024", 147456, 1024, 1024, torch.float16, torch.float16, 0),
