@@ -275,13 +275,17 @@ typedef struct tp_linear_args {
     int64_t lda;               /* elements between consecutive rows of A                           */
     int64_t ldc;               /* elements between consecutive rows of C                           */
     const void* A;
-    const void* W;             /* [N,K] contiguous                                                 */
+    const void* W;             /* [N,K], rows ldw elements apart (ldw = 0: contiguous)             */
     const float* bias;
     void* C;
     const float* row_mean_rstd;/* LN_FOLD: fp32 [M][2]                                             */
     const float* colsum;       /* LN_FOLD: fp32 [N]                                                */
     int32_t tile;              /* 0 = auto, 128 or 256: force the block tile                       */
-    int32_t reserved1;
+    int32_t ldw;               /* elements between consecutive rows of W; 0 = K (contiguous).  (ABI 4, round 5: the field was
+                                * reserved1.  It exists for tools/stride_ab.py: an isolated LDS-DMA stream over rows a power of two
+                                * apart runs at 28 GB/s per CU against 123 with +64 elements of padding — tools/probes/
+                                * operand_fetch_probe.hip — but INSIDE the GEMMs, where an XCD's 32 tiles share their operands,
+                                * padded A / W / C strides measure +-0.5 %, profiles/r05f_stride_ab.json; nothing is padded) */
     float*  row_stats_out;     /* ROW_STATS                                                        */
 } tp_linear_args;
 int tp_linear(const tp_linear_args* args, void* stream);

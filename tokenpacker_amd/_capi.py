@@ -83,7 +83,7 @@ class tp_linear_args(Structure):
                 ("a_batch_stride", c_int64), ("lda", c_int64), ("ldc", c_int64),
                 ("A", c_void_p), ("W", c_void_p), ("bias", c_void_p), ("C", c_void_p),
                 ("row_mean_rstd", c_void_p), ("colsum", c_void_p),
-                ("tile", c_int32), ("reserved1", c_int32), ("row_stats_out", c_void_p)]
+                ("tile", c_int32), ("ldw", c_int32), ("row_stats_out", c_void_p)]
 
 
 class tp_hd_image(Structure):

@@ -650,6 +650,10 @@ int tp_linear(const tp_linear_args* a, void* stream) {
     g.bias = a->bias; g.stats_in = a->row_mean_rstd; g.colsum = a->colsum; g.stats_out = a->row_stats_out;
     g.rows_per_batch = (a->rows_per_batch > 0 && a->rows_per_batch < a->M) ? a->rows_per_batch : a->M;
     g.a_batch_stride_bytes = a->a_batch_stride * 2; g.lda_bytes = a->lda * 2; g.ldc = a->ldc;
+    if (a->ldw != 0) {
+        if (a->ldw < a->K || a->ldw % 8 != 0) { set_error("tp_linear: ldw must be 0 or a multiple of 8 elements >= K"); return TP_ERR_INVALID_ARG; }
+        g.ldw_bytes = (long long)a->ldw * 2;
+    }
     g.M = a->M; g.N = a->N; g.K = a->K; g.flags = a->flags;
     g.groups = 1; g.tile = a->tile;
     if (a->flags & TP_LINEAR_OUT_F32) { set_error("tp_linear: TP_LINEAR_OUT_F32 was replaced by out_dtype = TP_F32"); return TP_ERR_INVALID_ARG; }

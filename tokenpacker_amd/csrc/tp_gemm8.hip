@@ -244,6 +244,18 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
             // are fetched twice.  Total fabric traffic is the same to first order; measured: see profiles/.
             const int blk = Lt >> 6, i = Lt & 63, half = i >> 5, j = i & 31;
             if ((blk << 3) + 8 <= tiles_m) { tm = (blk << 3) + (j >> 2); tile_n = (half << 2) + (j & 3); }
+        } else if (xcd_swizzle == 2 && tiles_n > 8) {
+            // round 5: launches with MORE than 8 N-tiles (mlp[0], mlp[2]: 16; D = 5120: 20).  In row-panel-major order the 32 tiles an
+            // XCD has resident are 2 row panels x 16 N-tiles: per K-tile they pull 2 A slabs + 16 W slabs = 18 x 32 KiB through the
+            // fabric, and ALL of W once per round (PMC: mlp[2] reads 2.73 GB per launch for 0.34 GB of operands).  Walk blocks of 4 row
+            // panels column group by column group (groups of 8 N-tiles, the last one narrower): 4 + 8 = 12 slabs per K-tile, -33 %.
+            const int per_blk = tiles_n << 2, blk = Lt / per_blk, i = Lt - blk * per_blk;
+            if ((blk << 2) + 4 <= tiles_m) {
+                const int full = tiles_n >> 3, g = i >> 5;              // (a full group = 4 x 8 = 32 tiles)
+                const int c0 = (g < full ? g : full) << 3, w = g < full ? 8 : tiles_n - c0, j = i - (g < full ? g << 5 : full << 5);
+                const int r = j / w;
+                tm = (blk << 2) + r; tile_n = c0 + (j - r * w);
+            }
         }
         m0 = p.m_begin + tm * BM; n0 = tile_n * BN;
         if constexpr (XMODE == 1) {
