@@ -1060,20 +1060,19 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
                                                     (const float*)(ws + W.mr_kv) + (size_t)rows_kv * 2, uu, B, g, s, stream, attn_mask, mask_mode));
         // O[:, h*128:(h+1)*128] = u[:, h, :] · W'v[h*128:(h+1)*128, :]^T + b'v   (eight N = 128 groups)
         // RAW: a_h (u_h · Wc_v,h^T + d_v,h - (e_h / a_h) c_v,h) + b'v,h — a LayerNorm-fold epilogue with (mean, rstd) := mr_u
-        // u_split: the contraction runs over (u_hi | u_lo | u_hi) against Wc'_v's rows as [hi | hi | lo] (K = 3 E; the operand's three
-        // K ranges are two views of u, GemmArgs::A_parts) — neither u's nor the pre-multiplied weight's fp16 rounding survives
+        // u_split: the contraction runs over u_hi·W_hi + u_hi·W_lo + u_lo·W_hi (K = 3 E over the 2 E-wide u, GemmArgs::a_k_dup) —
+        // neither u's nor the pre-multiplied weight's fp16 rounding survives
         const int uK = u_split ? 3 * E : E, uld = u_split ? 2 * E : E;
         GemmArgs a = plain_gemm(uu, 8 * uld, u_split ? pw + P.w_cc_v3
                                                      : (absorb_raw ? (tri ? pw + P.w_cc_kv : pw + P.w_c_kv) : pw + P.w_in_kv) + (size_t)E * E * 2,
                                 ws + W.o, E, rows_q, kHeadDim, uK, (const float*)(pw + P.b_in_kv) + E, absorb_raw ? TP_LINEAR_LN_FOLD : 0);
         a.groups = kHeads; a.a_gs = uld * 2; a.w_gs = (long long)kHeadDim * uK * 2; a.c_gs = kHeadDim * 2; a.bias_gs = kHeadDim;
-        // Round 5: on the 128-tile kernel this K = 3 E contraction ran at 0.47 PFLOP/s (221 us at B = 256, s = 3: a third of the
-        // round-4 s = 3 / 4 regression).  The pair kernel's 256 x 128 tile fits N = 128 per head: its A operand is the
-        // stored [hi | lo] row read cyclically (GemmArgs::a_k_wrap = 2 E: K-tiles 32 .. 47 re-read hi) — same K order, same epilogue, same
-        // bits as the A_parts form, which stays for launches of less than half a round of pair tiles and for TP_TUNE_PAIR_GEMM = 1.
-        const long long pair_tiles = (long long)((rows_q + 255) / 256) * kHeads;
-        if (u_split && tuning(TP_TUNE_PAIR_GEMM) != 1 && pair_tiles * 2 >= gemm_pair_workgroups()) a.a_k_wrap = 2 * E;
-        else if (u_split) { a.A_parts[0] = uu; a.A_parts[1] = uu + (size_t)E * 2; a.A_parts[2] = uu; a.A_parts[3] = uu; a.k_part = E; }
+        // Round 5: this K = 3 E contraction is HBM-bound on u (N = 128 per head: every byte of A belongs to ONE tile), and with W's rows as
+        // [hi | hi | lo] the u_hi half was fetched twice, 2 E apart: 805 MB and 221 us at B = 256, s = 3 whichever kernel ran it
+        // (profiles/r05b_bench_ab.json).  W's rows are now [hi_0 lo_0 hi_1 lo_1 .. | hi_0 .. hi_15] and GemmArgs::a_k_dup lets every u_hi
+        // K-tile serve its two W K-tiles back to back (the second fetch hits the L2): 537 MB.  Large launches take the pair kernel (its
+        // 256 x 128 tile fits N = 128), small ones the 128-tile kernel — one K order, the same bits (gemm_takes_pair_route).
+        if (u_split) a.a_k_dup = E;
         if (absorb_raw) {
             a.acc_init = (const float*)(tri ? pw + P.d_cc_kv : pw + P.d_in_kv) + E; a.acc_init_gs = kHeadDim;
             a.colsum = (const float*)(pw + P.c_in_kv) + E; a.colsum_gs = kHeadDim;

@@ -98,6 +98,10 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
         const int kt = kt_rel + kt0;
         char* dst = smem + stage * STAGE + wave * CPW * 1024;
         long long a_adv = (long long)kt * ROW_BYTES;            // K advance of the A pieces
+        if constexpr (AMODE == 0) {                              // GemmArgs::a_k_dup: the leading K-tiles of A serve two K-tiles of W each
+            const int w = p.a_k_dup / BK;
+            a_adv = (long long)(kt < 2 * w ? kt >> 1 : kt - w) * ROW_BYTES;
+        }
         if constexpr (AMODE == 2) {                              // K split over four source tensors
             // (a K-split launch — groups over K, a_gs = 0 — walks the sources with the group's GLOBAL K-tile index)
             const int ktg = kt + (p.parts_k_groups ? g * (p.K / BK) : 0);
@@ -260,12 +264,11 @@ static int launch_types(const GemmArgs& a, hipStream_t stream) {
     const bool train_epi = (a.flags & (TP_LINEAR_SAVE_PRE | TP_LINEAR_GELU_BWD)) != 0;
     if ((a.flags & TP_LINEAR_NO_STORE) || a.acc_init) {     // the two GEMMs of the fused LayerNorm chain (128-tile form)
         if constexpr (std::is_same<TI, f16_t>::value && std::is_same<TO, f16_t>::value) {
-            if (strided || train_epi || ((a.flags & TP_LINEAR_NO_STORE) && a.acc_init) || (a.A_parts[0] && (!a.acc_init || a.attn_mode))) {
+            if (strided || train_epi || ((a.flags & TP_LINEAR_NO_STORE) && a.acc_init) || a.A_parts[0]) {
                 set_error("tp gemm: NO_STORE / acc_init take a contiguous A, no training epilogue, and not both at once");
                 return TP_ERR_INVALID_ARG;
             }
-            // (acc_init with K split over source tensors: the absorbed schedule's per-head V GEMM over u = hi | lo | hi)
-            if (a.A_parts[0]) return launch_cfg<TI, TO, 128, 128, 64, 64, 2, false, 2>(a, stream);
+            // (the absorbed schedule's per-head V GEMM over u = hi | lo arrives here as a contiguous A with GemmArgs::a_k_dup)
             if (a.attn_mode)                                 // (validated by gemm_launch)
                 return a.attn_mode == 1 ? launch_cfg<TI, TO, 128, 128, 64, 64, 0, false, 3>(a, stream)
                                         : launch_cfg<TI, TO, 128, 128, 64, 64, 0, false, 4>(a, stream);
@@ -366,7 +369,12 @@ static int gemm_route(const GemmArgs& a, long long* head_rows_out) {
 // a 32 .. 64-image shard (profiles/r04b_pair_ab.json).  TP_TUNE_PAIR_GEMM: 0 that policy | 1 never | 2 wherever supported.
 static bool gemm_takes_pair_route(int in_dtype, int out_dtype, const GemmArgs& a) {
     const int mode = tuning(TP_TUNE_PAIR_GEMM);
-    if (a.a_k_wrap) return gemm_pair_supports(in_dtype, out_dtype, a);      // (only the pair kernel wraps A's K index; the caller chose)
+    if (a.a_k_dup) {
+        // the absorbed schedule's per-head V GEMM (N = 128 per head: the 256-column kernel cannot take it): the pair kernel from half a
+        // round of its tiles on, the 128-tile kernel below that and with TP_TUNE_PAIR_GEMM = 1 — same K order, same bits either way
+        const long long t = (long long)((a.M + 255) / 256) * (a.N / 128) * (a.groups > 0 ? a.groups : 1);
+        return mode != 1 && a.tile == 0 && t * 2 >= gemm_pair_workgroups() && gemm_pair_supports(in_dtype, out_dtype, a);
+    }
     if (mode == 1 || a.tile != 0 || (tuning(TP_TUNE_GEMM_TILE) != 0 && tuning(TP_TUNE_GEMM_TILE) != 4)) return false;
     if (!gemm_pair_supports(in_dtype, out_dtype, a)) return false;
     if (mode == 2) return true;
@@ -432,7 +440,20 @@ int gemm_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stre
     // (a third main loop — one wave per SIMD, 128 x 128 wave tiles, AGPR accumulators, one barrier per K-tile — was built,
     // measured 8-22 % slower and removed in round 4: commit 638f1b9, profiles/r04k_solo_gemm_ab.json)
     if (gemm_takes_pair_route(in_dtype, out_dtype, a)) return gemm_pair_launch(in_dtype, out_dtype, a, stream);
-    if (a.a_k_wrap) { set_error("tp gemm: a_k_wrap is served by the pair kernel only, which does not take this launch"); return TP_ERR_INVALID_ARG; }
+    if (a.a_k_dup) {                                    // ... otherwise the 128-tile kernel (contiguous A, no training epilogue)
+        const bool strided = a.rows_per_batch < a.M || a.a_region_s > 0;
+        if (a.a_k_dup % BK != 0 || 2 * a.a_k_dup > a.K || strided || a.A_parts[0] || a.tri || a.tt_rows || (a.flags & (TP_LINEAR_SAVE_PRE | TP_LINEAR_GELU_BWD))) {
+            set_error("tp gemm: a_k_dup needs a contiguous A, K >= 2 a_k_dup, a_k_dup %% 64 == 0 and an inference epilogue");
+            return TP_ERR_INVALID_ARG;
+        }
+        GemmArgs s = a; s.tile = 128;
+        if (in_dtype == TP_F16 && out_dtype == TP_F16) return launch_types<f16_t, f16_t>(s, stream);
+        if (in_dtype == TP_F16 && out_dtype == TP_F32) return launch_types<f16_t, float>(s, stream);
+        if (in_dtype == TP_BF16 && out_dtype == TP_BF16) return launch_types<bf16_t, bf16_t>(s, stream);
+        if (in_dtype == TP_BF16 && out_dtype == TP_F16) return launch_types<bf16_t, f16_t>(s, stream);
+        set_error("tp gemm: a_k_dup: unsupported dtypes in=%d out=%d", in_dtype, out_dtype);
+        return TP_ERR_INVALID_ARG;
+    }
     {
         long long head_rows = 0;
         const int route = gemm_route(a, &head_rows);

@@ -536,7 +536,10 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         if constexpr (WAIT >= 0) wait_vmcnt<WAIT>();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // (the builtin, not inline asm — round 5: after an asm wait the compiler still believes the fragment reads outstanding and
+        // threads its OWN s_waitcnt lgkmcnt(7) .. (0) between the segment's MFMAs, 16 dead issue slots per K-tile in the one place
+        // where an extra slot costs matrix-pipe time; 0xc07f = lgkmcnt(0), vmcnt / expcnt untouched.  tp_gemm_pair.hip found the same.)
+        __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_sched_barrier(0);
         // -- matrix segment ---------------------------------------------------------------------------
         constexpr int a = (P >= 2) ? 1 : 0, b = (P == 1 || P == 2) ? 1 : 0;
@@ -900,6 +903,7 @@ static int launch8_types(const GemmArgs& a, hipStream_t stream) {
 
 // Preconditions (checked by gemm_launch): N % 256 == 0, K % 64 == 0, (long long)N_tile_rows * K * 2 < 2^31.
 int gemm8_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream) {
+    if (a.a_k_dup) { set_error("tp gemm8: a_k_dup is served by the pair kernel and the 128-tile kernel"); return TP_ERR_INVALID_ARG; }
     if (a.tt_rows == 0 && (a.lda_bytes >= (1 << 23) || (a.ldw_bytes ? a.ldw_bytes : (long long)a.K * 2) >= (1 << 23))) {
         set_error("tp gemm8: row strides must stay below 8 MiB (24-bit offset arithmetic)");
         return TP_ERR_INVALID_ARG;

@@ -190,9 +190,10 @@ gemm_pair_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const i
     // segments were issue-bound (measured: 1.80 instead of 1.45 us per K-tile and 256 x 256 tile).
     // K advances through the DMA instructions' scalar offset: soff_k = byte offset of K-tile u + 1 (pieces of tile u + 2: + 128).
     // The A operand's own K offsets for the pieces one / two K-tiles ahead (D = 1 / 2): equal to soff_k, soff_k + 128 unless
-    // GemmArgs::a_k_wrap makes A's K index cyclic (three SALU instructions per K-tile in advance()).
-    int soff_k = 0, soff_a1 = 0, soff_a2 = 0;
-    const int a_wrap_bytes = p.a_k_wrap > 0 ? p.a_k_wrap * 2 : 0x7fffffff;
+    // GemmArgs::a_k_dup lets the leading K-tiles of A serve two K-tiles of W each (a_map; six SALU instructions per K-tile in advance()).
+    int soff_k = 0, soff_a1 = 0, soff_a2 = 0, a_step = 0;            // a_step: the K-tile soff_a2 belongs to
+    const int a_dup_tiles = p.a_k_dup / BK;
+    auto a_map = [&](const int j) __attribute__((always_inline)) -> int { return j < 2 * a_dup_tiles ? j >> 1 : j - a_dup_tiles; };
     int a_p0 = 0, a_p2 = 0, w_p0 = 0, w_p1 = 0;
     auto next_a = [&](const int off) __attribute__((always_inline)) -> int { return off == 2 * GP_AGRP ? 0 : off + GP_AGRP; };
     auto next_w = [&](const int off) __attribute__((always_inline)) -> int { return off == 2 * GP_WGRP ? 0 : off + GP_WGRP; };
@@ -227,7 +228,7 @@ gemm_pair_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const i
     // the epilogue's scratch while this prologue is in flight; b0(1) follows in phase 0 of K-tile 0.
     auto issue_prologue = [&]() __attribute__((always_inline)) {
         soff_k = (kt_base + 1) * ROW_BYTES;                 // (K-tile 0 = "D = 0", K-tile 1 = D = 1)
-        soff_a1 = soff_k; soff_a2 = soff_k + ROW_BYTES;     // (a_k_wrap >= 3 K-tiles and kt_base = 0 with it: checked on the host)
+        soff_a1 = (kt_base + a_map(1)) * ROW_BYTES; soff_a2 = (kt_base + a_map(2)) * ROW_BYTES; a_step = 2;
         // sequence indices 0, 1, 2 -> slots 0, 1, 2:  a0(0) b0(0) | b1(0) a1(0) | a0(1)
         issue_a(I0{}, I0{}, 0, I0{}); issue_a(I0{}, I1{}, 0, I0{}); issue_a(I0{}, I2{}, 0, I0{}); issue_a(I0{}, I3{}, 0, I0{});
         issue_w(I0{}, I0{}, 0, I0{}); issue_w(I0{}, I1{}, 0, I0{});
@@ -355,7 +356,8 @@ gemm_pair_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const i
             a_p0 = a0n; w_p0 = w0n;
             soff_k += ROW_BYTES;
             soff_a1 = soff_a2;
-            soff_a2 = soff_a2 + ROW_BYTES == a_wrap_bytes ? 0 : soff_a2 + ROW_BYTES;
+            ++a_step;
+            soff_a2 = (kt_base + a_map(a_step)) * ROW_BYTES;
         };
         // K-tile kinds: steady (every phase issues), last but one (nothing beyond K-tile nk - 1 to fetch), last (drain)
         // K-tile 0: a0(1) came whole with the prologue; b0(1) goes out in its phase 0
@@ -473,7 +475,7 @@ bool gemm_pair_supports(int in_dtype, int out_dtype, const GemmArgs& a) {
         if (a.attn_mode && a.groups != 1) return false;
     }
     if (a.A_parts[0] && out_dtype != TP_F16) return false;
-    if (a.a_k_wrap && (a.a_k_wrap % BK != 0 || a.a_k_wrap < 3 * BK || a.a_k_wrap > a.K || strided_a || a.A_parts[0] || a.tri)) return false;
+    if (a.a_k_dup && (a.a_k_dup % BK != 0 || 2 * a.a_k_dup > a.K || strided_a || a.A_parts[0] || a.tri)) return false;
     if ((a.flags & TP_LINEAR_ROW_STATS) && out_dtype == TP_F32) return false;
     return in_dtype == TP_BF16 || in_dtype == TP_F16;
 }

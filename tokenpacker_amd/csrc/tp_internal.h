@@ -85,10 +85,13 @@ struct GemmArgs {
     long long ldw_bytes;              // between rows of W (0: K * 2 — a contiguous [N, K] weight)
     const char* A_parts[4];           // K split over 4 source tensors of k_part columns each (NULL: A alone)
     int k_part;
-    int a_k_wrap;                     // pair kernel, contiguous A: the A operand's K index wraps to 0 after a_k_wrap elements (a multiple of 64,
-                                      // >= 192) while W's runs on to K — A = [u_hi | u_lo] against W rows [hi | hi | lo] contracts
-                                      // (u_hi | u_lo | u_hi) with K = 3 E from ONE stored [.., 2 E] operand (the absorbed schedule's per-head
-                                      // V GEMM; same K order as the A_parts form of the 128-tile kernel -> same bits).  0: no wrap
+    int a_k_dup;                      // pair kernel and 128-tile kernel, contiguous A: the first a_k_dup K-elements of A (a multiple of 64) are
+                                      // each used for TWO consecutive K-tiles of W, the rest once: K-tile j of the contraction reads A's K-tile
+                                      // j / 2 while j < 2 w (w = a_k_dup / 64) and j - w after that, so K = a_k_dup + (A's width).  The absorbed
+                                      // schedule's per-head V GEMM contracts A = [u_hi | u_lo] (2 E wide) against W rows laid out
+                                      // [hi_0 lo_0 hi_1 lo_1 .. | hi_0 .. hi_15] (K = 3 E): u_hi·W_hi + u_hi·W_lo + u_lo·W_hi with every byte of u
+                                      // fetched from HBM ONCE — the second use of a u_hi K-tile follows the first by one K-tile and hits the L2
+                                      // (round 5; [hi | hi | lo] with u_hi fetched twice 2 E apart read 805 MB instead of 537).  0: off
     int parts_k_groups;               // A_parts + groups over K (128-tile kernel): group g covers K-tiles g*K/64 .. of the sources
     int tri;                          // statistics-only launches (NO_STORE): W is UPPER TRIANGULAR (W[n][k] = 0 for k < n): the output
                                       // tile at column n0 starts its K loop at K-tile n0 / 64 (tp_pack_qr.hip)
@@ -213,7 +216,7 @@ int pack_qr_center_launch(const void* w2_f16, const float* b2, void* scratch, in
 int pack_qr_factor_launch(void* scratch, int nmat, hipStream_t stream);
 int pack_qr_extract_launch(const void* scratch, int m, void* r_f16, float* ctil, hipStream_t stream, int* sat);
 int pack_center_product_launch(const float* P, const float* c, const float* wbar, void* out_f16, const float* d, float* d_out,
-                               hipStream_t stream, int* sat, const float* P2 = nullptr, void* out3_f16 = nullptr);   // out3: rows [hi | hi | lo]
+                               hipStream_t stream, int* sat, const float* P2 = nullptr, void* out3_f16 = nullptr);   // out3: rows [hi_0 lo_0 .. hi_15 lo_15 | hi_0 .. hi_15]
 // lo = fp16(W' − fp16(W')), c_exact = rowsum(W'), d_exact = W'·v (v may be NULL), W' = w·diag(gamma) exact in fp32 (tp_kernels.hip)
 int pack_ln_fold_residual_launch(int dtype, const void* w, const void* gamma, const float* v, void* lo_f16, float* c_exact,
                                  float* d_exact, int n_out, int n_in, hipStream_t stream);

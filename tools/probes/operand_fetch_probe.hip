@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(512, 2) probe(const char* __restrict__ src, fl
     //   4 identity, the piece's 8 rows are 8 rows apart (row = 8 i + j instead of 8 j + i)      5 / 6: 1 / 2 with a row stride of 8 KiB + 128 B
     //   7 slot ^= row & 4 (half-line swap only)      8 slot ^= row & 3 (permutation inside a 64-B half only)
     constexpr int LDA = (PATTERN == 5 || PATTERN == 6) ? 8192 + 128 : 8192;
-    if constexpr (PATTERN >= 1) {
+    if constexpr (PATTERN >= 1 && PATTERN < 9) {
         const int r = lane >> 3, pslot = lane & 7;
         const int slot16 = (PATTERN == 2 || PATTERN == 6) ? (pslot ^ r) : PATTERN == 3 ? ((pslot + r) & 7) : PATTERN == 7 ? (pslot ^ (r & 4)) :
                            PATTERN == 8 ? (pslot ^ (r & 3)) : pslot;
@@ -49,7 +49,28 @@ __global__ void __launch_bounds__(512, 2) probe(const char* __restrict__ src, fl
         voff = row * LDA + slot16 * 16;
     }
     constexpr int PSTEP = PATTERN == 0 ? 8192 : 64 * LDA;           // piece p -> p-th block of 64 rows
-    if constexpr (MODE == 0) {
+    if constexpr (MODE == 0 && PATTERN >= 9) {
+        // Shared streams (what a GEMM's operands are): the 32 workgroups of an XCD read the SAME 64 KiB per step, in lockstep only by
+        // their equal pace.  9: always the same 64 KiB (L2-resident, shared)  10: a 24-MiB region per XCD walked round and round
+        // (beyond the 4-MiB L2, inside the Infinity Cache)  11: as 10 but each workgroup starts a quarter of the region apart in
+        // groups of 8 (four streams per XCD, 8 sharers each — kv_layer0's A panels)  12: a PRIVATE 24-MiB-per-XCD / 32 stream each
+        const char* base = src + (size_t)x * (24u << 20);
+        const int steps = (24 << 20) / 65536;                            // 384 steps per lap
+        int st = PATTERN == 11 ? (slot >> 3) * (steps / 4) : PATTERN == 12 ? slot * (steps / 32) : 0;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+        for (int it = 0; it < iters; ++it) {
+            char* dst = smem + (it & 1) * 65536 + wave * 1024;
+            const int soff = PATTERN == 9 ? 0 : st * 65536;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(dst + p * 8192), 16, voff, soff + p * 8192, 0, 0);
+                wait_vm<IN_FLIGHT - 1>();
+            }
+            st = st + 1 == steps ? 0 : st + 1;
+            if constexpr (BARRIER) __builtin_amdgcn_s_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if constexpr (MODE == 0) {
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)win, 0, 0x7fffffff, 0x00020000);
         for (int it = 0; it < iters; ++it) {
             char* dst = smem + (it & 1) * 65536 + wave * 1024;
@@ -129,6 +150,11 @@ int main() {
         PAT(4, "8 rows x 128 B, slots in order, rows 64 KiB apart")
         PAT(5, "8 rows x 128 B, slots in order, row stride 8 KiB + 128 B")
         PAT(6, "8 rows x 128 B, slot ^= row, row stride 8 KiB + 128 B")
+        printf("  LDS-DMA, 1-KiB pieces, streams SHARED inside an XCD (the 32 workgroups read the same bytes at their own pace):\n");
+        PAT(9, "the same 64 KiB for ever (L2-resident, 32 sharers)")
+        PAT(10, "one 24-MiB stream per XCD (Infinity Cache), 32 sharers")
+        PAT(11, "four 24-MiB streams per XCD, 8 sharers each")
+        PAT(12, "32 streams per XCD, no sharing")
         fflush(stdout);
     }
     hipError_t e = hipDeviceSynchronize();
