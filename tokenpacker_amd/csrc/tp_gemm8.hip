@@ -537,8 +537,9 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         // (the builtin, not inline asm — round 5: after an asm wait the compiler still believes the fragment reads outstanding and
-        // threads its OWN s_waitcnt lgkmcnt(7) .. (0) between the segment's MFMAs, 16 dead issue slots per K-tile in the one place
-        // where an extra slot costs matrix-pipe time; 0xc07f = lgkmcnt(0), vmcnt / expcnt untouched.  tp_gemm_pair.hip found the same.)
+        // threads its OWN s_waitcnt lgkmcnt(7) .. (0) between the segment's MFMAs, 16 per K-tile; 0xc07f = lgkmcnt(0), vmcnt / expcnt
+        // untouched.  Already-satisfied waits turned out to be free — same-box A/B of the two builds +-0.5 %, profiles/
+        // r05h_lib_ab_wait.json — so this is tidiness, as in tp_gemm_pair.hip, not speed.)
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_sched_barrier(0);
         // -- matrix segment ---------------------------------------------------------------------------

@@ -225,11 +225,17 @@ int region_attention_launch(const void* q, const void* k, const void* v, void* o
 //         w_t = p_t rstd_t,  a_h = sum_t w_t,  e_h = sum_t w_t mu_t,  u_h = (sum_t w_t hkv^v_t) / a_h
 // i.e. the per-head V GEMM behind it is a LayerNorm-fold GEMM with (mean, rstd) := (e_h / a_h, a_h), written to `mr_u`
 // ([8 heads][B M][2]).  No per-element normalisation on load: two VALU operations less per element and key.
+// Waves per SIMD the absorbed attention kernel is compiled for.  2: 190 VGPRs, no scratch.  3 (-DTP_ABSORB_WAVES=3, `make variant
+// VSRC=tp_kernels`): 168 VGPRs + 29 spilled — measured 0.52 -> 0.645 ms for the attention stage at B = 256, s = 3 (0.39 -> 0.48 at s = 4):
+// the kernel is HBM-bound at 4.6-4.9 TB/s and the spills cost more than the third wave's loads in flight buy (profiles/r05k_absorb_waves_ab.txt).
+#ifndef TP_ABSORB_WAVES
+#define TP_ABSORB_WAVES 2
+#endif
 constexpr int kAbsorbMaxKeys = 64;          // s*s <= 64 (s <= 8): logits of a region live in LDS
 
 // QT32 (with u_ld = 2 E: the library's own s >= 3 schedule): qt arrives in fp32 — the per-head query GEMM's accumulators, not rounded.
 template <bool RAW, bool QT32 = false>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, TP_ABSORB_WAVES)
 region_attention_absorbed_kernel(const void* __restrict__ qt_, const f16_t* __restrict__ h2k, const f16_t* __restrict__ h2v,
                                  const float* __restrict__ mr_k, const float* __restrict__ mr_v, f16_t* __restrict__ u,
                                  int B, int g, int s, float scale, const float* __restrict__ mask, int mask_mode,
