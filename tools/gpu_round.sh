@@ -31,8 +31,9 @@ if has ktests; then
 fi
 if has tests; then
   echo "== pytest gpu =="
-  timeout 1500 python -m pytest tests -m gpu -q -s -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1
-  echo "pytest exit $?"; grep -E "passed|failed|error" $OUT/pytest_gpu.log | tail -5; grep -E "^\[parity\]|^\[eager|^\[e2e\]|^\[adv\]|^\[grad\].*worst" $OUT/pytest_gpu.log | tail -120; grep -E "^(FAILED|ERROR)" $OUT/pytest_gpu.log | head -40
+  # (exactly the driver's command plus the 25 slowest tests: the whole suite must stay far below the driver's 1200 s limit — VERDICT r4)
+  T0=$(date +%s); timeout 1500 python -m pytest tests -m gpu -q -s -p no:cacheprovider --durations=25 > $OUT/pytest_gpu.log 2>&1
+  echo "pytest exit $? wall $(( $(date +%s) - T0 )) s"; grep -E "passed|failed|error" $OUT/pytest_gpu.log | tail -5; grep -E "^\[parity\]|^\[eager|^\[e2e\]|^\[adv\]|^\[grad\].*worst" $OUT/pytest_gpu.log | tail -120; grep -E "^(FAILED|ERROR)" $OUT/pytest_gpu.log | head -40
   cp gpurun_out/eager_rocm_s*.json $OUT/ 2>/dev/null
 fi
 if has gemm; then
