@@ -22,10 +22,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 #   there (two fp16 roundings sit on the logit path, Q and qt, against one at s = 2): 127 of 128 seeds <= 1e-3, worst 1.09e-3.
 # Round 4 removed three fp16 roundings that sat in series on the value path (the LayerNorm fold inside the pre-multiplied chain
 # weights; on the absorbed schedule `u` and the pre-multiplied V weight, both carried as hi + lo): medians -10 .. -12 %.
-# This test runs TP_PARITY_SEEDS seeds and gates the WORST seed, the p90 and the median.  Default 4 (round 5): every seed is six fp64
-# CPU-oracle forwards, and the round-4 default of 48 (288 oracle forwards in ONE test) pushed the driver's `pytest -m gpu` past its
-# 1200 s limit (GPUTEST_r04: rc 124).  The 128-seed distribution is an artefact of tools/parity_sweep.py kept under profiles/, not
-# something the default collection recomputes.
+# This test runs TP_PARITY_SEEDS seeds and gates the WORST seed, the p90 and the median.  Default 12 (round 5): every seed is six fp64
+# CPU-oracle forwards, and the round-4 default of 48 (288 SERIAL oracle forwards in one test, ~1.4 s each) pushed the driver's
+# `pytest -m gpu` past its 1200 s limit (GPUTEST_r04: rc 124).  The sweep now prepares its CPU side on 8 threads ahead of the GPU loop
+# (4 seeds: 4.5 s on the r05q box; the whole 128-seed, 768-forward distribution: 130 s, profiles/r05q_parity_seed_sweep.json) — the
+# 128-seed distribution stays an artefact of tools/parity_sweep.py, not something the default collection recomputes.
 # (the absorbed schedule's query side: qt stays fp32 between the per-head query GEMM and the attention kernel — the tail of the
 # s = 3, 4 distributions was on the logit side: worst of the first 64 seeds 9.7e-4 / 1.05e-3 -> 9.0e-4 / 9.1e-4)
 GATES = {2: dict(worst=1.0e-3, p90=8.2e-4, median=7.0e-4), 3: dict(worst=1.0e-3, p90=8.2e-4, median=7.0e-4),
@@ -35,8 +36,8 @@ GATES = {2: dict(worst=1.0e-3, p90=8.2e-4, median=7.0e-4), 3: dict(worst=1.0e-3,
 def test_parity_seed_sweep_gated_on_the_worst_seed():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import parity_sweep
-    seeds = int(os.environ.get("TP_PARITY_SEEDS", "4"))
-    summary = parity_sweep.sweep(seeds, log=lambda m: print("\n" + m))
+    seeds = int(os.environ.get("TP_PARITY_SEEDS", "12"))
+    summary = parity_sweep.sweep(seeds, log=lambda m: print("\n" + m), workers=8)
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/parity_seed_sweep_test.json", "w") as f:
         json.dump(summary, f, indent=1)
