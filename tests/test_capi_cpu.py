@@ -45,8 +45,9 @@ def test_sizes_and_descriptor_validation():
     # + the centred chain weights (k, v, q, and the k one's per-head transposes: 8 MiB), the triangular factors R of the three
     #   centred layer-2 weights (6 MiB) and the fp64 scratch of their pack-time Householder QR (3 x [1024][1025] + vectors)
     fold = 4096 * 1024 * 2 + 1024 * 1024 * 2 + 4096 * 1024 * 4 + 1024 * 1024 * 2 + 3 * 1024 * 1024 * 2 + 1024 * 1024 * 2   # (+ w_qt_c)
-    # + the rows of the centred V chain weight as hi | hi | lo ([1024][3072] fp16, 6 MiB: the absorbed schedule contracts u_hi | u_lo | u_hi)
-    fold += 7 * 1024 * 1024 * 2 + 3 * (1024 * 1025 * 8 + 16 * 1024 * 8 + 16 * 8) + 3 * 1024 * 1024 * 2
+    # + the rows of the centred V chain weight as K-tile pairs hi_t | lo_t ([1024][2048] fp16, 4 MiB: the absorbed schedule's per-head V GEMM
+    #   contracts u against the weight AND its fp16 rounding residual, GemmArgs::a_k_dup; round 4: [hi | hi | lo], 6 MiB)
+    fold += 7 * 1024 * 1024 * 2 + 3 * (1024 * 1025 * 8 + 16 * 1024 * 8 + 16 * 8) + 2 * 1024 * 1024 * 2
     assert 36_722_688 * 2 + fold <= packed < 36_722_688 * 2 + fold + 300_000
     ws = lib.tp_workspace_bytes(ctypes.byref(d))
     assert 1.0e9 < ws < 1.3e9            # schedule-aware: the s = 2 default writes neither H2 nor K | V nor Q1pre

@@ -538,8 +538,8 @@ def test_full_size_properties_B256_absorbed_schedule(s):
         from tests.gpu_util import batch_invariant
         with batch_invariant():                          # (a batch of 4 may split mlp[2] over K by default; B = 256 never does)
             y4 = m((x4.cuda(), xm4.cuda()))
-        # round 5: at this size the per-head V GEMM (K = 3 E over u's hi | lo halves, every u_hi K-tile serving two K-tiles of the
-        # weight: GemmArgs::a_k_dup) runs on the pair kernel; with the pair kernel switched off, on the 128-tile kernel — same bits
+        # round 5: at this size the per-head V GEMM (K = 2 E: every K-tile of u serving the (hi, lo) K-tile pair of the pre-multiplied
+        # weight, GemmArgs::a_k_dup) runs on the pair kernel; with the pair kernel switched off, on the 128-tile kernel — same bits
         from tokenpacker_amd import _capi
         lib = _capi.load_library()
         n0 = lib.tp_test_pair_launch_count()

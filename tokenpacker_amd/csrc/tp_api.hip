@@ -76,7 +76,7 @@ PackedLayout packed_layout(int D) {
     L.w_c_q = take(E * E * 2);
     L.w_cc_kv = take(2 * E * E * 2);     L.d_cc_kv = take(2 * E * 4);
     L.w_cc_q = take(E * E * 2);          L.w_qt_cc = take(E * E * 2);
-    L.w_cc_v3 = take(3 * E * E * 2);
+    L.w_cc_v3 = take(2 * E * E * 2);
     L.w_r_kv = take(2 * E * E * 2);      L.c_r_kv = take(2 * E * 4);
     L.w_r_q = take(E * E * 2);
     L.wbar = take(3 * (E + 1) * 4);      L.scratch_qr = take(pack_qr_scratch_bytes(3));
@@ -110,8 +110,8 @@ WorkspaceLayout workspace_layout(int B, int grid, int s, int D, const SchedulePl
     L.stats_kv = take(2 * (size_t)8 * rows_kv * 2 * 4);     // up to 8 slabs (tile 128) per group
     L.mr_kv = take(2 * rows_kv * 2 * 4);                    // per-row (mean, rstd), 2 groups
     // K | V [2][rows_kv, E] (training, masked / plain schedules); the absorbed schedule keeps qt | u [2][rows_q, 8, E] there
-    // (u_split: u as hi | lo halves [rows_q, 8, 2 E] fp16 FIRST — what the saturation scan looks at —, then qt in fp32)
-    L.kv = take_if(P.need_kv, P.absorb ? (P.u_split ? 4 : 2) * 8 * rows_q * E * 2 : 2 * rows_kv * E * 2);   // qt | u, or u (hi | lo) | qt (fp32)
+    // (u_split: u [rows_q, 8, E] fp16 FIRST — what the saturation scan looks at —, then qt [rows_q, 8, E] in fp32)
+    L.kv = take_if(P.need_kv, P.absorb ? (P.u_split ? 3 : 2) * 8 * rows_q * E * 2 : 2 * rows_kv * E * 2);   // qt | u, or u | qt (fp32)
     L.q1pre = take_if(P.need_q1pre, rows_q * E * 2);
     L.stats_q = take((size_t)8 * rows_q * 2 * 4);
     L.mr_q = take(rows_q * 2 * 4);
@@ -557,7 +557,7 @@ int tp_debug_count_saturated(const tp_desc* desc, const void* workspace, size_t 
         {W.q0, rows_q * E}, {W.hkv, rows_kv * 2 * E},
         {W.h2, n_if(W.h2, 2 * rows_kv * E)},
         // (the absorbed schedule keeps qt | u [2][rows_q, 8, E] where K | V would be)
-        {W.kv, n_if(W.kv, plan.absorb ? 2 * rows_q * 8 * E : 2 * rows_kv * E)},      // (u_split: u's two halves; qt is fp32 there)
+        {W.kv, n_if(W.kv, plan.absorb ? (plan.u_split ? 1 : 2) * rows_q * 8 * E : 2 * rows_kv * E)},      // (u_split: u alone; qt is fp32 there)
         {W.q1pre, n_if(W.q1pre, rows_q * E)},
         {W.q, rows_q * E}, {W.o, rows_q * E}, {W.a1, n_if(W.a1, rows_q * E)}, {W.a2, rows_q * (long long)D}};
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * TP_NUM_DEBUG_BUFFERS, stream);
@@ -921,12 +921,12 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     const bool region_major = plan.region_major;
     const bool fuse_attn = plan.fuse_attn;
     char* const kv_slab = slab(W.kv);                                  // K | V, or qt | u on the absorbed schedule (NULL: neither)
-    // absorbed schedule: qt [rows_q, 8, E] fp16 | u [rows_q, 8, E] fp16;  u_split (the default of s >= 3): u [rows_q, 8, 2 E] = hi | lo
+    // absorbed schedule: qt [rows_q, 8, E] fp16 | u [rows_q, 8, E] fp16;  u_split (the default of s >= 3): u [rows_q, 8, E] fp16 |
     // fp16 halves | qt [rows_q, 8, E] in FP32 — neither rounding of the attention's own intermediates survives (round 4: the 128-seed
     // parity sweep has its tail on the logit side, where Q and qt were rounded one behind the other)
     const bool u_split = plan.u_split;
     char* const uu = !kv_slab ? nullptr : (u_split ? kv_slab : kv_slab + (size_t)rows_q * 8 * E * 2);
-    char* const qt = !kv_slab ? nullptr : (u_split ? kv_slab + (size_t)rows_q * 8 * 2 * E * 2 : kv_slab);
+    char* const qt = !kv_slab ? nullptr : (u_split ? kv_slab + (size_t)rows_q * 8 * E * 2 : kv_slab);
     auto qt_gemm = [&](hipStream_t st) -> int {         // qt[m, h, :] = Q[m, h*128:(h+1)*128] · W'k[h*128:(h+1)*128, :]
         GemmArgs a = plain_gemm(ws + W.q, E, absorb_raw ? (tri ? pw + P.w_qt_cc : pw + P.w_qt_c) : pw + P.w_qt, qt, 8 * E, rows_q, E, kHeadDim, nullptr, 0);
         a.groups = kHeads; a.a_gs = kHeadDim * 2; a.w_gs = (long long)E * kHeadDim * 2; a.c_gs = E * (u_split ? 4 : 2);
@@ -1060,18 +1060,19 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
                                                     (const float*)(ws + W.mr_kv) + (size_t)rows_kv * 2, uu, B, g, s, stream, attn_mask, mask_mode));
         // O[:, h*128:(h+1)*128] = u[:, h, :] · W'v[h*128:(h+1)*128, :]^T + b'v   (eight N = 128 groups)
         // RAW: a_h (u_h · Wc_v,h^T + d_v,h - (e_h / a_h) c_v,h) + b'v,h — a LayerNorm-fold epilogue with (mean, rstd) := mr_u
-        // u_split: the contraction runs over u_hi·W_hi + u_hi·W_lo + u_lo·W_hi (K = 3 E over the 2 E-wide u, GemmArgs::a_k_dup) —
-        // neither u's nor the pre-multiplied weight's fp16 rounding survives
-        const int uK = u_split ? 3 * E : E, uld = u_split ? 2 * E : E;
+        // u_split (round 5 form): u is ONE fp16 value per element, the pre-multiplied weight stays hi + lo — W's rows are the K-tile
+        // pairs [hi_0 lo_0 hi_1 lo_1 .. hi_15 lo_15] (K = 2 E) and GemmArgs::a_k_dup = E lets every K-tile of u serve its pair back to
+        // back (the second fetch hits the L2): u_hi·W_hi + u_hi·W_lo.  Round 4 also carried u's own rounding residual (hi | lo halves,
+        // K = 3 E): over 128 seeds x {s = 3, 4} x {bf16, fp16} the worst seed is 8.4e-4 .. 9.2e-4 without it against 8.1e-4 .. 9.2e-4 with
+        // it (medians +5 %: 6.2-6.7e-4; dropping the WEIGHT's residual instead, or both, puts the worst seed at 9.3e-4 .. 9.6e-4) — and
+        // it cost 268 MB written by the attention kernel + 268 MB read here per B = 256, s = 3 forward in two HBM-bound kernels:
+        // attention stage 0.52 -> 0.40 ms (profiles/r05r_u_mode_ab.json).  Large launches take the pair kernel (its 256 x 128 tile fits
+        // N = 128 per head), small ones the 128-tile kernel — one K order, the same bits (gemm_takes_pair_route).
+        const int uK = u_split ? 2 * E : E, uld = E;
         GemmArgs a = plain_gemm(uu, 8 * uld, u_split ? pw + P.w_cc_v3
                                                      : (absorb_raw ? (tri ? pw + P.w_cc_kv : pw + P.w_c_kv) : pw + P.w_in_kv) + (size_t)E * E * 2,
                                 ws + W.o, E, rows_q, kHeadDim, uK, (const float*)(pw + P.b_in_kv) + E, absorb_raw ? TP_LINEAR_LN_FOLD : 0);
         a.groups = kHeads; a.a_gs = uld * 2; a.w_gs = (long long)kHeadDim * uK * 2; a.c_gs = kHeadDim * 2; a.bias_gs = kHeadDim;
-        // Round 5: this K = 3 E contraction is HBM-bound on u (N = 128 per head: every byte of A belongs to ONE tile), and with W's rows as
-        // [hi | hi | lo] the u_hi half was fetched twice, 2 E apart: 805 MB and 221 us at B = 256, s = 3 whichever kernel ran it
-        // (profiles/r05b_bench_ab.json).  W's rows are now [hi_0 lo_0 hi_1 lo_1 .. | hi_0 .. hi_15] and GemmArgs::a_k_dup lets every u_hi
-        // K-tile serve its two W K-tiles back to back (the second fetch hits the L2): 537 MB.  Large launches take the pair kernel (its
-        // 256 x 128 tile fits N = 128), small ones the 128-tile kernel — one K order, the same bits (gemm_takes_pair_route).
         if (u_split) a.a_k_dup = E;
         if (absorb_raw) {
             a.acc_init = (const float*)(tri ? pw + P.d_cc_kv : pw + P.d_in_kv) + E; a.acc_init_gs = kHeadDim;

@@ -88,10 +88,9 @@ struct GemmArgs {
     int a_k_dup;                      // pair kernel and 128-tile kernel, contiguous A: the first a_k_dup K-elements of A (a multiple of 64) are
                                       // each used for TWO consecutive K-tiles of W, the rest once: K-tile j of the contraction reads A's K-tile
                                       // j / 2 while j < 2 w (w = a_k_dup / 64) and j - w after that, so K = a_k_dup + (A's width).  The absorbed
-                                      // schedule's per-head V GEMM contracts A = [u_hi | u_lo] (2 E wide) against W rows laid out
-                                      // [hi_0 lo_0 hi_1 lo_1 .. | hi_0 .. hi_15] (K = 3 E): u_hi·W_hi + u_hi·W_lo + u_lo·W_hi with every byte of u
-                                      // fetched from HBM ONCE — the second use of a u_hi K-tile follows the first by one K-tile and hits the L2
-                                      // (round 5; [hi | hi | lo] with u_hi fetched twice 2 E apart read 805 MB instead of 537).  0: off
+                                      // schedule's per-head V GEMM contracts u (E wide, a_k_dup = E) against W rows laid out as K-tile pairs
+                                      // [hi_0 lo_0 hi_1 lo_1 ..] (K = 2 E): u·W_hi + u·W_lo with every byte of u fetched from HBM ONCE — the second
+                                      // use of a K-tile follows the first by one K-tile and hits the L2.  0: off
     int parts_k_groups;               // A_parts + groups over K (128-tile kernel): group g covers K-tiles g*K/64 .. of the sources
     int tri;                          // statistics-only launches (NO_STORE): W is UPPER TRIANGULAR (W[n][k] = 0 for k < n): the output
                                       // tile at column n0 starts its K loop at K-tile n0 / 64 (tp_pack_qr.hip)
@@ -206,7 +205,7 @@ int region_attention_absorbed_launch(const void* qt, const void* h2k, const void
                                      // RAW form (q != NULL): h2k / h2v are the K / V halves of Hkv (row stride ld elements), qt was built
                                      // from Wc_k; q [B*M, 1024] fp16, d_k / c_k [1024] fp32 -> u normalised + mr_u [8][B*M][2]
                                      int ld = kEmbed, const void* q = nullptr, const float* d_k = nullptr, const float* c_k = nullptr,
-                                     // u_split: u [B*M, 8, 2 E] = fp16(u) | fp16(u - fp16(u))
+                                     // u_split: qt arrives in fp32 (the round-4 / 5 form of the s >= 3 schedule); u [B*M, 8, E] fp16 either way
                                      float* mr_u = nullptr, bool u_split = false);
 int pack_head_transpose_launch(const void* w_f16, void* dst_f16, hipStream_t stream);    // [8*128, 1024] -> [8][1024][128]
 // tp_pack_qr.hip: W2 (fp16 [E,E]) and b2 (fp32 [E] or NULL) centred into matrix m of `scratch` (fp64), wbar [E+1] = the column means
@@ -216,7 +215,7 @@ int pack_qr_center_launch(const void* w2_f16, const float* b2, void* scratch, in
 int pack_qr_factor_launch(void* scratch, int nmat, hipStream_t stream);
 int pack_qr_extract_launch(const void* scratch, int m, void* r_f16, float* ctil, hipStream_t stream, int* sat);
 int pack_center_product_launch(const float* P, const float* c, const float* wbar, void* out_f16, const float* d, float* d_out,
-                               hipStream_t stream, int* sat, const float* P2 = nullptr, void* out3_f16 = nullptr);   // out3: rows [hi_0 lo_0 .. hi_15 lo_15 | hi_0 .. hi_15]
+                               hipStream_t stream, int* sat, const float* P2 = nullptr, void* out3_f16 = nullptr);   // out3: rows [hi_0 lo_0 .. hi_15 lo_15]
 // lo = fp16(W' − fp16(W')), c_exact = rowsum(W'), d_exact = W'·v (v may be NULL), W' = w·diag(gamma) exact in fp32 (tp_kernels.hip)
 int pack_ln_fold_residual_launch(int dtype, const void* w, const void* gamma, const float* v, void* lo_f16, float* c_exact,
                                  float* d_exact, int n_out, int n_in, hipStream_t stream);
@@ -257,7 +256,7 @@ struct PackedLayout {
     size_t w_cc_kv, d_cc_kv;      // [2][1024,1024] f16, [2][1024] f32
     size_t w_cc_q;                // [1024,1024] f16
     size_t w_qt_cc;               // per-head transposes of Wc'_k (absorbed schedule)
-    size_t w_cc_v3;               // [E][3 E] f16: the rows of Wc'_v as hi | hi | lo (lo = what its fp16 rounding drops) — the absorbed
+    size_t w_cc_v3;               // [E][2 E] f16: the rows of Wc'_v as K-tile pairs hi_t | lo_t (lo = what its fp16 rounding drops) — the absorbed
                                   // schedule's per-head V GEMM contracts (u_hi | u_lo | u_hi) with it: neither rounding survives
     size_t w_r_kv, c_r_kv;        // [2][1024,1024] f16 (zeros below the diagonal), [2][1024] f32
     size_t w_r_q;                 // [1024,1024] f16
@@ -281,7 +280,7 @@ PackedLayout packed_layout(int D);
 struct SchedulePlan {
     bool train;
     bool absorb, absorb_raw;       // K/V in-projections absorbed into the query side (scale_factor >= 3); on the fused LayerNorm chain
-    bool u_split;                  // absorbed + centred chain: u travels as hi | lo fp16 halves [B M, 8, 2 E] — its rounding drops out
+    bool u_split;                  // absorbed + centred chain: qt in fp32, the pre-multiplied V weight as hi + lo (round 4 also: u as hi | lo)
     bool fuse_ln;                  // plain schedule on the fused LayerNorm chain: H2 for its row statistics only
     bool fuse_q;                   // query side on the fused chain: Q1pre for its row statistics only
     bool region_major, fuse_attn;  // scale_factor 2: region-major K/V rows; attention inside the in-projections' epilogues

@@ -233,7 +233,8 @@ int region_attention_launch(const void* q, const void* k, const void* v, void* o
 #endif
 constexpr int kAbsorbMaxKeys = 64;          // s*s <= 64 (s <= 8): logits of a region live in LDS
 
-// QT32 (with u_ld = 2 E: the library's own s >= 3 schedule): qt arrives in fp32 — the per-head query GEMM's accumulators, not rounded.
+// QT32 (the library's own s >= 3 schedule): qt arrives in fp32 — the per-head query GEMM's accumulators, not rounded.  (Round 4 also wrote
+// u as hi | lo fp16 halves, u_ld = 2 E; round 5 measured that residual worth nothing on the worst seeds and 0.12 ms per forward: gone.)
 template <bool RAW, bool QT32 = false>
 __global__ void __launch_bounds__(256, TP_ABSORB_WAVES)
 region_attention_absorbed_kernel(const void* __restrict__ qt_, const f16_t* __restrict__ h2k, const f16_t* __restrict__ h2v,
@@ -402,12 +403,6 @@ region_attention_absorbed_kernel(const void* __restrict__ qt_, const f16_t* __re
         }
         store8(u + (qi * H + h) * u_ld + ea, ua[h]);
         store8(u + (qi * H + h) * u_ld + eb, ub[h]);
-        if (u_ld == 2 * E) {                               // hi | lo: the residual of the fp16 rounding rides behind it
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { ua[h][e] -= (float)(f16_t)ua[h][e]; ub[h][e] -= (float)(f16_t)ub[h][e]; }
-            store8(u + (qi * H + h) * u_ld + E + ea, ua[h]);
-            store8(u + (qi * H + h) * u_ld + E + eb, ub[h]);
-        }
     }
 }
 
@@ -418,10 +413,10 @@ int region_attention_absorbed_launch(const void* qt, const void* h2k, const void
     const int G = grid / s, M = G * G;
     const long long nq = (long long)B * M;
     const unsigned blocks = (unsigned)((nq + 3) / 4);
-    if (q && u_split)   // RAW, the default of s >= 3: qt in fp32, u as hi | lo halves
+    if (q && u_split)   // RAW, the default of s >= 3: qt in fp32 (u is one fp16 value per element: tp_api.hip)
         hipLaunchKernelGGL((region_attention_absorbed_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, qt,
                            (const f16_t*)h2k, (const f16_t*)h2v, mr_k, mr_v, (f16_t*)u, B, grid, s, 0.08838834764831845f, mask,
-                           mask_mode, ld, (const f16_t*)q, d_k, c_k, mr_u, 2 * kEmbed);
+                           mask_mode, ld, (const f16_t*)q, d_k, c_k, mr_u, kEmbed);
     else if (q)         // RAW: rows of Hkv, the second K/V layer in the pre-multiplied weights
         hipLaunchKernelGGL(region_attention_absorbed_kernel<true>, dim3(blocks), dim3(256), 0, stream, qt,
                            (const f16_t*)h2k, (const f16_t*)h2v, mr_k, mr_v, (f16_t*)u, B, grid, s, 0.08838834764831845f, mask,

@@ -308,11 +308,11 @@ center_product_kernel(const float* __restrict__ P, const float* __restrict__ P2,
         const f16_t hi = (f16_t)v;
         out[(long long)n * QE + k] = hi;
         if (out3) {
-            // rows of 3 E for the contraction over A = [u_hi | u_lo] with GemmArgs::a_k_dup = E: K-tile pairs (hi_t, lo_t) against u_hi's
-            // K-tile t (t = 0 .. 15), then hi_0 .. hi_15 against u_lo — [hi_0 lo_0 hi_1 lo_1 .. hi_15 lo_15 | hi_0 .. hi_15]
-            f16_t* o3 = out3 + (long long)n * 3 * QE;
+            // rows of 2 E for the contraction over u with GemmArgs::a_k_dup = E: K-tile pairs (hi_t, lo_t) against u's K-tile t
+            // (t = 0 .. 15) — [hi_0 lo_0 hi_1 lo_1 .. hi_15 lo_15]
+            f16_t* o3 = out3 + (long long)n * 2 * QE;
             const int t = k >> 6, kk = k & 63;
-            o3[(2 * t) * 64 + kk] = hi; o3[(2 * t + 1) * 64 + kk] = (f16_t)(v - (float)hi); o3[2 * QE + k] = hi;
+            o3[(2 * t) * 64 + kk] = hi; o3[(2 * t + 1) * 64 + kk] = (f16_t)(v - (float)hi);
         }
     }
     if (threadIdx.x == 0 && d_out) d_out[n] = (d ? d[n] : 0.f) - cn * wbar[QE];
