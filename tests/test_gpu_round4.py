@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # (the absorbed schedule's query side: qt stays fp32 between the per-head query GEMM and the attention kernel — the tail of the
 # s = 3, 4 distributions was on the logit side: worst of the first 64 seeds 9.7e-4 / 1.05e-3 -> 9.0e-4 / 9.1e-4)
 # Round 5: at s = 3, 4 `u` is ONE fp16 value again (its hi | lo residual cost 0.12 ms per B = 256 forward in two HBM-bound kernels and
-# bought nothing on the worst seeds): 128 seeds, profiles/r05s_parity_seed_sweep.json — worst 8.4e-4 .. 9.2e-4 (every seed <= 9.3e-4 as
+# bought nothing on the worst seeds): 128 seeds, profiles/r05y_parity_seed_sweep.json — worst 8.4e-4 .. 9.2e-4 (every seed <= 9.3e-4 as
 # before), medians 6.2e-4 / 6.7e-4 (bf16 + fp32 output / fp16; +5 %), p90 7.2e-4 .. 8.1e-4.  The in-suite sample is 12 seeds: its median and
 # its second-largest value scatter around those, so the s = 3, 4 gates sit one sample-sigma above them; the worst-seed gate is 1e-3 everywhere.
 GATES = {2: dict(worst=1.0e-3, p90=8.2e-4, median=7.0e-4), 3: dict(worst=1.0e-3, p90=8.8e-4, median=7.5e-4),
