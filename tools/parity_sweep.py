@@ -37,7 +37,8 @@ def sweep(seeds, D=256, B=4, scale_factors=(2, 3, 4), log=print, tags=("bf16_fp3
     from concurrent.futures import ThreadPoolExecutor
     summary = {}
     pool = ThreadPoolExecutor(max_workers=workers) if workers > 0 else None
-    if pool:
+    threads_before = torch.get_num_threads()
+    if pool:                                                 # (restored below: the caller may be a test process with more to run)
         torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // workers)))
     for s, (dtype, tag) in itertools.product(scale_factors, ((torch.bfloat16, "bf16_fp32out"), (torch.float16, "fp16"))):
         if tag not in tags:
@@ -68,6 +69,7 @@ def sweep(seeds, D=256, B=4, scale_factors=(2, 3, 4), log=print, tags=("bf16_fp3
             f" | rel-L2 median {r['l2_median']:.3e} max {r['l2_max']:.3e}")
     if pool:
         pool.shutdown()
+        torch.set_num_threads(threads_before)
     return summary
 
 
