@@ -79,9 +79,11 @@ def main():
     ap.add_argument("--out", default="gpurun_out/parity_seed_sweep.json")
     ap.add_argument("--scale-factors", type=int, nargs="+", default=[2, 3, 4])
     ap.add_argument("--tags", nargs="+", default=["bf16_fp32out", "fp16"])
+    ap.add_argument("--hidden-size", type=int, default=256, help="D (256 keeps the oracle cheap; 4096 = the LLM width of the headline)")
+    ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--workers", type=int, default=16, help="threads preparing the CPU side of the seeds ahead of the GPU loop (0: serial)")
     args = ap.parse_args()
-    summary = sweep(args.seeds, scale_factors=tuple(args.scale_factors), tags=tuple(args.tags), workers=args.workers)
+    summary = sweep(args.seeds, D=args.hidden_size, B=args.batch, scale_factors=tuple(args.scale_factors), tags=tuple(args.tags), workers=args.workers)
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     json.dump(summary, open(args.out, "w"), indent=1)
 
