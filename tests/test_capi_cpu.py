@@ -253,6 +253,11 @@ def test_tuning_contexts_are_private_copies():
         assert lib.tp_tuning_set(None, 0, 0) == _capi.TP_ERR_INVALID_ARG and lib.tp_tuning_get(None, 0) == -1
     finally:
         a.close(); b.close()
+    # a CLOSED context must not silently fall back to the process-wide table: the caller asked for ITS knobs
+    import pytest
+    with pytest.raises(ValueError, match="closed"):
+        _capi.make_desc(1, 24, 2, 4096, _capi.TP_BF16, tuning=a)
+    assert _capi.make_desc(1, 24, 2, 4096, _capi.TP_BF16, tuning=None).tuning is None      # (None stays "the table")
 
 
 def test_gemm_routing_policy_is_host_logic_and_pinned():
