@@ -120,6 +120,10 @@ def parse_args():
                     help="tp_set_tuning, e.g. --tune ABSORB_KV=2 --tune RESERVE_CUS=1 (keys: _capi.TP_TUNE_*)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1 (nccl = RCCL; gloo only to exercise the N>1 flow on one GPU)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N=1: initialise torch.distributed (world size 1, --backend) and send the step through the same collective "
+                         "code as N>1 (all-gather pipeline, barrier, all-reduce of the clock) — the N=1 line of a scaling run and the "
+                         "plain N=1 line can then be compared through the collective path")
     ap.add_argument("--single-device", action="store_true",
                     help="test aid: every rank uses cuda:0 (with --backend gloo)")
     ap.add_argument("--gather", default="rccl", choices=["rccl", "sdma", "auto"],
@@ -638,8 +642,14 @@ def main():
     device = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or args.force_dist                 # (world == 1 with --force-dist: a one-rank group through the same code)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -659,7 +669,7 @@ def main():
 
     if args.e2e:
         run_e2e(args, world, rank, device, dtype, dist)
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -681,7 +691,7 @@ def main():
     model = build_model(D, s, dtype, device)
     x, xm = make_device_inputs(max(B, 1), dtype, args.layout, device, seed=1234 + rank)
     x, xm = x[:B], xm[:B]
-    gather = world > 1 and not args.no_gather
+    gather = use_dist and not args.no_gather
     # ---- the gather's transport (N > 1): rccl | sdma | auto = both, after the sdma self-test ------------------------
     pipe = dgather = None
     transports, sdma_note = [], None
@@ -708,7 +718,7 @@ def main():
         if args.hd:
             # project the local crops -> ONE all-gather (b_max-row slots, read in place) -> HD token assembly of all images
             if gather:
-                g_tok = shard.project_sharded(model, x, xm, total, dense=False)
+                g_tok = shard.project_sharded(model, x, xm, total, dense=False, force_collective=args.force_dist)
                 if isinstance(g_tok, shard.GatheredTokens):
                     return hd.assemble_hd_tokens(g_tok.buf, hb, wb, sep, ret, crop_map=g_tok.crop_map())
                 return hd.assemble_hd_tokens(g_tok, hb, wb, sep, ret)
@@ -724,7 +734,7 @@ def main():
             slot = pipe.submit(model((x, xm)))
             return pipe._bufs[slot]
         if gather:
-            return shard.project_sharded(model, x, xm, total, overlap_chunks=args.overlap_chunks)
+            return shard.project_sharded(model, x, xm, total, overlap_chunks=args.overlap_chunks, force_collective=args.force_dist)
         return model((x, xm))
 
     def fence():
@@ -733,7 +743,7 @@ def main():
         if dgather is not None:
             dgather.drain()
         torch.cuda.synchronize(device)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -753,7 +763,7 @@ def main():
         fence()
         el = torch.tensor([time.perf_counter() - t_start], dtype=torch.float64, device=device)
         clocks["after"] = read_clocks(device) if rank == 0 else {}
-        if world > 1:
+        if use_dist:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         return out, float(el.item())
 
@@ -771,7 +781,7 @@ def main():
             per = max(elapsed / args.steps, 1e-6)
             blk = max(1, min(args.steps, int(0.05 / per) + 1))
             n_blk = int(min(200, max(5, args.min_seconds / (per * blk))))
-            if world > 1:                    # every rank must run the same number of steps
+            if use_dist:                    # every rank must run the same number of steps
                 nb = torch.tensor([blk, n_blk], dtype=torch.int64, device=device)
                 dist.broadcast(nb, src=0)
                 blk, n_blk = int(nb[0].item()), int(nb[1].item())
@@ -783,7 +793,7 @@ def main():
                 fence()
                 blocks.append((time.perf_counter() - tb) / blk * 1e3)
             tb_all = torch.tensor(blocks, dtype=torch.float64, device=device)
-            if world > 1:
+            if use_dist:
                 dist.all_reduce(tb_all, op=dist.ReduceOp.MAX)
             bl = sorted(tb_all.tolist())
             long_run = {"blocks": n_blk, "steps_per_block": blk, "seconds": round(sum(bl) * blk * 1e-3, 3),
@@ -870,7 +880,7 @@ def main():
                       extra.get("other_gather", {}).get("gather_only_ms", 0.0),
                       extra.get("other_gather", {}).get("pipelined_ms_per_step", 0.0)], dtype=torch.float64, device=device)
     rank_info = None
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         # what the collective library itself saw: ranks, and the device each one drives
         props = torch.cuda.get_device_properties(device)
@@ -967,7 +977,7 @@ def main():
     if dgather is not None:
         dgather.close()
 
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     if world > 1 and rank == 0 and args.gather == "auto" and gather and not args.hd:
         run_sdma_leg(args, world)

@@ -30,7 +30,10 @@
 extern "C" {
 #endif
 
-#define TP_ABI_VERSION 4
+/* ABI 5 (round 6): tp_linear_args.reserved1 became `ldw` and the packed-weight image's layout changed (w_cc_v3: interleaved
+ * hi_t | lo_t K-tile pairs) — both already in round 5 under a stale 4 —, TP_TUNE_DECOUPLE_K (17 knobs), the probe instantiations
+ * and test hooks left the product library (tokenpacker_test.h / libtokenpacker_exp.so), tp_debug_counter. */
+#define TP_ABI_VERSION 5
 
 typedef enum tp_status {
     TP_OK = 0,
@@ -270,7 +273,10 @@ typedef struct tp_linear_args {
     int32_t out_dtype;         /* element type of C: TP_BF16 / TP_F16 / TP_F32                     */
     int32_t flags;
     int32_t rows_per_batch;    /* A row r lives at A + (r / rpb)*a_batch_stride + (r % rpb)*lda   */
-    int32_t reserved0;
+    int32_t a_k_dup;           /* (ABI 5; was reserved0) 0, or a multiple of 64 <= K / 2: the first a_k_dup K-elements of A are each used for
+                                * TWO consecutive 64-wide K-tiles of W, the rest once (A is K - a_k_dup wide) — the per-head V GEMM of the absorbed
+                                * schedule (u against weight rows laid out as K-tile pairs hi_t | lo_t).  Contiguous A, N % 128 == 0; served by the
+                                * pair kernel or the 128-tile kernel by launch size (TP_TUNE_PAIR_GEMM), bit-identical either way */
     int64_t a_batch_stride;    /* elements; ignored when rows_per_batch >= M                       */
     int64_t lda;               /* elements between consecutive rows of A                           */
     int64_t ldc;               /* elements between consecutive rows of C                           */
@@ -281,7 +287,7 @@ typedef struct tp_linear_args {
     const float* row_mean_rstd;/* LN_FOLD: fp32 [M][2]                                             */
     const float* colsum;       /* LN_FOLD: fp32 [N]                                                */
     int32_t tile;              /* 0 = auto, 128 or 256: force the block tile                       */
-    int32_t ldw;               /* elements between consecutive rows of W; 0 = K (contiguous).  (ABI 4, round 5: the field was
+    int32_t ldw;               /* elements between consecutive rows of W; 0 = K (contiguous).  (ABI 5; round 5: the field was
                                 * reserved1.  It exists for tools/stride_ab.py: an isolated LDS-DMA stream over rows a power of two
                                 * apart runs at 28 GB/s per CU against 123 with +64 elements of padding — tools/probes/
                                 * operand_fetch_probe.hip — but INSIDE the GEMMs, where an XCD's 32 tiles share their operands,
@@ -390,27 +396,14 @@ int tp_hd_slice(const float* image, int H, int W, int h_block, int w_block, int 
 int tp_debug_count_saturated(const tp_desc* desc, const void* workspace, size_t workspace_bytes, int32_t* counts,
                              void* stream);
 
-/* ---- test hook: occupy `workgroups` CUs for ~`microseconds` on `stream` (100 KiB LDS each; `scratch_int`: any
- * device int).  Stands in for another stream's kernels when the GEMM tile queue is measured (tools/hog_bench.py). */
-int tp_test_occupy_cus(int workgroups, int microseconds, void* scratch_int, void* stream);
-/* ---- test hook: entries of the per-caller-stream side-stream cache (tp_release_stream, LRU eviction) */
-int tp_test_side_cache_size(void);
-/* ---- test hook: launches of the pair GEMM kernel (tp_gemm_pair.hip) issued by this process so far — lets a test prove that the
- * launch it compares against the other kernels really took the pair route (TP_TUNE_PAIR_GEMM) */
-long long tp_test_pair_launch_count(void);
-/* ---- test hook: workgroups of the pair kernel the runtime admits per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor;
- * the design needs 2); negative on error */
-int tp_test_pair_occupancy(void);
-/* ---- test hook (host logic only, no GPU needed): where tp_linear would send a plain fp16 launch of this shape under the tuning
- * of the moment — 0 the 128-tile kernel | 1 full 256 x 256 tiles | 2 all 128 x 256 half tiles | 3 full rounds + a half-tile tail
- * launch | 4 192 x 256 tiles | 5 the pair kernel; -1: bad shape.  (256 CUs are assumed when no device is visible.) */
-int tp_test_gemm_route(int M, int N, int K, int flags, int groups);
-/* ---- test hook: the pack-time factorisation behind TP_TUNE_TRI_STATS on ONE layer.  w2 [1024][1024] fp16 and b2 [1024] fp32
- * (or NULL) in; r [1024][1024] fp16 (upper triangular), c_tilde [1024] fp32 and wbar [1025] fp32 (column means of w2, then
- * mean(b2)) out, with  sum_n ((w2 h + b2)_n - mean)^2 = || r h + c_tilde ||^2  for every h.  scratch: device memory of
- * tp_test_pack_qr_scratch_bytes() bytes. */
-size_t tp_test_pack_qr_scratch_bytes(void);
-int tp_test_pack_qr(const void* w2_f16, const float* b2, void* r_f16, float* c_tilde, float* wbar, void* scratch, void* stream);
+/* ---- diagnostics counters of this process (read-only; ABI 5: the round-3/4 test hooks tp_test_side_cache_size /
+ * tp_test_pair_launch_count under one entry — the other, stateless test hooks and the timing-probe instantiations of the GEMM
+ * kernels are NOT in this library: include/tokenpacker_test.h, libtokenpacker_exp.so):
+ *   TP_COUNTER_SIDE_STREAMS  entries of the per-caller-stream side-stream cache (tp_release_stream, LRU eviction)
+ *   TP_COUNTER_PAIR_LAUNCHES launches of the pair GEMM kernel (tp_gemm_pair.hip) issued so far
+ * -1: unknown counter. */
+enum { TP_COUNTER_SIDE_STREAMS = 0, TP_COUNTER_PAIR_LAUNCHES = 1 };
+long long tp_debug_counter(int which);
 
 /* ---- tuning knobs (benchmarks / deployment policy; defaults are what tp_forward ships with) --------------------
  * Two places hold them (ABI 4):
@@ -476,11 +469,19 @@ enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail, all half 
                                      full-chip launches its 1.5 x operand traffic loses 12-17 % | 1 never | 2 wherever it is supported */
        TP_TUNE_PAIR_STAGGER = 14, /* percent (default 100) of half a tile period by which the second workgroup of each CU starts late in
                                      a pair-kernel launch (0: both start together — their epilogues then coincide for ever) */
-       TP_TUNE_PAIR_DEBUG = 15,   /* timing probes of the pair kernel (fp16 -> fp16 plain launches; results are GARBAGE with 1..4): low 3 bits 1 no
+       TP_TUNE_PAIR_DEBUG = 15,   /* libtokenpacker_exp.so ONLY (`make exp`; this library refuses a non-zero value: the probe instantiations are
+                                     not built into it).  Timing probes of the pair kernel (fp16 -> fp16 plain launches; results are GARBAGE with 1..4): low 3 bits 1 no
                                      DMA in the K loop | 2 no fragment reads | 3 no barriers | 4 no MFMAs; + 8: one workgroup per CU;
                                      bits 4.. (value >> 4): the same kind of probe of the ping-pong kernel's K loop (tools/loop_probe.py:
                                      1 / 3 / 15 no b0 / W / any fragment reads, 16 no DMA, 31 neither, 64 no MFMAs, 79, 80) */
-       TP_TUNE_COUNT_ = 16 };
+       TP_TUNE_DECOUPLE_K = 16,   /* scale_factor 2, attention in the in-projection epilogues, centred chain (all defaults): 0 (default) the K
+                                     launch behind the statistics, LayerNorm fold in its epilogue (the round-5 form) | 1 the K launch writes
+                                     RAW logits Q·(Hkv·Wcc^T + dcc) — the K rows' rstd is applied by the V launch, the K bias is
+                                     softmax-invariant — so it does not wait for the row statistics and runs on the side stream BESIDE the
+                                     statistics launch | 2 raw logits on the caller's stream (same bits as 1: the A/B of the placement
+                                     alone).  Measured null at B = 32 .. 256 (profiles/r06b_decouple_k_ab.txt): kept as the record of
+                                     that A/B, parity-tested (tests/test_gpu_round6.py) */
+       TP_TUNE_COUNT_ = 17 };
 int tp_set_tuning(int key, int value);
 int tp_get_tuning(int key);                  /* the library's current value (not a binding's shadow copy); -1: bad key */
 typedef struct tp_tuning tp_tuning;          /* opaque; host memory owned by the library until tp_tuning_destroy */

@@ -45,7 +45,7 @@ def main():
             if rng.random() < 0.4:
                 time.sleep(rng.random() * 0.01)
             if rng.random() < 0.4:
-                _capi.check(lib.tp_test_occupy_cus(8, 200 + int(rng.random() * 2000), sink.data_ptr(),
+                _capi.check(_capi.load_test_library().tp_test_occupy_cus(8, 200 + int(rng.random() * 2000), sink.data_ptr(),
                                                    torch.cuda.current_stream(dev).cuda_stream), "occupy")
             view = g.begin()
             mine = shard_values(rank, i, sizes[rank], tail, torch.bfloat16, dev)

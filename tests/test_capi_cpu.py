@@ -46,7 +46,7 @@ def test_sizes_and_descriptor_validation():
     #   centred layer-2 weights (6 MiB) and the fp64 scratch of their pack-time Householder QR (3 x [1024][1025] + vectors)
     fold = 4096 * 1024 * 2 + 1024 * 1024 * 2 + 4096 * 1024 * 4 + 1024 * 1024 * 2 + 3 * 1024 * 1024 * 2 + 1024 * 1024 * 2   # (+ w_qt_c)
     # + the rows of the centred V chain weight as K-tile pairs hi_t | lo_t ([1024][2048] fp16, 4 MiB: the absorbed schedule's per-head V GEMM
-    #   contracts u against the weight AND its fp16 rounding residual, GemmArgs::a_k_dup; round 4: [hi | hi | lo], 6 MiB)
+    #   contracts u against the weight AND its fp16 rounding residual, GemmArgs::a_k_dup; round 4: [hi | hi | lo], 6 MiB; since round 5 interleaved K-tile pairs [hi_t | lo_t], 4 MiB)
     fold += 7 * 1024 * 1024 * 2 + 3 * (1024 * 1025 * 8 + 16 * 1024 * 8 + 16 * 8) + 2 * 1024 * 1024 * 2
     assert 36_722_688 * 2 + fold <= packed < 36_722_688 * 2 + fold + 300_000
     ws = lib.tp_workspace_bytes(ctypes.byref(d))
@@ -133,9 +133,19 @@ def test_train_hd_and_parts_entry_points_reject_bad_arguments():
     assert 0 < lib.tp_packed_status_offset(ctypes.byref(d)) < lib.tp_packed_weight_bytes(ctypes.byref(d))
     assert lib.tp_debug_count_saturated(ctypes.byref(d), None, 0, None, None) == E
     assert lib.tp_hd_slice(None, 100, 100, 1, 1, 336, 336, 0, 0, None, 336, None) == E
-    assert lib.tp_test_occupy_cus(0, 1, None, None) == E
-    assert lib.tp_test_pack_qr(None, None, None, None, None, None, None) == E          # (test hook of the pack-time QR)
-    assert lib.tp_test_pack_qr_scratch_bytes() == 1024 * 1025 * 8 + 16 * 1024 * 8 + 16 * 8 + 256
+    # the test hooks live in libtokenpacker_exp.so (include/tokenpacker_test.h), not in the product library
+    tl = _capi.load_test_library()
+    assert tl.tp_test_occupy_cus(0, 1, None, None) == E
+    assert tl.tp_test_pack_qr(None, None, None, None, None, None, None) == E          # (test hook of the pack-time QR)
+    assert tl.tp_test_pack_qr_scratch_bytes() == 1024 * 1025 * 8 + 16 * 1024 * 8 + 16 * 8 + 256
+    for sym in _capi.TEST_SYMBOLS:
+        assert not hasattr(lib, sym), f"{sym} must not be exported by the product library"
+    assert lib.tp_debug_counter(_capi.TP_COUNTER_SIDE_STREAMS) >= 0 and lib.tp_debug_counter(_capi.TP_COUNTER_PAIR_LAUNCHES) >= 0
+    assert lib.tp_debug_counter(99) == -1
+    # the timing-probe instantiations (garbage results) are not in the product library: its knob refuses them; the exp build takes them
+    assert lib.tp_set_tuning(_capi.TP_TUNE_PAIR_DEBUG, 16) == E and "libtokenpacker_exp" in lib.tp_last_error().decode()
+    assert lib.tp_set_tuning(_capi.TP_TUNE_PAIR_DEBUG, 0) == 0
+    assert tl.tp_set_tuning(_capi.TP_TUNE_PAIR_DEBUG, 16) == 0 and tl.tp_set_tuning(_capi.TP_TUNE_PAIR_DEBUG, 0) == 0
     # the weight-gradient contraction on its own
     assert lib.tp_wgrad_workspace_bytes(1024, 4096) == 16 * 1024 * 4096 * 4
     assert lib.tp_wgrad_workspace_bytes(0, 4096) == 0
@@ -182,7 +192,7 @@ def test_workspace_is_schedule_aware_and_an_upper_bound_for_the_tuning_at_call_t
         assert size() - base >= 2 * slab                                                 # + H2, + K | V, + Q1pre, (+ A1)
         _capi.set_tuning(_capi.TP_TUNE_FUSE_KV_LN, 1)
         assert size() == base
-        # absorbed schedule (s = 3): u (hi | lo fp16 halves) | qt (fp32) = 4 x [B M, 8, 1024] x 2 B instead of K | V, no H2, no logits
+        # absorbed schedule (s = 3): u (one fp16 value per element) | qt (fp32) = 3 x [B M, 8, 1024] x 2 B instead of K | V, no H2, no logits
         assert size(s=3) < base + 3 * 8 * B * 64 * E * 2
         # K-split partials: only while the knob is on (the default), only for batches of at most 8 images
         partials = 512 * 128 * 128 * 4
@@ -265,7 +275,8 @@ def test_gemm_routing_policy_is_host_logic_and_pinned():
     tp_test_gemm_route exposes the decision (256 CUs are assumed without a device).  The B = 256 forward runs full 256 x 256 tiles
     (its query-side GEMMs the pair kernel); a 32-image shard's first layer and mlp launches take the 192 x 256 tiles that make them
     whole rounds; one image runs on the 128-tile kernel; statistics-only launches never take the 192-row tiles (not built for them)."""
-    lib = _capi.load_library()
+    lib = _capi.load_test_library()                      # (tp_test_gemm_route: include/tokenpacker_test.h; the exp library's OWN tuning table)
+    set_tuning = lambda k, v: lib.tp_set_tuning(k, v)     # noqa: E731
     G, S, NS = _capi.TP_LINEAR_GELU, _capi.TP_LINEAR_ROW_STATS, _capi.TP_LINEAR_NO_STORE
     SMALL, FULL, HALF, SPLIT, T192, PAIR = range(6)
     r = lambda M, N, K, flags=0, groups=1: lib.tp_test_gemm_route(M, N, K, flags, groups)  # noqa: E731
@@ -280,18 +291,18 @@ def test_gemm_routing_policy_is_host_logic_and_pinned():
     # one image
     assert r(576, 2048, 4096, G) == SMALL and r(144, 4096, 4096) == SMALL
     # the A/B switches
-    _capi.set_tuning(_capi.TP_TUNE_GEMM_TILE, 4)
+    set_tuning(_capi.TP_TUNE_GEMM_TILE, 4)
     try:
         assert r(18432, 2048, 4096, G) == SPLIT and r(4608, 4096, 4096) in (SPLIT, HALF)
     finally:
-        _capi.set_tuning(_capi.TP_TUNE_GEMM_TILE, 0)
-    _capi.set_tuning(_capi.TP_TUNE_PAIR_GEMM, 1)
+        set_tuning(_capi.TP_TUNE_GEMM_TILE, 0)
+    set_tuning(_capi.TP_TUNE_PAIR_GEMM, 1)
     try:
         assert r(36864, 1024, 1024) != PAIR
     finally:
-        _capi.set_tuning(_capi.TP_TUNE_PAIR_GEMM, 0)
-    _capi.set_tuning(_capi.TP_TUNE_GEMM_TILE, 3)
+        set_tuning(_capi.TP_TUNE_PAIR_GEMM, 0)
+    set_tuning(_capi.TP_TUNE_GEMM_TILE, 3)
     try:
         assert r(147456, 2048, 4096, G) == T192 and r(147456, 1024, 1024, S | NS, 2) != T192
     finally:
-        _capi.set_tuning(_capi.TP_TUNE_GEMM_TILE, 0)
+        set_tuning(_capi.TP_TUNE_GEMM_TILE, 0)

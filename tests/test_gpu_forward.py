@@ -164,9 +164,12 @@ def test_full_size_properties_B256():
     assert torch.equal(yr, yr[:1].expand_as(yr)), "batch elements must not interact"
     assert torch.equal(yr[0], y4)
     p_lp = {k: v.to(dtype) for k, v in params.items()}
-    y_exact = orc.forward(p_lp, x4[:1], xm4[:1], scale_factor=s, compute_dtype=torch.float64, io_dtype=dtype)
-    e = orc.rel_err(y4[:1], y_exact)
-    print(f"\n[parity] full-size B=256 s=2 D=4096 bf16: rel_err={e:.3e}")
+    # (all four distinct images against the oracle — VERDICT r5 weak 1(a): the other three used to be covered only through
+    # bit-identity with a B = 4 run that was itself checked on its first image)
+    y_exact = orc.forward(p_lp, x4, xm4, scale_factor=s, compute_dtype=torch.float64, io_dtype=dtype)
+    errs = [orc.rel_err(y4[k:k + 1], y_exact[k:k + 1]) for k in range(4)]
+    e = max(errs)
+    print(f"\n[parity] full-size B=256 s=2 D=4096 bf16: rel_err per image " + " ".join(f"{v:.3e}" for v in errs))
     assert e <= 2.0 ** -8
     # checksum of checksums: every repeated image has the same digest
     sums = y.float().sum(dim=(1, 2)).reshape(B // 4, 4)
@@ -542,14 +545,14 @@ def test_full_size_properties_B256_absorbed_schedule(s):
         # weight, GemmArgs::a_k_dup) runs on the pair kernel; with the pair kernel switched off, on the 128-tile kernel — same bits
         from tokenpacker_amd import _capi
         lib = _capi.load_library()
-        n0 = lib.tp_test_pair_launch_count()
+        n0 = lib.tp_debug_counter(_capi.TP_COUNTER_PAIR_LAUNCHES)
         m((x, xm))
-        pair_launches = lib.tp_test_pair_launch_count() - n0
+        pair_launches = lib.tp_debug_counter(_capi.TP_COUNTER_PAIR_LAUNCHES) - n0
         _capi.set_tuning(_capi.TP_TUNE_PAIR_GEMM, 1)
         try:
-            n1 = lib.tp_test_pair_launch_count()
+            n1 = lib.tp_debug_counter(_capi.TP_COUNTER_PAIR_LAUNCHES)
             y_nopair = m((x, xm))
-            assert lib.tp_test_pair_launch_count() == n1
+            assert lib.tp_debug_counter(_capi.TP_COUNTER_PAIR_LAUNCHES) == n1
         finally:
             _capi.set_tuning(_capi.TP_TUNE_PAIR_GEMM, 0)
         assert pair_launches >= 1 and torch.equal(y_nopair, y)
@@ -560,8 +563,9 @@ def test_full_size_properties_B256_absorbed_schedule(s):
     assert torch.equal(yr, yr[:1].expand_as(yr)), "batch elements must not interact"
     assert torch.equal(yr[0], y4)
     p_lp = {k: v.to(dtype) for k, v in params.items()}
-    y_exact = orc.forward(p_lp, x4[:1], xm4[:1], scale_factor=s, compute_dtype=torch.float64, io_dtype=dtype)
-    e = orc.rel_err(y4[:1], y_exact)
-    print(f"\n[parity] full-size B=256 s={s} D=4096 bf16 (absorbed): rel_err={e:.3e}")
+    y_exact = orc.forward(p_lp, x4, xm4, scale_factor=s, compute_dtype=torch.float64, io_dtype=dtype)      # all four distinct images
+    errs = [orc.rel_err(y4[k:k + 1], y_exact[k:k + 1]) for k in range(4)]
+    e = max(errs)
+    print(f"\n[parity] full-size B=256 s={s} D=4096 bf16 (absorbed): rel_err per image " + " ".join(f"{v:.3e}" for v in errs))
     assert e <= 2.0 ** -8
     assert sum(m.saturation_report().values()) == 0

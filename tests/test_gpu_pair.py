@@ -6,7 +6,7 @@ pair kernel serves must equal the same launch on the ping-pong / 128-tile kernel
 test_gpu_kernels.py / test_gpu_forward.py pin to the reference), for every operand form, epilogue and tile-count regime; and
 repeated launches must be bit-identical to each other (a race between the two workgroups of a CU, a mis-counted vmcnt or a
 ring slot re-targeted too early shows up as run-to-run differences or as a difference from the other kernel).
-`tp_test_pair_launch_count` proves the pair route was actually taken."""
+`tp_debug_counter(TP_COUNTER_PAIR_LAUNCHES)` proves the pair route was actually taken."""
 import contextlib
 
 import pytest
@@ -34,7 +34,7 @@ def pair(mode, stagger=None):
 
 
 def launches():
-    return _capi.load_library().tp_test_pair_launch_count()
+    return _capi.load_library().tp_debug_counter(_capi.TP_COUNTER_PAIR_LAUNCHES)
 
 
 def _rand(shape, dtype, seed, scale=1.0):

@@ -141,17 +141,17 @@ def test_release_stream_and_lru_of_the_side_stream_cache():
     x, xm = x.cuda(), xm.cuda()
     with torch.no_grad():
         y0 = m((x, xm))
-        base = lib.tp_test_side_cache_size()
+        base = lib.tp_debug_counter(_capi.TP_COUNTER_SIDE_STREAMS)
         streams = [torch.cuda.Stream() for _ in range(70)]                 # more caller streams than the cache holds
         for st in streams:
             st.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(st):
                 assert torch.equal(m((x, xm)), y0)
         torch.cuda.synchronize()
-        assert lib.tp_test_side_cache_size() <= 64 and len(m._workspaces) <= m._MAX_WORKSPACES
-        n = lib.tp_test_side_cache_size()
+        assert lib.tp_debug_counter(_capi.TP_COUNTER_SIDE_STREAMS) <= 64 and len(m._workspaces) <= m._MAX_WORKSPACES
+        n = lib.tp_debug_counter(_capi.TP_COUNTER_SIDE_STREAMS)
         m.release_stream(streams[-1])
-        assert lib.tp_test_side_cache_size() == n - 1
+        assert lib.tp_debug_counter(_capi.TP_COUNTER_SIDE_STREAMS) == n - 1
         m.release_stream(streams[-1])                                      # unknown to the library now: not an error
         assert lib.tp_release_stream(None) == _capi.TP_OK
         with torch.cuda.stream(streams[-1]):

@@ -51,6 +51,22 @@ def test_parity_seed_sweep_gated_on_the_worst_seed():
         assert r["p90"] <= g["p90"] and r["median"] <= g["median"], (key, r["p90"], r["median"])
 
 
+# The worst seed of each recorded 128-seed distribution (profiles/r05y_parity_seed_sweep.json; tools/parity_sweep.py's seed numbering), as
+# NAMED regression cases: the 12-seed sample above no longer reaches the tail, these six forwards do.
+# A change of schedule moves low bits and with them WHICH seed is worst — re-mint the list from a fresh 128-seed artefact when the
+# s = 2 default or the absorbed schedule changes (round 6: the decoupled K launch; profiles/r06*_parity_seed_sweep.json).
+WORST_SEEDS = {"s2_bf16_fp32out": [100], "s2_fp16": [41], "s3_bf16_fp32out": [32], "s3_fp16": [62], "s4_bf16_fp32out": [7], "s4_fp16": [75]}
+
+
+def test_parity_worst_seeds_of_the_recorded_distributions():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import parity_sweep
+    summary = parity_sweep.sweep(0, log=lambda m: print("\n" + m), workers=6, seed_lists=WORST_SEEDS)
+    assert set(summary) == set(WORST_SEEDS)
+    for key, r in summary.items():
+        assert r["max"] <= 1.0e-3, (key, r["seed_list"], r["rel_max_per_seed"])
+
+
 def _inputs(B, dtype, seed=77):
     x, xm = synth.make_inputs(seed, B, dtype)
     return x.cuda(), xm.cuda()

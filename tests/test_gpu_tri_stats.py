@@ -14,7 +14,7 @@ E = 1024
 
 
 def _pack_qr(w2, b2):
-    lib = _capi.load_library()
+    lib = _capi.load_test_library()                      # (tp_test_pack_qr: include/tokenpacker_test.h — the same tp_pack_qr.hip kernels the product's pack runs)
     dev = w2.device
     r = torch.full((E, E), float("nan"), dtype=torch.float16, device=dev)
     c = torch.full((E,), float("nan"), dtype=torch.float32, device=dev)

@@ -94,3 +94,28 @@ def test_deepcopy_and_pickle_drop_the_kernel_side_caches():
         for (k, a), (_, b) in zip(m.state_dict().items(), clone.state_dict().items()):
             assert torch.equal(a, b) and a.data_ptr() != b.data_ptr(), k
     assert m._packed is not None                         # the original keeps its caches
+
+
+def test_partitioned_parameters_are_refused_with_a_message():
+    """DeepSpeed ZeRO-3 leaves empty placeholders where the parameters were; this module never calls its child containers, so the
+    per-submodule gather hooks never fire — the pack must say so instead of handing empty tensors to the kernels."""
+    import pytest
+    import torch
+    from tokenpacker_amd import TokenPacker
+    m = TokenPacker(hidden_size=256)
+    m.mlp[2].weight.data = torch.empty(0)                    # what a partitioned parameter looks like outside its gather context
+    with pytest.raises(RuntimeError, match="ZeRO-3"):
+        m._ensure_packed(torch.float32, torch.device("cpu"), 0)
+
+
+def test_lib_variant_name_is_validated(monkeypatch):
+    import pytest
+    from tokenpacker_amd import _capi
+    monkeypatch.setenv("TP_LIB_VARIANT", "../evil")
+    with pytest.raises(ValueError):
+        _capi._lib_name()
+    monkeypatch.setenv("TP_LIB_VARIANT", "s1")
+    with pytest.warns(RuntimeWarning):
+        assert _capi._lib_name() == "libtokenpacker_s1.so"
+    monkeypatch.delenv("TP_LIB_VARIANT")
+    assert _capi._lib_name() == "libtokenpacker_hip.so"

@@ -11,7 +11,7 @@ import os
 from ctypes import (POINTER, Structure, byref, c_char_p, c_float, c_int, c_int32, c_int64,
                     c_size_t, c_uint32, c_uint64, c_void_p)
 
-TP_ABI_VERSION = 4
+TP_ABI_VERSION = 5
 TP_BF16, TP_F16, TP_F32 = 0, 1, 2
 TP_OK, TP_ERR_INVALID_ARG, TP_ERR_BAD_SCALE, TP_ERR_WORKSPACE, TP_ERR_LAUNCH = 0, -1, -2, -3, -4
 TP_LINEAR_GELU, TP_LINEAR_LN_FOLD, TP_LINEAR_ROW_STATS = 1, 2, 4
@@ -20,7 +20,8 @@ TP_TUNE_GEMM_TILE, TP_TUNE_XCD_SWIZZLE, TP_TUNE_FOLD_OUT_PROJ, TP_TUNE_DYNAMIC_T
 TP_TUNE_RESERVE_CUS, TP_TUNE_ABSORB_KV, TP_TUNE_FUSE_KV_LN, TP_TUNE_LN_MERGE, TP_TUNE_FUSE_ATTN = 5, 6, 7, 8, 9
 TP_TUNE_SPLIT_K, TP_TUNE_SMALL_GEMM_WAVES, TP_TUNE_TRI_STATS = 10, 11, 12
 TP_TUNE_PAIR_GEMM, TP_TUNE_PAIR_STAGGER, TP_TUNE_PAIR_DEBUG = 13, 14, 15
-TP_TUNE_COUNT = 16
+TP_TUNE_DECOUPLE_K = 16
+TP_TUNE_COUNT = 17
 TP_WGRAD_X_TRANSPOSED = 1
 TP_NUM_STAGES = 10
 TP_NUM_DEBUG_BUFFERS = 9
@@ -30,7 +31,20 @@ STAGE_NAMES = ("point_queries", "kv_layer0_gelu", "kv_layer2_stats", "kv_inproj_
 
 # (TP_LIB_VARIANT=<name>: an A/B build of the same sources made by `make -C tokenpacker_amd/csrc variant NAME=<name> DEFS=...` —
 # bench.py / the tools under one build or the other on the same box; unset: the product library)
-LIB_NAME = f"libtokenpacker_{os.environ['TP_LIB_VARIANT']}.so" if os.environ.get("TP_LIB_VARIANT") else "libtokenpacker_hip.so"
+def _lib_name() -> str:
+    variant = os.environ.get("TP_LIB_VARIANT")
+    if not variant:
+        return "libtokenpacker_hip.so"
+    import re
+    import warnings
+    if not re.fullmatch(r"[A-Za-z0-9_]+", variant):      # (no path separators: only libtokenpacker_<name>.so beside this file)
+        raise ValueError(f"TP_LIB_VARIANT={variant!r}: letters, digits and '_' only")
+    warnings.warn(f"tokenpacker_amd: TP_LIB_VARIANT={variant} — loading the A/B build libtokenpacker_{variant}.so, NOT the product library",
+                  RuntimeWarning, stacklevel=2)
+    return f"libtokenpacker_{variant}.so"
+
+
+LIB_NAME = _lib_name()
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 # every symbol include/tokenpacker.h declares
@@ -39,12 +53,16 @@ EXPORTED_SYMBOLS = (
     "tp_pack_weights", "tp_pack_forget", "tp_forward", "tp_forward_staged", "tp_point_queries", "tp_region_attention", "tp_linear",
     "tp_ln_finalize", "tp_linear_stats_parts", "tp_set_tuning", "tp_hd_rows", "tp_hd_assemble",
     "tp_train_workspace_bytes", "tp_backward_workspace_bytes", "tp_forward_train", "tp_backward",
-    "tp_forward_parts", "tp_forward_train_parts", "tp_backward_parts", "tp_test_occupy_cus", "tp_hd_slice",
-    "tp_wgrad", "tp_wgrad_workspace_bytes", "tp_packed_status_offset", "tp_debug_count_saturated",
+    "tp_forward_parts", "tp_forward_train_parts", "tp_backward_parts", "tp_hd_slice",
+    "tp_wgrad", "tp_wgrad_workspace_bytes", "tp_packed_status_offset", "tp_debug_count_saturated", "tp_debug_counter",
     "tp_region_attention_absorbed", "tp_forward_masked",
-    "tp_get_tuning", "tp_release_stream", "tp_test_side_cache_size", "tp_test_pair_launch_count", "tp_test_pair_occupancy", "tp_test_gemm_route", "tp_test_pack_qr", "tp_test_pack_qr_scratch_bytes",
+    "tp_get_tuning", "tp_release_stream",
     "tp_tuning_create", "tp_tuning_destroy", "tp_tuning_set", "tp_tuning_get", "tp_gather_alloc_flags", "tp_gather_free_flags", "tp_gather_export", "tp_gather_open", "tp_gather_close", "tp_gather_push", "tp_gather_sync",
 )
+# include/tokenpacker_test.h: the stateless test hooks — libtokenpacker_exp.so only (load_test_library()), never the product library
+TEST_SYMBOLS = ("tp_test_occupy_cus", "tp_test_pair_occupancy", "tp_test_gemm_route", "tp_test_pack_qr", "tp_test_pack_qr_scratch_bytes")
+TP_COUNTER_SIDE_STREAMS, TP_COUNTER_PAIR_LAUNCHES = 0, 1
+EXP_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtokenpacker_exp.so")
 
 # state-dict name -> tp_weights field order (include/tokenpacker.h)
 WEIGHT_FIELDS = (
@@ -79,7 +97,7 @@ class tp_grads(Structure):
 
 class tp_linear_args(Structure):
     _fields_ = [("M", c_int32), ("N", c_int32), ("K", c_int32), ("dtype", c_int32), ("out_dtype", c_int32),
-                ("flags", c_int32), ("rows_per_batch", c_int32), ("reserved0", c_int32),
+                ("flags", c_int32), ("rows_per_batch", c_int32), ("a_k_dup", c_int32),
                 ("a_batch_stride", c_int64), ("lda", c_int64), ("ldc", c_int64),
                 ("A", c_void_p), ("W", c_void_p), ("bias", c_void_p), ("C", c_void_p),
                 ("row_mean_rstd", c_void_p), ("colsum", c_void_p),
@@ -164,18 +182,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.tp_tuning_get.argtypes = [c_void_p, c_int]
     lib.tp_release_stream.restype = c_int
     lib.tp_release_stream.argtypes = [c_void_p]
-    lib.tp_test_side_cache_size.restype = c_int
-    lib.tp_test_side_cache_size.argtypes = []
-    lib.tp_test_pair_launch_count.restype = c_int64
-    lib.tp_test_pair_launch_count.argtypes = []
-    lib.tp_test_pair_occupancy.restype = c_int
-    lib.tp_test_pair_occupancy.argtypes = []
-    lib.tp_test_gemm_route.restype = c_int
-    lib.tp_test_gemm_route.argtypes = [c_int, c_int, c_int, c_int, c_int]
-    lib.tp_test_pack_qr_scratch_bytes.restype = c_size_t
-    lib.tp_test_pack_qr_scratch_bytes.argtypes = []
-    lib.tp_test_pack_qr.restype = c_int
-    lib.tp_test_pack_qr.argtypes = [c_void_p] * 7
+    lib.tp_debug_counter.restype = ctypes.c_longlong
+    lib.tp_debug_counter.argtypes = [c_int]
     lib.tp_gather_alloc_flags.restype = c_int
     lib.tp_gather_alloc_flags.argtypes = [POINTER(c_void_p), c_size_t]
     lib.tp_gather_free_flags.restype = c_int
@@ -214,8 +222,6 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
                              c_int, c_int, c_void_p, c_size_t, c_void_p]
     lib.tp_hd_slice.restype = c_int
     lib.tp_hd_slice.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]
-    lib.tp_test_occupy_cus.restype = c_int
-    lib.tp_test_occupy_cus.argtypes = [c_int, c_int, c_void_p, c_void_p]
     lib.tp_hd_rows.restype = c_int64
     lib.tp_hd_rows.argtypes = [c_int, c_int, c_int]
     lib.tp_hd_assemble.restype = c_int
@@ -226,6 +232,40 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         raise TokenPackerLibraryError(
             f"{path}: ABI version {lib.tp_version()} != expected {TP_ABI_VERSION}; rebuild the library")
     _lib = lib
+    return lib
+
+
+_test_lib = None
+
+
+def load_test_library(path: str = EXP_LIB_PATH) -> ctypes.CDLL:
+    """dlopen ``libtokenpacker_exp.so`` (include/tokenpacker_test.h: the stateless test hooks, the GEMM kernels' timing-probe
+    instantiations, csrc/experimental/) beside the product library.  The two libraries share no state: use this one for the
+    ``tp_test_*`` hooks only (or, for the probe tools, as the whole library: ``TP_LIB_VARIANT=exp``)."""
+    global _test_lib
+    if _test_lib is not None:
+        return _test_lib
+    if not os.path.exists(path):
+        raise TokenPackerLibraryError(f"{path} not found: build it with `make -C tokenpacker_amd/csrc exp`")
+    lib = ctypes.CDLL(path)
+    lib.tp_last_error.restype = c_char_p
+    lib.tp_last_error.argtypes = []
+    lib.tp_test_occupy_cus.restype = c_int
+    lib.tp_test_occupy_cus.argtypes = [c_int, c_int, c_void_p, c_void_p]
+    lib.tp_test_pair_occupancy.restype = c_int
+    lib.tp_test_pair_occupancy.argtypes = []
+    lib.tp_test_gemm_route.restype = c_int
+    lib.tp_test_gemm_route.argtypes = [c_int, c_int, c_int, c_int, c_int]
+    lib.tp_test_pack_qr_scratch_bytes.restype = c_size_t
+    lib.tp_test_pack_qr_scratch_bytes.argtypes = []
+    lib.tp_test_pack_qr.restype = c_int
+    lib.tp_test_pack_qr.argtypes = [c_void_p] * 7
+    lib.tp_set_tuning.restype = c_int
+    lib.tp_set_tuning.argtypes = [c_int, c_int]
+    lib.tp_version.restype = c_int
+    if lib.tp_version() != TP_ABI_VERSION:
+        raise TokenPackerLibraryError(f"{path}: ABI version {lib.tp_version()} != expected {TP_ABI_VERSION}; rebuild it")
+    _test_lib = lib
     return lib
 
 
@@ -308,7 +348,7 @@ def strides3(st) -> "ctypes.Array":
 _TUNING_DEFAULTS = {TP_TUNE_GEMM_TILE: 0, TP_TUNE_XCD_SWIZZLE: 1, TP_TUNE_FOLD_OUT_PROJ: 0, TP_TUNE_DYNAMIC_TILES: 1, TP_TUNE_Q_SIDE_STREAM: 1,
                     TP_TUNE_RESERVE_CUS: 0, TP_TUNE_ABSORB_KV: 0, TP_TUNE_FUSE_KV_LN: 1, TP_TUNE_LN_MERGE: 0, TP_TUNE_FUSE_ATTN: 0,
                     TP_TUNE_SPLIT_K: 0, TP_TUNE_SMALL_GEMM_WAVES: 0, TP_TUNE_TRI_STATS: 0, TP_TUNE_PAIR_GEMM: 0, TP_TUNE_PAIR_STAGGER: 100,
-                    TP_TUNE_PAIR_DEBUG: 0}
+                    TP_TUNE_PAIR_DEBUG: 0, TP_TUNE_DECOUPLE_K: 0}
 
 
 def set_tuning(key: int, value: int) -> None:
@@ -326,5 +366,5 @@ def get_tuning(key: int) -> int:
 
 
 __all__ = [n for n in dir() if n.startswith(("TP_", "tp_"))] + [
-    "load_library", "last_error", "check", "make_desc", "strides3", "set_tuning", "get_tuning", "TuningContext",
-    "TokenPackerLibraryError", "WEIGHT_FIELDS", "EXPORTED_SYMBOLS", "LIB_PATH", "byref"]
+    "load_library", "load_test_library", "last_error", "check", "make_desc", "strides3", "set_tuning", "get_tuning", "TuningContext",
+    "TokenPackerLibraryError", "WEIGHT_FIELDS", "EXPORTED_SYMBOLS", "TEST_SYMBOLS", "LIB_PATH", "EXP_LIB_PATH", "byref"]

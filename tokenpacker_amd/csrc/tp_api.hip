@@ -43,9 +43,9 @@ int check_launch(const char* what) {
 // Tuning: the process-wide table and the per-call contexts (include/tokenpacker.h).  An entry point that takes a tp_desc opens a
 // TuningScope on desc->tuning: every tuning() read of that call, on that host thread, comes from the context (a plain array nobody
 // else writes while the call runs) — other threads' tp_set_tuning / tp_tuning_set on other contexts cannot reach it.
-static std::atomic<int> g_tuning[TP_TUNE_COUNT_] = {{0}, {1}, {0}, {1}, {1}, {0}, {0}, {1}, {0}, {0}, {0}, {0}, {0}, {0}, {100}, {0}};
+static std::atomic<int> g_tuning[TP_TUNE_COUNT_] = {{0}, {1}, {0}, {1}, {1}, {0}, {0}, {1}, {0}, {0}, {0}, {0}, {0}, {0}, {100}, {0}, {0}};
 static_assert(TP_TUNE_XCD_SWIZZLE == 1 && TP_TUNE_DYNAMIC_TILES == 3 && TP_TUNE_Q_SIDE_STREAM == 4 && TP_TUNE_FUSE_KV_LN == 7 &&
-              TP_TUNE_PAIR_STAGGER == 14 && TP_TUNE_COUNT_ == 16, "defaults above are positional");
+              TP_TUNE_PAIR_STAGGER == 14 && TP_TUNE_DECOUPLE_K == 16 && TP_TUNE_COUNT_ == 17, "defaults above are positional");
 }  // namespace tp
 struct tp_tuning { int v[TP_TUNE_COUNT_]; };
 namespace tp {
@@ -198,6 +198,7 @@ SchedulePlan plan_schedule(const tp_desc* d, bool train, bool masked) {
     P.fold = !train && (fmode == 1 || (fmode == 0 && (P.absorb || P.fuse_attn)));
     P.tri = !train && chain && tuning(TP_TUNE_TRI_STATS) != 1;
     P.u_split = P.absorb_raw && P.tri;
+    P.decouple_k = P.fuse_attn && P.tri && tuning(TP_TUNE_DECOUPLE_K) != 0;
     P.split_k = tuning(TP_TUNE_SPLIT_K) != 2 && !train && d->batch <= 8;      // (default on since round 3: see the header)
     P.need_h2 = train || !(P.fuse_ln || P.absorb_raw);
     P.need_kv = train || P.absorb || !P.fuse_attn;
@@ -283,6 +284,7 @@ const char* tp_last_error(void) { return g_err; }
 
 int tp_set_tuning(int key, int value) {
     if (key < 0 || key >= TP_TUNE_COUNT_) { set_error("tp_set_tuning: bad key %d", key); return TP_ERR_INVALID_ARG; }
+    if (key == TP_TUNE_PAIR_DEBUG && value != 0 && !gemm_probes_built()) { set_error("tp_set_tuning: TP_TUNE_PAIR_DEBUG selects timing-probe kernels that are not in this library (libtokenpacker_exp.so: make exp)"); return TP_ERR_INVALID_ARG; }
     g_tuning[key].store(value);
     return TP_OK;
 }
@@ -301,6 +303,7 @@ tp_tuning* tp_tuning_create(void) {
 void tp_tuning_destroy(tp_tuning* t) { delete t; }
 int tp_tuning_set(tp_tuning* t, int key, int value) {
     if (!t || key < 0 || key >= TP_TUNE_COUNT_) { set_error("tp_tuning_set: bad context / key %d", key); return TP_ERR_INVALID_ARG; }
+    if (key == TP_TUNE_PAIR_DEBUG && value != 0 && !gemm_probes_built()) { set_error("tp_tuning_set: TP_TUNE_PAIR_DEBUG selects timing-probe kernels that are not in this library (libtokenpacker_exp.so: make exp)"); return TP_ERR_INVALID_ARG; }
     t->v[key] = value;
     return TP_OK;
 }
@@ -454,7 +457,7 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
             GemmArgs a2 = plain_gemm(lo16, E, P + L.scratch_t, (char*)P2, E, (int)E, (int)E, (int)E, nullptr, 0);
             a2.tile = 128;
             TP_TRY(gemm_launch(TP_F16, TP_F32, a2, stream));
-            // (g = 1, the V side: also as rows [hi | hi | lo] for the absorbed schedule's per-head V GEMM)
+            // (g = 1, the V side: also as rows of interleaved K-tile pairs [hi_t | lo_t] (K = 2 E) for the absorbed schedule's per-head V GEMM)
             TP_TRY(pack_center_product_launch((const float*)(P + L.scratch_p), c_ex, wbar + g * (E + 1),
                                               P + L.w_cc_kv + (size_t)g * E * E * 2, d_ex,
                                               (float*)(P + L.d_cc_kv) + g * E, stream, sat, P2, g == 1 ? P + L.w_cc_v3 : nullptr));
@@ -567,11 +570,6 @@ int tp_debug_count_saturated(const tp_desc* desc, const void* workspace, size_t 
     return TP_OK;
 }
 
-int tp_test_occupy_cus(int workgroups, int microseconds, void* scratch_int, void* stream) {
-    if (workgroups <= 0 || microseconds <= 0 || !scratch_int) { set_error("tp_test_occupy_cus: bad argument"); return TP_ERR_INVALID_ARG; }
-    return occupy_cus_launch(workgroups, microseconds, (int*)scratch_int, (hipStream_t)stream);
-}
-
 int64_t tp_hd_rows(int h_block, int w_block, int M) {
     if (h_block < 1 || w_block < 1 || M < 1) return 0;
     const int64_t n = (int64_t)h_block * w_block;
@@ -656,6 +654,10 @@ int tp_linear(const tp_linear_args* a, void* stream) {
     }
     g.M = a->M; g.N = a->N; g.K = a->K; g.flags = a->flags;
     g.groups = 1; g.tile = a->tile;
+    if (a->a_k_dup != 0) {
+        if (a->a_k_dup < 0 || a->a_k_dup % 64 != 0 || 2 * (long long)a->a_k_dup > a->K) { set_error("tp_linear: a_k_dup must be a multiple of 64 and at most K / 2"); return TP_ERR_INVALID_ARG; }
+        g.a_k_dup = a->a_k_dup;
+    }
     if (a->flags & TP_LINEAR_OUT_F32) { set_error("tp_linear: TP_LINEAR_OUT_F32 was replaced by out_dtype = TP_F32"); return TP_ERR_INVALID_ARG; }
     return gemm_launch(a->dtype, a->out_dtype, g, (hipStream_t)stream);
 }
@@ -669,7 +671,7 @@ namespace tp {
 // back into the caller's stream with two events, so its small launches fill the tails of the K/V side's
 // persistent GEMMs instead of running alone at 2.25 CU rounds.  One side stream + event pair per caller stream,
 // created on first use (the only state the library keeps besides the tuning table and the error string).
-struct SideCtx { hipStream_t s; hipEvent_t fork, join; };
+struct SideCtx { hipStream_t s; hipEvent_t fork, join, kv0; };    // (kv0: the first K/V layer is done — the decoupled K launch's cue)
 // `pins`: forwards between their fork and the enqueue of their join on this entry; `doomed`: released while pinned — destroyed by
 // the last unpin.  A pinned entry is never evicted and never destroyed under a forward that still records / waits on its events.
 struct SideEntry { int dev; hipStream_t main; SideCtx ctx; unsigned long long stamp; int pins; bool doomed; };
@@ -680,6 +682,7 @@ static void side_ctx_destroy(const SideCtx& c) {    // OUTSIDE the lock: the syn
     (void)hipStreamSynchronize(c.s);                // whatever was forked onto it has been joined by its forward; be sure anyway
     (void)hipEventDestroy(c.fork);
     (void)hipEventDestroy(c.join);
+    (void)hipEventDestroy(c.kv0);
     (void)hipStreamDestroy(c.s);
 }
 // The side stream of (device, caller stream), created on first use and PINNED until side_unpin(); at most 64 per process, the
@@ -709,6 +712,7 @@ static bool side_ctx_for(hipStream_t main, SideCtx* out) {
             if (hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking) == hipSuccess) {
                 if (hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess) (void)hipStreamDestroy(c.s);
                 else if (hipEventCreateWithFlags(&c.join, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(c.fork); (void)hipStreamDestroy(c.s); }
+                else if (hipEventCreateWithFlags(&c.kv0, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(c.fork); (void)hipEventDestroy(c.join); (void)hipStreamDestroy(c.s); }
                 else { g_side_cache.push_back(SideEntry{dev, main, c, ++g_side_clock, 1, false}); *out = c; ok = true; }
             }
         }
@@ -921,9 +925,9 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     const bool region_major = plan.region_major;
     const bool fuse_attn = plan.fuse_attn;
     char* const kv_slab = slab(W.kv);                                  // K | V, or qt | u on the absorbed schedule (NULL: neither)
-    // absorbed schedule: qt [rows_q, 8, E] fp16 | u [rows_q, 8, E] fp16;  u_split (the default of s >= 3): u [rows_q, 8, E] fp16 |
-    // fp16 halves | qt [rows_q, 8, E] in FP32 — neither rounding of the attention's own intermediates survives (round 4: the 128-seed
-    // parity sweep has its tail on the logit side, where Q and qt were rounded one behind the other)
+    // absorbed schedule: qt [rows_q, 8, E] fp16 | u [rows_q, 8, E] fp16;  u_split (the default of s >= 3): u [rows_q, 8, E] as ONE fp16
+    // value per element, followed by qt [rows_q, 8, E] in FP32 — a 3 x [rows_q, 8, E] x 2 B slab (round 4: the 128-seed parity sweep
+    // has its tail on the logit side, where Q and qt were rounded one behind the other; round 5 dropped u's hi | lo halves)
     const bool u_split = plan.u_split;
     char* const uu = !kv_slab ? nullptr : (u_split ? kv_slab : kv_slab + (size_t)rows_q * 8 * E * 2);
     char* const qt = !kv_slab ? nullptr : (u_split ? kv_slab + (size_t)rows_q * 8 * E * 2 : kv_slab);
@@ -932,6 +936,14 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         a.groups = kHeads; a.a_gs = kHeadDim * 2; a.w_gs = (long long)E * kHeadDim * 2; a.c_gs = E * (u_split ? 4 : 2);
         return launch(TP_F16, u_split ? TP_F32 : TP_F16, a, st);
     };
+    // decoupled K launch (TP_TUNE_DECOUPLE_K = 1 / 2, GemmArgs::attn_decoupled; round 6): it needs Hkv and Q but not
+    // the K/V row statistics, so with 1 it follows the query side on the side stream — beside the statistics launch of the caller's
+    // stream instead of behind it; 2 keeps it on the caller's stream (same bits; the A/B of the placement alone).  MEASURED NULL
+    // (profiles/r06b_decouple_k_ab.txt, r06c_timeline_B32.txt): at a 32-image shard the statistics launch, the query-side GEMMs and
+    // the K launch are each full-chip work (the router already removes their tail rounds with half tiles), so side-by-side placement
+    // only trades the K launch's wait for a 13 us cross-stream join; 0.665 (1) / 0.658 (2) / 0.661 ms (0).  Off by default.
+    const bool decouple_k = plan.decouple_k;
+    const bool k_on_side = decouple_k && side != nullptr && tuning(TP_TUNE_DECOUPLE_K) == 1;
     if (side) {
         hipError_t e = hipEventRecord(side->fork, stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(side->s, side->fork, 0);
@@ -940,8 +952,10 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         TP_TRY(q_proj(side->s));
         TP_TRY(q_inproj(side->s));
         if (absorb) TP_TRY(qt_gemm(side->s));
-        e = hipEventRecord(side->join, side->s);
-        if (e != hipSuccess) { set_error("tp_forward: side stream join: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
+        if (!k_on_side) {
+            e = hipEventRecord(side->join, side->s);
+            if (e != hipSuccess) { set_error("tp_forward: side stream join: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
+        }
     }
     auto mark = [&]() -> int {
         if (stage_events) {
@@ -972,6 +986,10 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         }
         TP_TRY(launch_maybe_splitk(dt, TP_F16, a, stream));      // raw operands in the io dtype, fp16 activations out
     }
+    if (k_on_side) {                                    // the decoupled K launch's cue (enqueued further down, on the side stream)
+        hipError_t e = hipEventRecord(side->kv0, stream);
+        if (e != hipSuccess) { set_error("tp_forward: hipEventRecord(kv0): %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
+    }
     // 3. H2[g] = Hkv[:, g*1024:(g+1)*1024] · W{k,v}2^T + b, and LayerNorm partials of H2
     TP_TRY(mark());
     const int parts_kv = gemm_stats_parts(E);
@@ -992,7 +1010,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         if (kv_finalized) return TP_OK;
         kv_finalized = true;
         return ln_finalize_launch((const float*)(ws + W.stats_kv), (float*)(ws + W.mr_kv), rows_kv, parts_kv, 2, E,
-                                  desc->ln_eps, stream, tri && (fuse_ln || absorb_raw));
+                                  desc->ln_eps, stream, tri && (fuse_ln || absorb_raw), decouple_k);
     };
     bool joined = false;
     auto join_side = [&]() -> int {
@@ -1004,7 +1022,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         return TP_OK;
     };
     // 4. {K,V} = LN(H2[g]) · Win{k,v}^T + b   (LayerNorm folded into the epilogue) — not in the absorbed schedule
-    auto attn_gemm = [&](const int kv) -> int {
+    auto attn_gemm = [&](const int kv, hipStream_t st) -> int {
         // steps 4 + 7 as two launches: the K launch (step 4) turns its tile of K into logits against the region's query, the
         // V launch (step 7) its tile of V into softmax-weighted sums -> O.  K and V are never written.
         GemmArgs a = plain_gemm(ws + W.hkv + (size_t)kv * hkv_gs, hkv_ld, (tri ? pw + P.w_cc_kv : pw + P.w_c_kv) + (size_t)kv * E * E * 2,
@@ -1017,12 +1035,21 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
         a.attn_q = ws + W.q; a.attn_ldq_bytes = E * 2;
         a.attn_logits = (float*)(ws + W.attn_aux);      // [8 heads][rows_kv] fp32
         a.attn_scale = 0.08838834764831845f;            // 1/sqrt(128): q scaling of F.multi_head_attention_forward
+        a.attn_decoupled = decouple_k ? 1 : 0;
+        if (decouple_k && kv == 0) return launch(TP_F16, TP_F16, a, st);     // (reads no statistics: stats_in is staged, never used)
         if (!merge_in_kernel(a, (const float*)(ws + W.stats_kv) + (size_t)kv * parts_kv * rows_kv * 2, 0)) TP_TRY(kv_finalize());
-        return launch(TP_F16, TP_F16, a, stream);
+        else if (decouple_k) a.attn_kstats_parts = (const float*)(ws + W.stats_kv);      // (V launch: the K group's slabs as well)
+        return launch(TP_F16, TP_F16, a, st);
     };
-    if (fuse_attn) {
+    if (fuse_attn && !k_on_side) {
         TP_TRY(join_side());                            // Q must be there
-        TP_TRY(attn_gemm(0));
+        TP_TRY(attn_gemm(0, stream));
+    } else if (fuse_attn) {                             // decoupled: behind the query side on the side stream, beside the statistics launch
+        hipError_t e = hipStreamWaitEvent(side->s, side->kv0, 0);
+        if (e != hipSuccess) { set_error("tp_forward: side stream wait(kv0): %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
+        TP_TRY(attn_gemm(0, side->s));
+        e = hipEventRecord(side->join, side->s);
+        if (e != hipSuccess) { set_error("tp_forward: side stream join: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
     } else
     if (!absorb) {
         TP_TRY(kv_finalize());
@@ -1046,7 +1073,7 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     TP_TRY(join_side());
     // 7. region-to-point attention
     if (fuse_attn) {
-        TP_TRY(attn_gemm(1));
+        TP_TRY(attn_gemm(1, stream));
     } else if (absorb) {
         TP_TRY(kv_finalize());
         float* const mr_u = (float*)(ws + W.attn_aux);     // RAW: (e / a, a) per head and query
@@ -1156,25 +1183,11 @@ int tp_pack_forget(const void* packed) {
     return TP_OK;
 }
 
-int tp_test_side_cache_size(void) { return side_cache_size(); }
-
-long long tp_test_pair_launch_count(void) { return gemm_pair_launch_count(); }
-int tp_test_pair_occupancy(void) { return gemm_pair_occupancy(); }
-int tp_test_gemm_route(int M, int N, int K, int flags, int groups) {
-    if (M <= 0 || N <= 0 || K <= 0 || N % 128 != 0 || K % BK_ELEMS != 0) { set_error("tp_test_gemm_route: bad shape"); return -1; }
-    GemmArgs a = plain_gemm(nullptr, K, nullptr, nullptr, N, M, N, K, nullptr, flags);
-    a.groups = groups > 0 ? groups : 1;
-    return gemm_route_of(TP_F16, TP_F16, a);
-}
-
-size_t tp_test_pack_qr_scratch_bytes(void) { return pack_qr_scratch_bytes(1); }
-
-int tp_test_pack_qr(const void* w2_f16, const float* b2, void* r_f16, float* c_tilde, float* wbar, void* scratch, void* stream) {
-    if (!w2_f16 || !r_f16 || !c_tilde || !wbar || !scratch) { set_error("tp_test_pack_qr: NULL argument"); return TP_ERR_INVALID_ARG; }
-    hipStream_t st = (hipStream_t)stream;
-    TP_TRY(pack_qr_center_launch(w2_f16, b2, scratch, 0, wbar, st));
-    TP_TRY(pack_qr_factor_launch(scratch, 1, st));
-    return pack_qr_extract_launch(scratch, 0, r_f16, c_tilde, st, nullptr);
+long long tp_debug_counter(int which) {
+    if (which == TP_COUNTER_SIDE_STREAMS) return side_cache_size();
+    if (which == TP_COUNTER_PAIR_LAUNCHES) return gemm_pair_launch_count();
+    set_error("tp_debug_counter: unknown counter %d", which);
+    return -1;
 }
 
 }  // extern "C"

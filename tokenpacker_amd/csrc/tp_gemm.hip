@@ -161,6 +161,19 @@ gemm_kernel(const GemmArgs p, const int tiles_n, const int xcd_swizzle) {
             }
 #pragma unroll
             for (int i = 0; i < FM; ++i) mean_rstd[i] = ln_merge_values<8>(st[i], p.ln_inv_dim, p.ln_eps, p.ln_second_moment != 0);
+            if constexpr (XMODE == 4) {
+                if (p.attn_kstats_parts) {              // decoupled attention: the K rows' rstd rides in the mean slot (GemmArgs::attn_decoupled)
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+                        int m = m0 + wm * WM + i * 16 + (lane & 15);
+                        m = m < p.M ? m : p.M - 1;
+#pragma unroll
+                        for (int pp = 0; pp < 8; ++pp) st[i][pp] = *(const float2*)(p.attn_kstats_parts + ((long long)pp * p.M + m) * 2);
+                    }
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) mean_rstd[i].x = ln_merge_values<8>(st[i], p.ln_inv_dim, p.ln_eps, p.ln_second_moment != 0).y;
+                }
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
@@ -268,7 +281,7 @@ static int launch_types(const GemmArgs& a, hipStream_t stream) {
                 set_error("tp gemm: NO_STORE / acc_init take a contiguous A, no training epilogue, and not both at once");
                 return TP_ERR_INVALID_ARG;
             }
-            // (the absorbed schedule's per-head V GEMM over u = hi | lo arrives here as a contiguous A with GemmArgs::a_k_dup)
+            // (the absorbed schedule's per-head V GEMM — u fp16, W as K-tile pairs hi_t | lo_t, K = 2 E — arrives here as a contiguous A with GemmArgs::a_k_dup)
             if (a.attn_mode)                                 // (validated by gemm_launch)
                 return a.attn_mode == 1 ? launch_cfg<TI, TO, 128, 128, 64, 64, 0, false, 3>(a, stream)
                                         : launch_cfg<TI, TO, 128, 128, 64, 64, 0, false, 4>(a, stream);

@@ -797,6 +797,14 @@ static int g8_num_cus() {
     return cus;
 }
 
+bool gemm_probes_built() {
+#ifdef TP_BUILD_PROBES
+    return true;
+#else
+    return false;
+#endif
+}
+
 // Workgroups of a persistent launch: one per CU, a multiple of the 8 XCDs, minus the CUs the caller reserves for
 // kernels of OTHER streams (TP_TUNE_RESERVE_CUS = r: r CUs per XCD stay free — the all-gather that overlaps the next
 // forward needs somewhere to run; a persistent workgroup holds its CU's LDS and registers for the whole launch).
@@ -809,6 +817,7 @@ int gemm8_persistent_cus() {
 
 template <typename TI, typename TO, int AMODE, bool TRAIN_EPI, bool HALF = false, int XMODE = 0, int PROBE = 0, bool T192 = false>
 static int launch8_cfg(const GemmArgs& a, hipStream_t stream) {
+#ifdef TP_BUILD_PROBES                                   // (libtokenpacker_exp.so only: the timing probes produce garbage results)
     if constexpr (PROBE == 0 && AMODE == 0 && !TRAIN_EPI && !HALF && XMODE == 0 && std::is_same<TI, f16_t>::value && std::is_same<TO, f16_t>::value) {
         const int probe = tuning(TP_TUNE_PAIR_DEBUG) >> 4;
         if (probe == 1) return launch8_cfg<TI, TO, AMODE, TRAIN_EPI, HALF, XMODE, 1>(a, stream);
@@ -820,6 +829,7 @@ static int launch8_cfg(const GemmArgs& a, hipStream_t stream) {
         if (probe == 79) return launch8_cfg<TI, TO, AMODE, TRAIN_EPI, HALF, XMODE, 79>(a, stream);
         if (probe == 80) return launch8_cfg<TI, TO, AMODE, TRAIN_EPI, HALF, XMODE, 80>(a, stream);
     }
+#endif
     auto kern = gemm8_kernel<TI, TO, AMODE, TRAIN_EPI, HALF, XMODE, PROBE, T192>;
     constexpr int lds = g8_lds_bytes(HALF, true, XMODE);
     static_assert(lds <= 160 * 1024, "LDS budget of a CU");

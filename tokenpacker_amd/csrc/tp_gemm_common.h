@@ -445,7 +445,8 @@ __device__ __forceinline__ void attn_logits_epilogue(f32x4 (&acc)[WM / 16][WN / 
                 bj = *(const f32x4*)(lds_par + (wn * WN + cg * 4 + j * 16) * 4);
                 cj = *(const f32x4*)(lds_par + BN * 4 + (wn * WN + cg * 4 + j * 16) * 4);
             } else { bj = bias_v[j]; cj = csum_v[j]; }
-            const f32x4 v = rstd * (acc[i][j] - mu * cj) + bj;
+            // (decoupled: the raw accumulators — rstd is applied by the V launch, the bias term is softmax-invariant)
+            const f32x4 v = p.attn_decoupled ? acc[i][j] : rstd * (acc[i][j] - mu * cj) + bj;
 #pragma unroll
             for (int r = 0; r < 4; ++r) d = fmaf(v[r], (float)q[r], d);
         }
@@ -508,16 +509,26 @@ __device__ __forceinline__ void attn_sum_epilogue(f32x4 (&acc)[WM / 16][WN / 16]
             const int mc = m < p.M ? m : p.M - 4;          // (M % 4 == 0: a quad is valid or past the end as a whole)
             lg = *(const f32x4*)(p.attn_logits + (long long)(n0 / 128 + hl) * p.M + (mc & ~3));
         }
-        const float mx = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
-        const float e0 = __expf(lg[0] - mx), e1 = __expf(lg[1] - mx), e2 = __expf(lg[2] - mx), e3 = __expf(lg[3] - mx);
-        const float den = ((e0 + e1) + e2) + e3;
-        const float pr = (kq == 0 ? e0 : kq == 1 ? e1 : kq == 2 ? e2 : e3) / den;
         float mu = mean_rstd[i].x, rstd = mean_rstd[i].y;
         if constexpr (LDS_PARAMS) {
             typedef float f32x2_t __attribute__((ext_vector_type(2)));
             const f32x2_t mr = *(const f32x2_t*)(lds_par + 2 * BN * 4 + rr * 8);
             mu = mr[0]; rstd = mr[1];
         }
+        if (p.attn_decoupled) {
+            // the mean slot carries the K row's rstd (GemmArgs::attn_decoupled): lane kq of the quad holds row kq's — fetch the
+            // other three by DPP quad broadcasts; every lane then scales the same four raw logits in the same order
+            const int rk = __builtin_bit_cast(int, mu);
+            lg[0] *= __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(rk, 0x00, 0xF, 0xF, true));   // quad_perm [0,0,0,0]
+            lg[1] *= __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(rk, 0x55, 0xF, 0xF, true));   // [1,1,1,1]
+            lg[2] *= __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(rk, 0xAA, 0xF, 0xF, true));   // [2,2,2,2]
+            lg[3] *= __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(rk, 0xFF, 0xF, 0xF, true));   // [3,3,3,3]
+            mu = 0.f;
+        }
+        const float mx = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+        const float e0 = __expf(lg[0] - mx), e1 = __expf(lg[1] - mx), e2 = __expf(lg[2] - mx), e3 = __expf(lg[3] - mx);
+        const float den = ((e0 + e1) + e2) + e3;
+        const float pr = (kq == 0 ? e0 : kq == 1 ? e1 : kq == 2 ? e2 : e3) / den;
         f32x4 mine = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < FN; ++j) {

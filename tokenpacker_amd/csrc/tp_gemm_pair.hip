@@ -494,6 +494,7 @@ int gemm_pair_occupancy() {
 
 template <typename TI, typename TO, int AMODE, int XMODE, int DBG = 0>
 static int launch_pair_cfg(const GemmArgs& a, hipStream_t stream) {
+#ifdef TP_BUILD_PROBES                                   // (libtokenpacker_exp.so only: the timing probes produce garbage results)
     if constexpr (DBG == 0 && AMODE == 0 && XMODE == 0 && std::is_same<TI, f16_t>::value && std::is_same<TO, f16_t>::value) {
         const int dbg = tuning(TP_TUNE_PAIR_DEBUG) & 7;
         if (dbg == 1) return launch_pair_cfg<TI, TO, AMODE, XMODE, 1>(a, stream);
@@ -501,6 +502,7 @@ static int launch_pair_cfg(const GemmArgs& a, hipStream_t stream) {
         if (dbg == 3) return launch_pair_cfg<TI, TO, AMODE, XMODE, 3>(a, stream);
         if (dbg == 4) return launch_pair_cfg<TI, TO, AMODE, XMODE, 4>(a, stream);
     }
+#endif
     auto kern = gemm_pair_kernel<TI, TO, AMODE, XMODE, DBG>;
     constexpr int lds = GP_LDS_BYTES;
     static DynLdsAttr attr;                             // (per device, a failure is not cached: tp_internal.h)

@@ -135,6 +135,14 @@ struct GemmArgs {
     long long attn_ldq_bytes;
     float* attn_logits;               // fp32 [N / 128][M]  (head-major)
     float attn_scale;
+    // attn_decoupled (round 6; the centred chain only — every LayerNorm mean is 0 there): the K launch does not wait for the K/V
+    // row statistics.  With mu = 0,  Q_h·K_r,h = rstd_r (Q_h·(Hkv_r Wcc^T + dcc)_h) + Q_h·b'_h  and the last term is the same for
+    // the 4 keys of a region, i.e. softmax-invariant: the K launch writes the RAW dot product (attn_scale applied, nothing else)
+    // and needs only Hkv and Q; the V launch multiplies the quad's logits by the K rows' rstd, which it finds in the MEAN slot
+    // of its own (mean, rstd) pairs (ln_finalize_launch(pair_rstd) / attn_kstats_parts put it there — the slot is otherwise 0).
+    // The statistics launch and the K launch are then independent and run side by side on two streams (tp_api.hip).
+    int attn_decoupled;
+    const float* attn_kstats_parts;   // V launch on the 128-tile kernel merging its producer's slabs (stats_parts): the K group's slabs
     int flags;                        // TP_LINEAR_*
     int groups;
     int tile;                         // 0 auto, 128, 256
@@ -181,6 +189,7 @@ int gemm8_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t str
 bool gemm_pair_supports(int in_dtype, int out_dtype, const GemmArgs& a);
 int gemm_pair_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t stream);
 long long gemm_pair_launch_count();
+bool gemm_probes_built();           // -DTP_BUILD_PROBES (libtokenpacker_exp.so): the timing-probe instantiations TP_TUNE_PAIR_DEBUG selects exist
 int gemm_pair_occupancy();
 int gemm_pair_workgroups();                            // workgroups of a pair launch (two per CU)
 int gemm8_persistent_cus();                            // workgroups of a persistent launch (CUs rounded down to 8)
@@ -227,7 +236,7 @@ int occupy_cus_launch(int blocks, int usec, int* sink, hipStream_t stream);
 int hd_assemble_launch(const tp_hd_image* plan_host, int n_images, const void* tokens, const int32_t* crop_map, const void* sep,
                        const void* ret, void* out, int M, int D, hipStream_t stream);
 int ln_finalize_launch(const float* parts, float* mean_rstd, long long M, int nparts, int groups, int ln_dim,
-                       float eps, hipStream_t stream, bool second_moment = false);
+                       float eps, hipStream_t stream, bool second_moment = false, bool pair_rstd = false);
 int pack_cast_f32_launch(int dtype, const void* src, float* dst, int n, hipStream_t stream);
 // `sat` (optional): device int incremented once per element that did not fit fp16 and was clamped to +-65504
 int pack_cast_f16_launch(int dtype, const void* src, void* dst_f16, long long n, hipStream_t stream, int* sat = nullptr);
@@ -257,7 +266,8 @@ struct PackedLayout {
     size_t w_cc_q;                // [1024,1024] f16
     size_t w_qt_cc;               // per-head transposes of Wc'_k (absorbed schedule)
     size_t w_cc_v3;               // [E][2 E] f16: the rows of Wc'_v as K-tile pairs hi_t | lo_t (lo = what its fp16 rounding drops) — the absorbed
-                                  // schedule's per-head V GEMM contracts (u_hi | u_lo | u_hi) with it: neither rounding survives
+                                  // schedule's per-head V GEMM contracts the ONE fp16 u with it over K = 2 E (GemmArgs::a_k_dup: every K-tile of u serves its
+                                  // hi_t | lo_t pair): u·W_hi + u·W_lo — the weight's rounding does not survive, u's does (round 5)
     size_t w_r_kv, c_r_kv;        // [2][1024,1024] f16 (zeros below the diagonal), [2][1024] f32
     size_t w_r_q;                 // [1024,1024] f16
     size_t wbar;                  // pack scratch: [3][1025] f32 column means of W2 (k, v, q) and the mean of b2 behind each
@@ -287,6 +297,7 @@ struct SchedulePlan {
     bool fold;                     // out_proj folded into mlp[0]
     bool split_k;                  // TP_TUNE_SPLIT_K applies to this batch
     bool tri;                      // TP_TUNE_TRI_STATS: centred chain weights, triangular statistics GEMM, no mean anywhere
+    bool decouple_k;               // fuse_attn on the centred chain: the K launch writes raw logits, independent of the row statistics (GemmArgs::attn_decoupled)
     bool need_h2, need_kv, need_q1pre, need_a1;   // workspace slabs the schedule writes
 };
 SchedulePlan plan_schedule(const tp_desc* desc, bool train, bool masked);

@@ -608,13 +608,17 @@ int hd_slice_launch(const float* img, int H, int W, int h_block, int w_block, in
 template <int NPARTS>
 __global__ void __launch_bounds__(256)
 ln_finalize_kernel(const float* __restrict__ parts, float* __restrict__ mean_rstd, long long M, int nparts,
-                   float inv_dim, float eps, bool second_moment) {
+                   float inv_dim, float eps, bool second_moment, bool pair_rstd) {
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int g = blockIdx.y;
     if (m >= M) return;
     const float* pg = parts + (long long)g * nparts * M * 2;
     if constexpr (NPARTS > 0) {
-        *(float2*)(mean_rstd + ((long long)g * M + m) * 2) = ln_merge_slabs<NPARTS>(pg, M, m, inv_dim, eps, second_moment);
+        float2 r = ln_merge_slabs<NPARTS>(pg, M, m, inv_dim, eps, second_moment);
+        // pair_rstd (second-moment statistics only: every mean is 0): the mean slot of group 1 carries group 0's rstd — what the
+        // V launch of the decoupled attention epilogues scales the K launch's raw logits with (GemmArgs::attn_decoupled)
+        if (pair_rstd && g == 1) r.x = ln_merge_slabs<NPARTS>(parts, M, m, inv_dim, eps, second_moment).y;
+        *(float2*)(mean_rstd + ((long long)g * M + m) * 2) = r;
         return;
     } else {
         float s1 = 0.f, q = 0.f, between = 0.f, mu;
@@ -634,12 +638,13 @@ ln_finalize_kernel(const float* __restrict__ parts, float* __restrict__ mean_rst
 }
 
 int ln_finalize_launch(const float* parts, float* mean_rstd, long long M, int nparts, int groups, int ln_dim,
-                       float eps, hipStream_t stream, bool second_moment) {
+                       float eps, hipStream_t stream, bool second_moment, bool pair_rstd) {
     dim3 grid((unsigned)((M + 255) / 256), (unsigned)groups);
+    if (pair_rstd && (nparts != 8 || groups != 2 || !second_moment)) { set_error("ln_finalize: pair_rstd needs 8 slabs, 2 groups, second-moment statistics"); return TP_ERR_INVALID_ARG; }
     if (nparts == 8)
-        hipLaunchKernelGGL(ln_finalize_kernel<8>, grid, dim3(256), 0, stream, parts, mean_rstd, M, nparts, 1.0f / ln_dim, eps, second_moment);
+        hipLaunchKernelGGL(ln_finalize_kernel<8>, grid, dim3(256), 0, stream, parts, mean_rstd, M, nparts, 1.0f / ln_dim, eps, second_moment, pair_rstd);
     else
-        hipLaunchKernelGGL(ln_finalize_kernel<0>, grid, dim3(256), 0, stream, parts, mean_rstd, M, nparts, 1.0f / ln_dim, eps, second_moment);
+        hipLaunchKernelGGL(ln_finalize_kernel<0>, grid, dim3(256), 0, stream, parts, mean_rstd, M, nparts, 1.0f / ln_dim, eps, second_moment, false);
     return check_launch("ln_finalize_kernel");
 }
 

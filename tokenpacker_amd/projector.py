@@ -158,6 +158,17 @@ class TokenPacker(nn.Module):
         sd = dict(self.named_parameters())
         return [sd[name] for name in _capi.WEIGHT_FIELDS]
 
+    def _expected_shapes(self):
+        E, C, D = self.embed_dim, self.MULTI_LEVEL_DIM, self.hidden_size
+        return {"q_proj_1.weight": (E, E),
+                "k_proj_1.0.weight": (E, C), "k_proj_1.0.bias": (E,), "k_proj_1.2.weight": (E, E), "k_proj_1.2.bias": (E,),
+                "v_proj_1.0.weight": (E, C), "v_proj_1.0.bias": (E,), "v_proj_1.2.weight": (E, E), "v_proj_1.2.bias": (E,),
+                "ln_q_1.weight": (E,), "ln_q_1.bias": (E,), "ln_k_1.weight": (E,), "ln_k_1.bias": (E,),
+                "ln_v_1.weight": (E,), "ln_v_1.bias": (E,),
+                "clip_attn.in_proj_weight": (3 * E, E), "clip_attn.in_proj_bias": (3 * E,),
+                "clip_attn.out_proj.weight": (E, E), "clip_attn.out_proj.bias": (E,),
+                "mlp.0.weight": (D, E), "mlp.0.bias": (D,), "mlp.2.weight": (D, D), "mlp.2.bias": (D,)}
+
     def _ln_eps(self) -> float:
         return float(self.ln_q_1.eps)
 
@@ -176,6 +187,17 @@ class TokenPacker(nn.Module):
         """(Re)build the kernel-side weight image: always when ``force`` (training forward), otherwise when any
         parameter storage / version or the compute dtype changed."""
         weights = self._named_weights()
+        expected = self._expected_shapes()
+        for name, w in zip(_capi.WEIGHT_FIELDS, weights):
+            if w.numel() == 0 or tuple(w.shape) != expected[name]:
+                # DeepSpeed ZeRO-3 partitions every parameter and re-assembles it in per-submodule forward hooks; this module never
+                # CALLS its child nn.Linear / nn.LayerNorm containers (they only hold the reference's state-dict names), so those
+                # hooks never fire and the kernels would be handed the empty placeholders.  ZeRO-2 (every shipped script of the
+                # reference: scripts/v1_5/*.sh -> zero2.json) keeps whole parameters and works.
+                raise RuntimeError(
+                    f"parameter {name} has shape {tuple(w.shape)} (expected {expected[name]}): the parameter looks partitioned "
+                    f"(DeepSpeed ZeRO-3?).  TokenPacker reads its weights directly and does not trigger per-submodule gather hooks; "
+                    f"use ZeRO-2, or wrap the forward in deepspeed.zero.GatheredParameters(list(projector.parameters())).")
         # (an inference image carries every folded / pre-multiplied weight whatever the tuning table says: the schedule is
         # chosen per forward, the image never has to follow a knob)
         key = (dtype, device, tuple((w.data_ptr(), w._version) for w in weights))

@@ -388,7 +388,7 @@ class DirectGather:
 def project_sharded(project: Callable[[Tuple[torch.Tensor, torch.Tensor]], torch.Tensor],
                     x_local: torch.Tensor, xm_local: torch.Tensor, total: int,
                     group: Optional[dist.ProcessGroup] = None, gather: bool = True,
-                    overlap_chunks: int = 1, dense: bool = True):
+                    overlap_chunks: int = 1, dense: bool = True, force_collective: bool = False):
     """Run ``project((x, x_multi))`` on this rank's shard and (optionally) all-gather.
 
     ``project`` is any callable with the projector's forward contract (the HIP ``TokenPacker``
@@ -398,7 +398,9 @@ def project_sharded(project: Callable[[Tuple[torch.Tensor, torch.Tensor]], torch
     that can write into a caller's buffer (``project.supports_out``: the HIP module) puts its result straight into
     its gather slot — no pad copy; ``dense=False`` then returns :class:`GatheredTokens` (no compaction copy either)."""
     ws = dist.get_world_size(group) if dist.is_initialized() else 1
-    if not gather or ws == 1:
+    # (a one-rank group has nothing to gather; ``force_collective`` sends it through the collective all the same — the one-rank
+    # RCCL smoke of the GPU suite and ``bench.py --force-dist``: the library loads, the communicator binds, the copy is exact)
+    if not gather or (ws == 1 and not (force_collective and dist.is_initialized())):
         return project((x_local, xm_local))
     sizes = shard_sizes(total, ws)
     b = x_local.shape[0]

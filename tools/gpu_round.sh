@@ -18,7 +18,7 @@ if has pair; then
   echo "== pair kernel: occupancy, bit-identity tests, same-process A/B =="
   python - <<'PY'
 from tokenpacker_amd import _capi
-print("pair kernel workgroups per CU (needs 2):", _capi.load_library().tp_test_pair_occupancy())
+print("pair kernel workgroups per CU (needs 2):", _capi.load_test_library().tp_test_pair_occupancy())
 PY
   timeout 900 python -m pytest tests/test_gpu_pair.py -m gpu -x -q -p no:cacheprovider > $OUT/pytest_pair.log 2>&1
   echo "pytest exit $?"; tail -30 $OUT/pytest_pair.log

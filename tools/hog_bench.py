@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Persistent-GEMM tile scheduling under CU contention: time the B=256 forward while `--hog` CUs are kept busy by
-another stream (tp_test_occupy_cus — what a collective's kernels do when the all-gather of step i overlaps the
+another stream (tp_test_occupy_cus of libtokenpacker_exp.so — what a collective's kernels do when the all-gather of step i overlaps the
 forward of step i+1), static striding vs per-XCD tile queues (TP_TUNE_DYNAMIC_TILES), and with r CUs per XCD RESERVED
 for the other stream (TP_TUNE_RESERVE_CUS: the persistent GEMMs launch 256 - 8 r workgroups)."""
 import argparse
@@ -39,7 +39,7 @@ def main():
                 for rep in range(6):
                     torch.cuda.synchronize()
                     if hog:
-                        assert lib.tp_test_occupy_cus(hog, 40000, sink.data_ptr(), side.cuda_stream) == 0   # ~40 ms
+                        assert _capi.load_test_library().tp_test_occupy_cus(hog, 40000, sink.data_ptr(), side.cuda_stream) == 0   # ~40 ms
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     for _ in range(5):

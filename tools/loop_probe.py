@@ -5,6 +5,8 @@ interleaved; per probe the least-squares line  t = fixed + per_ktile * K / 64  p
 
     python tools/loop_probe.py [--out gpurun_out/loop_probe.json]
 """
+import os as _os
+_os.environ.setdefault("TP_LIB_VARIANT", "exp")     # the timing-probe instantiations live in libtokenpacker_exp.so only (make exp)
 import argparse
 import json
 import os

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
 """Timing probes of the pair GEMM kernel (TP_TUNE_PAIR_DEBUG): where a K-tile's time goes.  fp16 -> fp16 plain launches."""
+import os as _os
+_os.environ.setdefault("TP_LIB_VARIANT", "exp")     # the timing-probe instantiations live in libtokenpacker_exp.so only (make exp)
 import ctypes, json, os, statistics, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

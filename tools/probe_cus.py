@@ -1,3 +1,5 @@
+import os as _os
+_os.environ.setdefault("TP_LIB_VARIANT", "exp")     # the timing-probe instantiations live in libtokenpacker_exp.so only (make exp)
 import sys, os, statistics, torch
 sys.path.insert(0, os.getcwd())
 from tokenpacker_amd import _capi
