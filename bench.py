@@ -503,6 +503,7 @@ def run_e2e(args, world, rank, device, dtype, dist):
         out["multi_gpu"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "per_rank_batches": shard.shard_sizes(args.e2e_batch, world),
                             "collective_self_check": dict(COLLECTIVE_CHECK),
                             "note": "DDP-style: the only collectives of this line are the start-up self-check and the MAX-reduction of the clock"}
+    flush_c_stdio()
     print(json.dumps(out), flush=True)
 
 
@@ -625,6 +626,16 @@ def collective_self_check(dist, world: int, rank: int, device, backend: str, tim
             "seconds": round(time.perf_counter() - t0, 3), "when": "before the warm-up"}
 
 
+def flush_c_stdio() -> None:
+    """RCCL announces itself with a printf to C stdout ("Librccl path : ..."), which is block-buffered when stdout is a pipe and
+    would surface at process exit — BEHIND the one JSON line a driver that reads the last line of stdout is looking for."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                        # noqa: cosmetic
+        pass
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -655,6 +666,7 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         COLLECTIVE_CHECK.update(collective_self_check(dist, world, rank, device, args.backend))
+        flush_c_stdio()                      # (RCCL's "Librccl path : ..." banner: out NOW, on every rank, not behind the JSON line at exit)
 
     from tokenpacker_amd import _capi, hd, shard
 
@@ -972,6 +984,7 @@ def main():
             out.update(gpu_extras(args, model, x, xm, dtype, device, images_per_s))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, s, D, args.cpu_threads)
+        flush_c_stdio()
         print(json.dumps(out), flush=True)
 
     if dgather is not None:

@@ -87,7 +87,9 @@ def test_bench_force_dist_line_matches_the_plain_shape():
                           "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--min-seconds", "0"], env=env, capture_output=True,
                          text=True, timeout=300)
     assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-4000:])
-    line = json.loads(res.stdout.strip().splitlines()[-1])
+    lines = res.stdout.strip().splitlines()
+    assert lines[-1].startswith("{"), ("the JSON line must be the LAST line of stdout (RCCL's banner flushed before it)", lines[-3:])
+    line = json.loads(lines[-1])
     assert line["n_gpus"] == 1 and line["config"]["global_batch"] == 8 and line["value"] > 0
     mg = line["multi_gpu"]
     assert mg["backend"] == "nccl" and mg["ranks"] == 1 and mg["collective_self_check"]["all_gather_into_tensor"] == "ok"
