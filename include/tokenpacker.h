@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 /* ABI 5 (round 6): tp_linear_args.reserved1 became `ldw` and the packed-weight image's layout changed (w_cc_v3: interleaved
- * hi_t | lo_t K-tile pairs) — both already in round 5 under a stale 4 —, TP_TUNE_DECOUPLE_K (17 knobs), the probe instantiations
+ * hi_t | lo_t K-tile pairs) — both already in round 5 under a stale 4 —, TP_TUNE_DECOUPLE_K and TP_TUNE_BWD_CHAIN (18 knobs), the probe instantiations
  * and test hooks left the product library (tokenpacker_test.h / libtokenpacker_exp.so), tp_debug_counter. */
 #define TP_ABI_VERSION 5
 
@@ -481,7 +481,13 @@ enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail, all half 
                                      statistics launch | 2 raw logits on the caller's stream (same bits as 1: the A/B of the placement
                                      alone).  Measured null at B = 32 .. 256 (profiles/r06b_decouple_k_ab.txt): kept as the record of
                                      that A/B, parity-tested (tests/test_gpu_round6.py) */
-       TP_TUNE_COUNT_ = 17 };
+       TP_TUNE_BWD_CHAIN = 17,    /* tp_backward of a bf16 model: 0 (default) gradients travel between the backward's kernels in FP16 behind a
+                                     dynamic power-of-two scale (S = 2^k brings amax(dy) to (16, 32], computed on the device per call; every
+                                     parameter gradient is multiplied by 1 / S — exact — when its fp32 sum is cast to bf16): the weight gradients
+                                     read the forward's saved fp16 activations in place instead of through a bf16 copy each (6 of 9 cast passes
+                                     gone), and the chain keeps 11 mantissa bits instead of 8 | 1 gradients travel in bf16 (rounds 1-5).  fp16
+                                     models are not affected (their gradients travel in fp16, unscaled, as before) */
+       TP_TUNE_COUNT_ = 18 };
 int tp_set_tuning(int key, int value);
 int tp_get_tuning(int key);                  /* the library's current value (not a binding's shadow copy); -1: bad key */
 typedef struct tp_tuning tp_tuning;          /* opaque; host memory owned by the library until tp_tuning_destroy */

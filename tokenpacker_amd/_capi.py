@@ -20,8 +20,8 @@ TP_TUNE_GEMM_TILE, TP_TUNE_XCD_SWIZZLE, TP_TUNE_FOLD_OUT_PROJ, TP_TUNE_DYNAMIC_T
 TP_TUNE_RESERVE_CUS, TP_TUNE_ABSORB_KV, TP_TUNE_FUSE_KV_LN, TP_TUNE_LN_MERGE, TP_TUNE_FUSE_ATTN = 5, 6, 7, 8, 9
 TP_TUNE_SPLIT_K, TP_TUNE_SMALL_GEMM_WAVES, TP_TUNE_TRI_STATS = 10, 11, 12
 TP_TUNE_PAIR_GEMM, TP_TUNE_PAIR_STAGGER, TP_TUNE_PAIR_DEBUG = 13, 14, 15
-TP_TUNE_DECOUPLE_K = 16
-TP_TUNE_COUNT = 17
+TP_TUNE_DECOUPLE_K, TP_TUNE_BWD_CHAIN = 16, 17
+TP_TUNE_COUNT = 18
 TP_WGRAD_X_TRANSPOSED = 1
 TP_NUM_STAGES = 10
 TP_NUM_DEBUG_BUFFERS = 9
@@ -348,7 +348,7 @@ def strides3(st) -> "ctypes.Array":
 _TUNING_DEFAULTS = {TP_TUNE_GEMM_TILE: 0, TP_TUNE_XCD_SWIZZLE: 1, TP_TUNE_FOLD_OUT_PROJ: 0, TP_TUNE_DYNAMIC_TILES: 1, TP_TUNE_Q_SIDE_STREAM: 1,
                     TP_TUNE_RESERVE_CUS: 0, TP_TUNE_ABSORB_KV: 0, TP_TUNE_FUSE_KV_LN: 1, TP_TUNE_LN_MERGE: 0, TP_TUNE_FUSE_ATTN: 0,
                     TP_TUNE_SPLIT_K: 0, TP_TUNE_SMALL_GEMM_WAVES: 0, TP_TUNE_TRI_STATS: 0, TP_TUNE_PAIR_GEMM: 0, TP_TUNE_PAIR_STAGGER: 100,
-                    TP_TUNE_PAIR_DEBUG: 0, TP_TUNE_DECOUPLE_K: 0}
+                    TP_TUNE_PAIR_DEBUG: 0, TP_TUNE_DECOUPLE_K: 0, TP_TUNE_BWD_CHAIN: 0}
 
 
 def set_tuning(key: int, value: int) -> None:

@@ -43,9 +43,9 @@ int check_launch(const char* what) {
 // Tuning: the process-wide table and the per-call contexts (include/tokenpacker.h).  An entry point that takes a tp_desc opens a
 // TuningScope on desc->tuning: every tuning() read of that call, on that host thread, comes from the context (a plain array nobody
 // else writes while the call runs) — other threads' tp_set_tuning / tp_tuning_set on other contexts cannot reach it.
-static std::atomic<int> g_tuning[TP_TUNE_COUNT_] = {{0}, {1}, {0}, {1}, {1}, {0}, {0}, {1}, {0}, {0}, {0}, {0}, {0}, {0}, {100}, {0}, {0}};
+static std::atomic<int> g_tuning[TP_TUNE_COUNT_] = {{0}, {1}, {0}, {1}, {1}, {0}, {0}, {1}, {0}, {0}, {0}, {0}, {0}, {0}, {100}, {0}, {0}, {0}};
 static_assert(TP_TUNE_XCD_SWIZZLE == 1 && TP_TUNE_DYNAMIC_TILES == 3 && TP_TUNE_Q_SIDE_STREAM == 4 && TP_TUNE_FUSE_KV_LN == 7 &&
-              TP_TUNE_PAIR_STAGGER == 14 && TP_TUNE_DECOUPLE_K == 16 && TP_TUNE_COUNT_ == 17, "defaults above are positional");
+              TP_TUNE_PAIR_STAGGER == 14 && TP_TUNE_DECOUPLE_K == 16 && TP_TUNE_BWD_CHAIN == 17 && TP_TUNE_COUNT_ == 18, "defaults above are positional");
 }  // namespace tp
 struct tp_tuning { int v[TP_TUNE_COUNT_]; };
 namespace tp {

@@ -109,11 +109,13 @@ int bw_transpose_launch(int src_dtype, int dst_dtype, const void* src, long long
 // out[i] = cast( scale-free sum over parts of part[s][i] ), i < n   (split-K wgrad partials, column-sum partials)
 template <typename TD>
 __global__ void __launch_bounds__(256)
-reduce_parts_kernel(const float* __restrict__ part, long long part_stride, int nparts, long long n, TD* __restrict__ out) {
+reduce_parts_kernel(const float* __restrict__ part, long long part_stride, int nparts, long long n, TD* __restrict__ out,
+                    const float* __restrict__ out_scale) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
     for (int k = 0; k < nparts; ++k) s += part[(long long)k * part_stride + i];
+    if (out_scale) s *= out_scale[0];                   // (a power of two: exact)
     out[i] = sat_cast<TD>(s);
 }
 
@@ -150,7 +152,7 @@ reduce_cols_stage1_kernel(const float* __restrict__ part, long long part_stride,
 }
 
 int bw_reduce_many_parts_launch(int dst_dtype, const float* part, long long part_stride, int nparts, int n, void* out,
-                                float* scratch, hipStream_t stream) {
+                                float* scratch, hipStream_t stream, const float* out_scale) {
     if ((n & 3) || (part_stride & 3) || ((uintptr_t)part & 15)) {
         set_error("bw reduce: n / part stride must be multiples of 4 floats, partials 16-byte aligned");
         return TP_ERR_INVALID_ARG;
@@ -160,7 +162,7 @@ int bw_reduce_many_parts_launch(int dst_dtype, const float* part, long long part
     hipLaunchKernelGGL(reduce_cols_stage1_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)S), dim3(256), 0, stream,
                        part, part_stride, nparts, n, scratch);
     if (int rc = check_launch("reduce_cols_stage1_kernel")) return rc;
-    return bw_reduce_parts_launch(dst_dtype, scratch, n, S, n, out, stream);
+    return bw_reduce_parts_launch(dst_dtype, scratch, n, S, n, out, stream, out_scale);
 }
 
 // Column sums of a row-major 16-bit matrix (bias gradients of the layers whose weight gradient reads dY in place):
@@ -168,9 +170,12 @@ int bw_reduce_many_parts_launch(int dst_dtype, const float* part, long long part
 // row) and every 4th row of its slice; the 4 row-lanes combine through LDS in a fixed order.
 template <typename TS>
 __global__ void __launch_bounds__(256)
-colsum_rows_kernel(const TS* __restrict__ src, long long ld, long long R, int C, float* __restrict__ part) {
+colsum_rows_kernel(const TS* __restrict__ src, long long ld, long long R, int C, float* __restrict__ part,
+                   float* __restrict__ amax_part) {
     using S8 = typename Vec<TS>::x8;
     __shared__ float red[4][64][8];
+    __shared__ float red_max[256];
+    float amax = 0.f;                                     // (amax_part: max |v| of the block's values, NaN sticks — bw_dynamic_scale)
     const int co = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = (blockIdx.x * 64 + co) * 8;
     const int S = gridDim.y, slice = blockIdx.y;
@@ -191,13 +196,30 @@ colsum_rows_kernel(const TS* __restrict__ src, long long ld, long long R, int C,
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[u][e] += (float)v[u][e];
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)v[u][e];
+                    acc[u][e] += f;
+                    if (amax_part) { const float a = fabsf(f); amax = (a != a || a > amax) ? a : amax; }
+                }
         }
         for (; r < r1; r += 4) {
             const S8 v = *(const S8*)(b + r * ld);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[0][e] += (float)v[e];
+            for (int e = 0; e < 8; ++e) {
+                const float f = (float)v[e];
+                acc[0][e] += f;
+                if (amax_part) { const float a = fabsf(f); amax = (a != a || a > amax) ? a : amax; }
+            }
         }
+    }
+    if (amax_part) {
+        red_max[threadIdx.x] = amax;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) { const float a = red_max[threadIdx.x + o], m = red_max[threadIdx.x]; red_max[threadIdx.x] = (a != a || a > m) ? a : m; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) amax_part[blockIdx.y * gridDim.x + blockIdx.x] = red_max[0];
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[rl][co][e] = (acc[0][e] + acc[1][e]) + (acc[2][e] + acc[3][e]);
@@ -210,7 +232,8 @@ colsum_rows_kernel(const TS* __restrict__ src, long long ld, long long R, int C,
 }
 
 // -> part[slices][C]; returns the number of slices written (a fixed function of R and C), or a negative status
-int bw_colsum_rows_launch(int dtype, const void* src, long long ld, long long R, int C, float* part, hipStream_t stream) {
+int bw_colsum_rows_launch(int dtype, const void* src, long long ld, long long R, int C, float* part, hipStream_t stream,
+                          float* amax_part, int* amax_count) {
     if ((C & 7) || (ld & 7) || ((uintptr_t)src & 15)) {
         set_error("bw colsum: columns / row stride must be multiples of 8 elements, the source 16-byte aligned");
         return TP_ERR_INVALID_ARG;
@@ -221,42 +244,141 @@ int bw_colsum_rows_launch(int dtype, const void* src, long long ld, long long R,
     if (S < 1) S = 1;
     if (S > kColsumMaxSlices) S = kColsumMaxSlices;
     if (dtype == TP_BF16)
-        hipLaunchKernelGGL(colsum_rows_kernel<bf16_t>, dim3((unsigned)gx, (unsigned)S), dim3(256), 0, stream, (const bf16_t*)src, ld, R, C, part);
+        hipLaunchKernelGGL(colsum_rows_kernel<bf16_t>, dim3((unsigned)gx, (unsigned)S), dim3(256), 0, stream, (const bf16_t*)src, ld, R, C, part, amax_part);
     else if (dtype == TP_F16)
-        hipLaunchKernelGGL(colsum_rows_kernel<f16_t>, dim3((unsigned)gx, (unsigned)S), dim3(256), 0, stream, (const f16_t*)src, ld, R, C, part);
+        hipLaunchKernelGGL(colsum_rows_kernel<f16_t>, dim3((unsigned)gx, (unsigned)S), dim3(256), 0, stream, (const f16_t*)src, ld, R, C, part, amax_part);
     else { set_error("bw colsum: unsupported dtype %d", dtype); return TP_ERR_INVALID_ARG; }
     if (int rc = check_launch("colsum_rows_kernel")) return rc;
+    if (amax_count) *amax_count = (int)(gx * S);          // (amax_part entries written: kColsumAmaxParts bounds it)
     return (int)S;
 }
 
 int bw_reduce_parts_launch(int dst_dtype, const float* part, long long part_stride, int nparts, long long n, void* out,
-                           hipStream_t stream) {
+                           hipStream_t stream, const float* out_scale) {
     const unsigned blocks = (unsigned)((n + 255) / 256);
     if (dst_dtype == TP_BF16)
-        hipLaunchKernelGGL(reduce_parts_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, part, part_stride, nparts, n, (bf16_t*)out);
+        hipLaunchKernelGGL(reduce_parts_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, part, part_stride, nparts, n, (bf16_t*)out, out_scale);
     else if (dst_dtype == TP_F16)
-        hipLaunchKernelGGL(reduce_parts_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream, part, part_stride, nparts, n, (f16_t*)out);
+        hipLaunchKernelGGL(reduce_parts_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream, part, part_stride, nparts, n, (f16_t*)out, out_scale);
     else if (dst_dtype == TP_F32)
-        hipLaunchKernelGGL(reduce_parts_kernel<float>, dim3(blocks), dim3(256), 0, stream, part, part_stride, nparts, n, (float*)out);
+        hipLaunchKernelGGL(reduce_parts_kernel<float>, dim3(blocks), dim3(256), 0, stream, part, part_stride, nparts, n, (float*)out, out_scale);
     else { set_error("bw reduce: unsupported dtype %d", dst_dtype); return TP_ERR_INVALID_ARG; }
     return check_launch("reduce_parts_kernel");
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Dynamic power-of-two scale of a gradient tensor (tp_internal.h: bw_dynamic_scale_launch).  Stage 1: 1024 workgroups, a thread
+// strides over 16-byte pieces and keeps max |v| (NaN-propagating through the comparison's falsehood is not needed: a non-finite
+// maximum is detected in stage 2 by its exponent); stage 2: one workgroup reduces the 1024 partials and writes S, 1 / S.
+template <typename TS>
+__global__ void __launch_bounds__(256)
+amax_partials_kernel(const TS* __restrict__ src, long long n8, float* __restrict__ part) {
+    using S8 = typename Vec<TS>::x8;
+    __shared__ float red[256];
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const S8 v = *(const S8*)(src + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float a = fabsf((float)v[e]); m = a > m ? a : (a != a ? a : m); }   // (NaN sticks)
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { const float a = red[threadIdx.x + o], b = red[threadIdx.x]; red[threadIdx.x] = (a != a || a > b) ? a : b; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ void __launch_bounds__(256)
+scale_from_amax_kernel(const float* __restrict__ part, int nparts, float* __restrict__ scale) {
+    __shared__ float red[256];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) { const float a = part[i]; m = (a != a || a > m) ? a : m; }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { const float a = red[threadIdx.x + o], b = red[threadIdx.x]; red[threadIdx.x] = (a != a || a > b) ? a : b; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float amax = red[0];
+        float S = 1.f;
+        if (amax > 0.f && amax < INFINITY) {            // (zero, inf, NaN: S = 1 — the values travel as they are)
+            int e;
+            (void)frexpf(amax, &e);                      // amax = f * 2^e, f in [0.5, 1)  ->  amax * 2^(5 - e) in [16, 32)
+            int k = 5 - e;
+            k = k > 60 ? 60 : (k < -60 ? -60 : k);
+            S = ldexpf(1.f, k);
+        }
+        scale[0] = S; scale[1] = 1.f / S;
+    }
+}
+template <typename TS>
+__global__ void __launch_bounds__(256)
+scale_cast_f16_kernel(const TS* __restrict__ src, long long n8, const float* __restrict__ scale, f16_t* __restrict__ dst) {
+    using S8 = typename Vec<TS>::x8;
+    using D8 = typename Vec<f16_t>::x8;
+    const float S = scale[0];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const S8 v = *(const S8*)(src + i * 8);
+        D8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = sat_cast<f16_t>((float)v[e] * S);
+        *(D8*)(dst + i * 8) = o;
+    }
+}
+
+int bw_dynamic_scale_launch(int src_dtype, const void* src, long long n, float* part, float* scale, hipStream_t stream) {
+    if ((n & 7) || ((uintptr_t)src & 15)) { set_error("bw dynamic scale: element count must be a multiple of 8, the source 16-byte aligned"); return TP_ERR_INVALID_ARG; }
+    const int nb = 1024;
+    if (src_dtype == TP_BF16)
+        hipLaunchKernelGGL(amax_partials_kernel<bf16_t>, dim3(nb), dim3(256), 0, stream, (const bf16_t*)src, n / 8, part);
+    else if (src_dtype == TP_F16)
+        hipLaunchKernelGGL(amax_partials_kernel<f16_t>, dim3(nb), dim3(256), 0, stream, (const f16_t*)src, n / 8, part);
+    else { set_error("bw dynamic scale: unsupported dtype %d", src_dtype); return TP_ERR_INVALID_ARG; }
+    if (int rc = check_launch("amax_partials_kernel")) return rc;
+    return bw_scale_from_partials_launch(part, nb, scale, stream);
+}
+
+int bw_scale_from_partials_launch(const float* amax_part, int nparts, float* scale, hipStream_t stream) {
+    hipLaunchKernelGGL(scale_from_amax_kernel, dim3(1), dim3(256), 0, stream, amax_part, nparts, scale);
+    return check_launch("scale_from_amax_kernel");
+}
+
+int bw_scale_cast_launch(int src_dtype, const void* src, long long n, const float* scale, void* dst_f16, hipStream_t stream) {
+    if ((n & 7) || ((uintptr_t)src & 15) || ((uintptr_t)dst_f16 & 15)) { set_error("bw scale cast: element count must be a multiple of 8, pointers 16-byte aligned"); return TP_ERR_INVALID_ARG; }
+    const int nb = 2048;
+    if (src_dtype == TP_BF16)
+        hipLaunchKernelGGL(scale_cast_f16_kernel<bf16_t>, dim3(nb), dim3(256), 0, stream, (const bf16_t*)src, n / 8, scale, (f16_t*)dst_f16);
+    else if (src_dtype == TP_F16)
+        hipLaunchKernelGGL(scale_cast_f16_kernel<f16_t>, dim3(nb), dim3(256), 0, stream, (const f16_t*)src, n / 8, scale, (f16_t*)dst_f16);
+    else { set_error("bw scale cast: unsupported dtype %d", src_dtype); return TP_ERR_INVALID_ARG; }
+    return check_launch("scale_cast_f16_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------
 // LayerNorm backward over rows of E = 1024 (one wave per row, 16 elements per lane):
 //   xhat = (x - mean) rstd,  g = dy gamma,  dx = rstd (g - mean(g) - xhat mean(g xhat))
-// plus per-workgroup partial sums of dgamma = sum_rows dy xhat and dbeta = sum_rows dy
-// (part[blk][0][E], part[blk][1][E]; reduced by bw_reduce_parts).  x: fp16 (forward activations), dy/dx: TG.
+// plus per-workgroup partial sums of dgamma = sum_rows dy xhat, dbeta = sum_rows dy and (round 6) the column sums of dx —
+// the bias gradient of the linear layer in front of the LayerNorm, which used to be a pass of its own over dx —
+// (part[blk][0][E], part[blk][1][E], part[blk][2][E]; reduced by bw_reduce_many_parts).  x: fp16 (forward activations), dy/dx: TG.
+// `xn` (round 6, optional): the LayerNorm's OUTPUT xhat gamma + beta, row-major in TG — the activation operand of the weight
+// gradient of the layer BEHIND the LayerNorm, which the K-major GEMM then reads in place (it used to be produced by a
+// transposing pass that re-read x and fetched (mean, rstd) per element: 0.82 ms per B = 256 step for the three LayerNorms).
 template <typename TG>
 __global__ void __launch_bounds__(256)
 ln_backward_kernel(const TG* __restrict__ dy, const f16_t* __restrict__ x, const float* __restrict__ mean_rstd,
-                   const float* __restrict__ gamma, TG* __restrict__ dx, float* __restrict__ part, long long rows) {
+                   const float* __restrict__ gamma, TG* __restrict__ dx, float* __restrict__ part, long long rows,
+                   const float* __restrict__ beta, TG* __restrict__ xn) {
     constexpr int E = kEmbed;
-    __shared__ float red[2][4][E];                       // 32 KiB
+    __shared__ float red[3][4][E];                       // 48 KiB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float dg[16], db[16], gm[16];
+    float dg[16], db[16], gm[16], dxs[16], bt[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { dg[e] = 0.f; db[e] = 0.f; gm[e] = gamma[(e >> 3) * 512 + lane * 8 + (e & 7)]; }
+    for (int e = 0; e < 16; ++e) {
+        dg[e] = 0.f; db[e] = 0.f; dxs[e] = 0.f; gm[e] = gamma[(e >> 3) * 512 + lane * 8 + (e & 7)];
+        bt[e] = xn ? beta[(e >> 3) * 512 + lane * 8 + (e & 7)] : 0.f;
+    }
     for (long long r = (long long)blockIdx.x * 4 + wave; r < rows; r += (long long)gridDim.x * 4) {
         const float mu = mean_rstd[2 * r], rstd = mean_rstd[2 * r + 1];
         float dyv[16], xh[16];
@@ -277,37 +399,42 @@ ln_backward_kernel(const TG* __restrict__ dy, const f16_t* __restrict__ x, const
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             using G8 = typename Vec<TG>::x8;
-            G8 o;
+            G8 o, n8;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int k = h * 8 + e;
                 o[e] = sat_cast<TG>(rstd * (dyv[k] * gm[k] - m1 - xh[k] * m2));
+                dxs[k] += (float)o[e];                  // (the ROUNDED value: what a column-sum pass over dx would have read)
                 dg[k] = fmaf(dyv[k], xh[k], dg[k]);
                 db[k] += dyv[k];
+                n8[e] = sat_cast<TG>(fmaf(xh[k], gm[k], bt[k]));
             }
             *(G8*)(dx + r * E + h * 512 + lane * 8) = o;
+            if (xn) *(G8*)(xn + r * E + h * 512 + lane * 8) = n8;
         }
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         red[0][wave][(e >> 3) * 512 + lane * 8 + (e & 7)] = dg[e];
         red[1][wave][(e >> 3) * 512 + lane * 8 + (e & 7)] = db[e];
+        red[2][wave][(e >> 3) * 512 + lane * 8 + (e & 7)] = dxs[e];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * E; i += 256) {
+    for (int i = threadIdx.x; i < 3 * E; i += 256) {
         const int w = i / E, c = i - w * E;
-        part[((long long)blockIdx.x * 2 + w) * E + c] = red[w][0][c] + red[w][1][c] + red[w][2][c] + red[w][3][c];
+        part[((long long)blockIdx.x * 3 + w) * E + c] = red[w][0][c] + red[w][1][c] + red[w][2][c] + red[w][3][c];
     }
 }
 
 int bw_ln_backward_launch(int gdtype, const void* dy, const void* x_f16, const float* mean_rstd, const float* gamma,
-                          void* dx, float* part, int nblocks, long long rows, hipStream_t stream) {
+                          void* dx, float* part, int nblocks, long long rows, hipStream_t stream, const float* beta, void* xn) {
+    if (xn && !beta) { set_error("bw ln backward: the normalised output needs beta"); return TP_ERR_INVALID_ARG; }
     if (gdtype == TP_BF16)
         hipLaunchKernelGGL(ln_backward_kernel<bf16_t>, dim3(nblocks), dim3(256), 0, stream, (const bf16_t*)dy,
-                           (const f16_t*)x_f16, mean_rstd, gamma, (bf16_t*)dx, part, rows);
+                           (const f16_t*)x_f16, mean_rstd, gamma, (bf16_t*)dx, part, rows, beta, (bf16_t*)xn);
     else
         hipLaunchKernelGGL(ln_backward_kernel<f16_t>, dim3(nblocks), dim3(256), 0, stream, (const f16_t*)dy,
-                           (const f16_t*)x_f16, mean_rstd, gamma, (f16_t*)dx, part, rows);
+                           (const f16_t*)x_f16, mean_rstd, gamma, (f16_t*)dx, part, rows, beta, (f16_t*)xn);
     return check_launch("ln_backward_kernel");
 }
 

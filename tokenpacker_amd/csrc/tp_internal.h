@@ -329,8 +329,16 @@ int splitk_reduce_launch(const float* partials, int S, int M, int N, const float
 int bw_transpose_launch(int src_dtype, int dst_dtype, const void* src, long long ld, int rows_per_batch,
                         long long batch_stride, int R, int C, void* dst, long long ldd, int Rpad, const float* mean_rstd,
                         const float* gamma, const float* beta, float* colsum_part, hipStream_t stream);
+// `out_scale` (device, optional): the sum is multiplied by out_scale[0] before the cast — the 1 / S of a backward chain that carries
+// its gradients scaled by a power of two S (bw_dynamic_scale_launch)
 int bw_reduce_parts_launch(int dst_dtype, const float* part, long long part_stride, int nparts, long long n, void* out,
-                           hipStream_t stream);
+                           hipStream_t stream, const float* out_scale = nullptr);
+// Dynamic power-of-two scale of a gradient tensor (the backward of a bf16 model runs its chain in fp16 — 11-bit mantissas, the
+// saved fp16 activations read in place by the weight gradients — and fp16's range needs the incoming dy brought to a known
+// magnitude): scale[0] = S = 2^k with amax(src) * S in (16, 32], scale[1] = 1 / S (S = 1 for an all-zero or non-finite tensor).
+// `part`: >= 1024 floats of scratch.  Then dst_f16 = saturate(src * S).  Nothing here synchronises: S lives on the device.
+int bw_dynamic_scale_launch(int src_dtype, const void* src, long long n, float* part, float* scale, hipStream_t stream);
+int bw_scale_cast_launch(int src_dtype, const void* src, long long n, const float* scale, void* dst_f16, hipStream_t stream);
 // Weight gradient straight from the row-major activations (tp_gemm8.hip, K-major operands):
 //   dW[Nout, Kin] = sum over the R token rows of dY[r, n] * X[r, k],   split over the rows, fp32 partials -> out_dtype.
 // X may be batch-strided (rows_per_batch % 64 == 0) and its Kin columns split over four tensors of n_part columns.
@@ -343,18 +351,26 @@ bool wgrad_tt_supported(long long R, int Nout, int Kin, const WgradX& X, long lo
 // rows [0, split_row) of dW go to grad_out, rows [split_row, Nout) to grad_out_hi (split_row = 0: all to grad_out)
 int wgrad_tt_launch(int dtype, const void* dY, long long ldy, const WgradX& X, long long R, int Nout, int Kin,
                     float* part, size_t part_bytes, int out_dtype, void* grad_out, int* counters, hipStream_t stream,
-                    void* grad_out_hi = nullptr, int split_row = 0);
+                    void* grad_out_hi = nullptr, int split_row = 0, const float* out_scale = nullptr);
 size_t wgrad_tt_part_bytes(int Nout, int Kin);
 int wgrad_tn_launch(int dtype, const void* dY, long long ldy, const void* XT, long long rpad, long long R, int Nout, int Kin,
-                    float* part, size_t part_bytes, int out_dtype, void* grad_out, int* counters, hipStream_t stream);
+                    float* part, size_t part_bytes, int out_dtype, void* grad_out, int* counters, hipStream_t stream,
+                    const float* out_scale = nullptr);
 
 constexpr int kColsumMaxSlices = 512;              // row slices of the column-sum kernel: scratch = slices * C floats
-int bw_colsum_rows_launch(int dtype, const void* src, long long ld, long long R, int C, float* part, hipStream_t stream);
+// amax_part / amax_count (optional): the pass also leaves max |v| per workgroup (*amax_count entries, <= kColsumAmaxParts) — the
+// incoming dy is read ONCE for its bias gradient and for the dynamic scale of the fp16 gradient chain (bw_scale_from_partials_launch)
+constexpr int kColsumAmaxParts = 8 * kColsumMaxSlices;
+int bw_colsum_rows_launch(int dtype, const void* src, long long ld, long long R, int C, float* part, hipStream_t stream,
+                          float* amax_part = nullptr, int* amax_count = nullptr);
+int bw_scale_from_partials_launch(const float* amax_part, int nparts, float* scale, hipStream_t stream);
 constexpr int kReduceSlices = 32;                  // stage-1 slices of the many-parts reduction: scratch = kReduceSlices * n floats
 int bw_reduce_many_parts_launch(int dst_dtype, const float* part, long long part_stride, int nparts, int n, void* out,
-                                float* scratch, hipStream_t stream);
+                                float* scratch, hipStream_t stream, const float* out_scale = nullptr);
+// part: [nblocks][3][E] — dgamma, dbeta, colsum(dx) partials.  beta / xn (optional): also write the LayerNorm's output in gdtype
 int bw_ln_backward_launch(int gdtype, const void* dy, const void* x_f16, const float* mean_rstd, const float* gamma,
-                          void* dx, float* part, int nblocks, long long rows, hipStream_t stream);
+                          void* dx, float* part, int nblocks, long long rows, hipStream_t stream, const float* beta = nullptr,
+                          void* xn = nullptr);
 int bw_region_attention_launch(int gdtype, const void* q, const void* k, const void* v, const void* dout, void* dq,
                                void* dk, void* dv, int B, int grid, int s, hipStream_t stream);
 int validate_desc(const tp_desc* d);

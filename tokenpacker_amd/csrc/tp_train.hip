@@ -39,6 +39,9 @@ struct BwLayout {
     size_t counters;                                  // tile-queue heads of the persistent GEMM launches (zeroed once)
     size_t part, colpart, lnpart;                     // fp32 partials: split-K wgrad, column sums, LN affine grads
     size_t redscratch;                                // stage-1 output of the many-parts reduction
+    // fp16 chain of a bf16 model (TP_TUNE_BWD_CHAIN = 0): dy scaled by a dynamic power of two and cast [Rq, D] f16, the scale
+    // pair (S, 1 / S) on the device, 1024 amax partials; kNoSlab otherwise
+    size_t dy16, scale, amaxpart;
     size_t part_bytes;
     size_t total;
     int Rp, Rqp;
@@ -48,7 +51,16 @@ struct BwLayout {
 // multiples of 8 by tp_forward's own argument check): images must be whole 64-row K-tiles.
 static bool xm_inplace(int grid) { const int N = grid * grid; return N % 64 == 0 && N >= 128; }
 
-static BwLayout bw_layout(int B, int grid, int s, int D) {
+// Whether the backward of this descriptor carries its gradients in fp16 behind a dynamic power-of-two scale (a bf16 model; the
+// default) instead of in the model dtype.  Why: the forward saves its activations in fp16, and an MFMA takes one
+// operand type — with bf16 gradients every weight gradient first re-wrote its activation operand as bf16 (nine cast / transpose
+// passes, 1.3 ms per B = 256 step); with fp16 gradients six of the nine read the saved activation in place, and the gradients
+// keep 11 mantissa bits instead of 8 through the chain.  fp16's range is handled like loss scaling handles it, but per call and
+// on the device: S = 2^k brings amax(dy) to (16, 32], everything downstream is linear in dy, every parameter gradient is
+// multiplied by 1 / S (exact) when its fp32 sum is cast to the model dtype.
+static bool bw_f16_chain(const tp_desc* d) { return d->dtype == TP_BF16 && tuning(TP_TUNE_BWD_CHAIN) == 0; }
+
+static BwLayout bw_layout(int B, int grid, int s, int D, bool f16_chain) {
     BwLayout L{};
     const size_t N = (size_t)grid * grid, G = grid / s, M = G * G, E = kEmbed;
     const size_t R = (size_t)B * N, Rq = (size_t)B * M;
@@ -81,9 +93,12 @@ static BwLayout bw_layout(int B, int grid, int s, int D) {
     L.part = take(L.part_bytes);
     const size_t cmax = (size_t)D > 2 * E ? (size_t)D : 2 * E;
     L.colpart = take((Rp / 64) * cmax * 4);
-    L.lnpart = take((size_t)256 * 2 * E * 4);
+    L.lnpart = take((size_t)256 * 3 * E * 4);
     L.redscratch = take((size_t)kReduceSlices * cmax * 4);
     L.counters = take(64 * 32 * 4);
+    L.dy16 = take_if(f16_chain, Rq * D * 2);
+    L.scale = take_if(f16_chain, 256);
+    L.amaxpart = take_if(f16_chain, (size_t)kColsumAmaxParts * 4);
     L.total = off;
     return L;
 }
@@ -109,7 +124,7 @@ bool wgrad_tt_supported(long long R, int Nout, int Kin, const WgradX& X, long lo
 
 int wgrad_tt_launch(int dtype, const void* dY, long long ldy, const WgradX& X, long long R, int Nout, int Kin,
                     float* part, size_t part_bytes, int out_dtype, void* grad_out, int* counters, hipStream_t stream,
-                    void* grad_out_hi, int split_row) {
+                    void* grad_out_hi, int split_row, const float* out_scale) {
     if (!wgrad_tt_supported(R, Nout, Kin, X, ldy)) {
         set_error("tp wgrad: unsupported shape R=%lld Nout=%d Kin=%d (need Kin %% 256 == 0, strides %% 8 == 0, batches of a multiple of 64 rows)",
                   R, Nout, Kin);
@@ -132,16 +147,17 @@ int wgrad_tt_launch(int dtype, const void* dY, long long ldy, const WgradX& X, l
     a.tile_counters = S <= 4 ? counters : nullptr;       // (a queue slot holds [4 groups][8 XCDs] heads)
     TP_TRY(gemm_launch(dtype, TP_F32, a, stream));
     if (!grad_out_hi || split_row <= 0 || split_row >= Nout)
-        return bw_reduce_parts_launch(out_dtype, part, (long long)Nout * Kin, S, (long long)Nout * Kin, grad_out, stream);
-    TP_TRY(bw_reduce_parts_launch(out_dtype, part, (long long)Nout * Kin, S, (long long)split_row * Kin, grad_out, stream));
+        return bw_reduce_parts_launch(out_dtype, part, (long long)Nout * Kin, S, (long long)Nout * Kin, grad_out, stream, out_scale);
+    TP_TRY(bw_reduce_parts_launch(out_dtype, part, (long long)Nout * Kin, S, (long long)split_row * Kin, grad_out, stream, out_scale));
     return bw_reduce_parts_launch(out_dtype, part + (size_t)split_row * Kin, (long long)Nout * Kin, S,
-                                  (long long)(Nout - split_row) * Kin, grad_out_hi, stream);
+                                  (long long)(Nout - split_row) * Kin, grad_out_hi, stream, out_scale);
 }
 
 // dW[Nout, Kin] = dY^T · X with dY [R, Nout] read in place (K-major) and X given TRANSPOSED, XT [Kin, rpad] (zero beyond
 // column R; rpad a multiple of 1024): the operand a cast / LayerNorm pass had to rewrite anyway.
 int wgrad_tn_launch(int dtype, const void* dY, long long ldy, const void* XT, long long rpad, long long R, int Nout, int Kin,
-                    float* part, size_t part_bytes, int out_dtype, void* grad_out, int* counters, hipStream_t stream) {
+                    float* part, size_t part_bytes, int out_dtype, void* grad_out, int* counters, hipStream_t stream,
+                    const float* out_scale) {
     if (R <= 0 || Nout <= 0 || Kin % 256 != 0 || Nout % 8 != 0 || ldy % 8 != 0 || rpad % 1024 != 0 || rpad < R) {
         set_error("tp wgrad: unsupported shape R=%lld rpad=%lld Nout=%d Kin=%d", R, rpad, Nout, Kin);
         return TP_ERR_INVALID_ARG;
@@ -158,7 +174,7 @@ int wgrad_tn_launch(int dtype, const void* dY, long long ldy, const void* XT, lo
     a.M = Nout; a.N = Kin; a.K = (int)Ks; a.groups = S; a.tt_rows = R; a.tt_w_kcontig = 1; a.rows_per_batch = Nout; a.tile = 256;
     a.tile_counters = S <= 4 ? counters : nullptr;
     TP_TRY(gemm_launch(dtype, TP_F32, a, stream));
-    return bw_reduce_parts_launch(out_dtype, part, (long long)Nout * Kin, S, (long long)Nout * Kin, grad_out, stream);
+    return bw_reduce_parts_launch(out_dtype, part, (long long)Nout * Kin, S, (long long)Nout * Kin, grad_out, stream, out_scale);
 }
 
 }  // namespace tp
@@ -203,7 +219,7 @@ size_t tp_train_workspace_bytes(const tp_desc* desc) {
 size_t tp_backward_workspace_bytes(const tp_desc* desc) {
     tp::TuningScope tuning_scope(desc);
     if (validate_desc(desc) != TP_OK) return 0;
-    return bw_layout(desc->batch, desc->raw_grid, desc->scale_factor, desc->hidden_size).total;
+    return bw_layout(desc->batch, desc->raw_grid, desc->scale_factor, desc->hidden_size, bw_f16_chain(desc)).total;
 }
 
 int tp_forward_train(const tp_desc* desc, const void* x, const int64_t x_strides[3], const void* x_multi,
@@ -241,11 +257,16 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
             if (!gp[i] || !wp[i]) { set_error("tp_backward: weight / gradient pointer #%zu is NULL", i); return TP_ERR_INVALID_ARG; }
     }
     if (desc->out_dtype != desc->dtype) { set_error("tp_backward: out_dtype must equal dtype"); return TP_ERR_INVALID_ARG; }
-    const int B = desc->batch, g = desc->raw_grid, s = desc->scale_factor, D = desc->hidden_size, GT = desc->dtype;
+    const int B = desc->batch, g = desc->raw_grid, s = desc->scale_factor, D = desc->hidden_size;
+    // MT: the model dtype — weights, x_multi, dy and the parameter gradients.  GT: the dtype gradients TRAVEL in between the
+    // backward's kernels: fp16 behind a dynamic power-of-two scale for a bf16 model (bw_f16_chain), the model dtype otherwise.
+    const int MT = desc->dtype;
+    const bool f16_chain = bw_f16_chain(desc);
+    const int GT = f16_chain ? TP_F16 : MT;
     const int N = g * g, Gq = g / s, M = Gq * Gq, E = kEmbed;
     const int R = B * N, Rq = B * M;
     const WorkspaceLayout W = workspace_layout(B, g, s, D, true);
-    const BwLayout L = bw_layout(B, g, s, D);
+    const BwLayout L = bw_layout(B, g, s, D, f16_chain);
     if (bw_workspace_bytes < L.total) {
         set_error("tp_backward: workspace %zu B < required %zu B", bw_workspace_bytes, L.total);
         return TP_ERR_WORKSPACE;
@@ -262,6 +283,8 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
     float* colpart = (float*)(bw + L.colpart);
     float* redscratch = (float*)(bw + L.redscratch);
     const long long kvE = (long long)R * E;
+    float* const scale = f16_chain ? (float*)(bw + L.scale) : nullptr;          // [0] = S, [1] = 1 / S (device)
+    const float* const inv_scale = scale ? scale + 1 : nullptr;
 
     int* counters = tuning(TP_TUNE_DYNAMIC_TILES) ? (int*)(bw + L.counters) : nullptr;
     if (counters) {
@@ -281,14 +304,14 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
     };
     // bias gradient from the column-sum partials the last transpose left behind
     auto bias_grad = [&](int rpad, int cols, void* out) -> int {
-        return bw_reduce_many_parts_launch(GT, colpart, cols, rpad / 64, cols, out, redscratch, stream);
+        return bw_reduce_many_parts_launch(MT, colpart, cols, rpad / 64, cols, out, redscratch, stream, inv_scale);
     };
     // dX[rows, Kin] = dY[rows, Nout] · W[Nout, Kin]  with W^T [Kin, Nout] given
     auto dgrad = [&](const void* dY, long long ldy, int rows, int Nout, const void* WT, int Kin, void* dX, long long ldx,
-                     int flags = 0, const void* Z = nullptr, long long ldz = 0) -> int {
+                     int flags = 0, const void* Z = nullptr, long long ldz = 0, int out_dt = -1) -> int {
         GemmArgs a = plain_gemm(dY, ldy, WT, dX, ldx, rows, Kin, Nout, nullptr, flags);
         a.Z = (const char*)Z; a.ldz = ldz;
-        return launch(GT, GT, a);
+        return launch(GT, out_dt < 0 ? GT : out_dt, a);
     };
     // dW[Nout, Kin] = dY^T[Nout, rpad] · X^T[Kin, rpad]^T, split over the token dimension
     auto wgrad = [&](const void* dYT, const void* XT, int Nout, int Kin, int rpad, void* grad_out) -> int {
@@ -301,62 +324,77 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
         a.groups = S; a.a_gs = (long long)(rpad / S) * 2; a.w_gs = (long long)(rpad / S) * 2; a.c_gs = (long long)Nout * Kin * 4;
         a.tile = (Nout % 256 == 0 && Kin % 256 == 0) ? 0 : 128;      // auto: 256-tile persistent kernel once S * tiles fills the chip
         TP_TRY(launch(GT, TP_F32, a));
-        return bw_reduce_parts_launch(GT, part, (long long)Nout * Kin, S, (long long)Nout * Kin, grad_out, stream);
+        return bw_reduce_parts_launch(MT, part, (long long)Nout * Kin, S, (long long)Nout * Kin, grad_out, stream, inv_scale);
     };
 
     // The same from dY in place (K-major GEMM operand, no dY^T): bias gradient by a column-sum pass over dY, weight
     // gradient with the activation operand either in place as well (`X` row-major in the model dtype) or transposed
     // (`XT` [Kin, rpad]: fp16 activations of a bf16 model are cast, LayerNorm inputs normalised, by that transpose).
     auto next_counters = [&]() -> int* { return (counters && launch_no < 64) ? counters + 32 * launch_no++ : nullptr; };
-    auto bias_grad_rows = [&](const void* dY, long long ldy, long long rows, int cols, void* out) -> int {
-        const int slices = bw_colsum_rows_launch(GT, dY, ldy, rows, cols, colpart, stream);
+    // (`dt`: the dtype dY is stored in; `sc`: the 1 / S its values carry, NULL for the unscaled incoming dy)
+    auto bias_grad_rows = [&](const void* dY, long long ldy, long long rows, int cols, void* out, int dt, const float* sc) -> int {
+        const int slices = bw_colsum_rows_launch(dt, dY, ldy, rows, cols, colpart, stream);
         if (slices < 0) return slices;
-        return bw_reduce_many_parts_launch(GT, colpart, cols, slices, cols, out, redscratch, stream);
+        return bw_reduce_many_parts_launch(MT, colpart, cols, slices, cols, out, redscratch, stream, sc);
     };
     auto wgrad_rows = [&](const void* dY, long long ldy, long long rows, int rpad, int Nout, int Kin, const void* X, long long ldx,
                           int x_dtype, char* XT_scratch, void* grad_out, const float* mr = nullptr, const float* gam = nullptr,
                           const float* bet = nullptr) -> int {
         const WgradX XR{X, ldx, 0, 0, nullptr, 0};
         if (x_dtype == GT && !mr && wgrad_tt_supported(rows, Nout, Kin, XR, ldy))
-            return wgrad_tt_launch(GT, dY, ldy, XR, rows, Nout, Kin, part, L.part_bytes, GT, grad_out, next_counters(), stream);
+            return wgrad_tt_launch(GT, dY, ldy, XR, rows, Nout, Kin, part, L.part_bytes, MT, grad_out, next_counters(), stream,
+                                   nullptr, 0, inv_scale);
+        if (!XT_scratch) { set_error("tp_backward: a row-major operand the K-major weight gradient cannot read in place (rows %lld, %d x %d)", rows, Nout, Kin); return TP_ERR_INVALID_ARG; }
         TP_TRY(T(x_dtype, X, ldx, (int)rows, Kin, XT_scratch, rpad, mr, gam, bet));
-        return wgrad_tn_launch(GT, dY, ldy, XT_scratch, rpad, rows, Nout, Kin, part, L.part_bytes, GT, grad_out, next_counters(),
-                               stream);
+        return wgrad_tn_launch(GT, dY, ldy, XT_scratch, rpad, rows, Nout, Kin, part, L.part_bytes, MT, grad_out, next_counters(),
+                               stream, inv_scale);
     };
     const bool inplace = (D % 256 == 0);                // (E = 1024 always is): every weight's Kin is a multiple of 256
 
     // ---- operands the backward needs in its own layout --------------------------------------------------------
     // transposed weights (model dtype): W [out, in] -> W^T [in, out]
-    TP_TRY(T(GT, raw->mlp_2_weight, D, D, D, bw + L.wt_m2, D));
-    TP_TRY(T(GT, raw->mlp_0_weight, E, D, E, bw + L.wt_m0, D));
-    TP_TRY(T(GT, raw->clip_attn_out_proj_weight, E, E, E, bw + L.wt_out, E));
+    TP_TRY(T(MT, raw->mlp_2_weight, D, D, D, bw + L.wt_m2, D));
+    TP_TRY(T(MT, raw->mlp_0_weight, E, D, E, bw + L.wt_m0, D));
+    TP_TRY(T(MT, raw->clip_attn_out_proj_weight, E, E, E, bw + L.wt_out, E));
     for (int t = 0; t < 3; ++t)
-        TP_TRY(T(GT, (const char*)raw->clip_attn_in_proj_weight + (size_t)t * E * E * 2, E, E, E, bw + L.wt_in + (size_t)t * E * E * 2, E));
-    TP_TRY(T(GT, raw->k_proj_1_2_weight, E, E, E, bw + L.wt_2, E));
-    TP_TRY(T(GT, raw->v_proj_1_2_weight, E, E, E, bw + L.wt_2 + (size_t)E * E * 2, E));
+        TP_TRY(T(MT, (const char*)raw->clip_attn_in_proj_weight + (size_t)t * E * E * 2, E, E, E, bw + L.wt_in + (size_t)t * E * E * 2, E));
+    TP_TRY(T(MT, raw->k_proj_1_2_weight, E, E, E, bw + L.wt_2, E));
+    TP_TRY(T(MT, raw->v_proj_1_2_weight, E, E, E, bw + L.wt_2 + (size_t)E * E * 2, E));
     float* ln_g = (float*)(bw + L.ln_g);
     float* ln_b = (float*)(bw + L.ln_b);
     const void* gam_src[3] = {raw->ln_q_1_weight, raw->ln_k_1_weight, raw->ln_v_1_weight};
     const void* bet_src[3] = {raw->ln_q_1_bias, raw->ln_k_1_bias, raw->ln_v_1_bias};
     for (int t = 0; t < 3; ++t) {
-        TP_TRY(pack_cast_f32_launch(GT, gam_src[t], ln_g + t * E, E, stream));
-        TP_TRY(pack_cast_f32_launch(GT, bet_src[t], ln_b + t * E, E, stream));
+        TP_TRY(pack_cast_f32_launch(MT, gam_src[t], ln_g + t * E, E, stream));
+        TP_TRY(pack_cast_f32_launch(MT, bet_src[t], ln_b + t * E, E, stream));
     }
 
+    // ---- the incoming gradient: as it is, or (fp16 chain) scaled by a dynamic power of two and cast ----------------------
+    // (ONE pass over dy gives mlp[2]'s bias gradient — column sums of the unscaled dy — and max |dy| for the scale)
+    const void* dyc = dy;                               // what the chain reads (dtype GT)
+    {
+        int n_amax = 0;
+        const int slices = bw_colsum_rows_launch(MT, dy, D, Rq, D, colpart, stream, f16_chain ? (float*)(bw + L.amaxpart) : nullptr, &n_amax);
+        if (slices < 0) return slices;
+        TP_TRY(bw_reduce_many_parts_launch(MT, colpart, D, slices, D, grads->mlp_2_bias, redscratch, stream, nullptr));
+        if (f16_chain) {
+            TP_TRY(bw_scale_from_partials_launch((const float*)(bw + L.amaxpart), n_amax, scale, stream));
+            TP_TRY(bw_scale_cast_launch(MT, dy, (long long)Rq * D, scale, bw + L.dy16, stream));
+            dyc = bw + L.dy16;
+        }
+    }
     // ---- mlp[2] ---------------------------------------------------------------------------------------------
     if (inplace) {
-        TP_TRY(bias_grad_rows(dy, D, Rq, D, grads->mlp_2_bias));
-        TP_TRY(wgrad_rows(dy, D, Rq, Rqp, D, D, fw + W.a2, D, TP_F16, bw + L.xt, grads->mlp_2_weight));
+        TP_TRY(wgrad_rows(dyc, D, Rq, Rqp, D, D, fw + W.a2, D, TP_F16, bw + L.xt, grads->mlp_2_weight));
     } else {
-        TP_TRY(T(GT, dy, D, Rq, D, bw + L.dyT, Rqp, nullptr, nullptr, nullptr, colpart));
-        TP_TRY(bias_grad(Rqp, D, grads->mlp_2_bias));
+        TP_TRY(T(GT, dyc, D, Rq, D, bw + L.dyT, Rqp));
         TP_TRY(T(TP_F16, fw + W.a2, D, Rq, D, bw + L.xt, Rqp));
         TP_TRY(wgrad(bw + L.dyT, bw + L.xt, D, D, Rqp, grads->mlp_2_weight));
     }
-    TP_TRY(dgrad(dy, D, Rq, D, bw + L.wt_m2, D, bw + L.dz2, D, TP_LINEAR_GELU_BWD, fw + W.z2, D));
+    TP_TRY(dgrad(dyc, D, Rq, D, bw + L.wt_m2, D, bw + L.dz2, D, TP_LINEAR_GELU_BWD, fw + W.z2, D));
     // ---- mlp[0] ---------------------------------------------------------------------------------------------
     if (inplace) {
-        TP_TRY(bias_grad_rows(bw + L.dz2, D, Rq, D, grads->mlp_0_bias));
+        TP_TRY(bias_grad_rows(bw + L.dz2, D, Rq, D, grads->mlp_0_bias, GT, inv_scale));
         TP_TRY(wgrad_rows(bw + L.dz2, D, Rq, Rqp, D, E, fw + W.a1, E, TP_F16, bw + L.xt, grads->mlp_0_weight));
     } else {
         TP_TRY(T(GT, bw + L.dz2, D, Rq, D, bw + L.dz2T, Rqp, nullptr, nullptr, nullptr, colpart));
@@ -366,7 +404,7 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
     }
     TP_TRY(dgrad(bw + L.dz2, D, Rq, D, bw + L.wt_m0, E, bw + L.da1, E));
     // ---- out_proj ---------------------------------------------------------------------------------------------
-    TP_TRY(bias_grad_rows(bw + L.da1, E, Rq, E, grads->clip_attn_out_proj_bias));
+    TP_TRY(bias_grad_rows(bw + L.da1, E, Rq, E, grads->clip_attn_out_proj_bias, GT, inv_scale));
     TP_TRY(wgrad_rows(bw + L.da1, E, Rq, Rqp, E, E, fw + W.o, E, TP_F16, bw + L.xt, grads->clip_attn_out_proj_weight));
     TP_TRY(dgrad(bw + L.da1, E, Rq, E, bw + L.wt_out, E, bw + L.dO, E));
     // ---- region attention ---------------------------------------------------------------------------------------
@@ -375,50 +413,55 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
     // ---- attention in-projection (rows of in_proj_weight / in_proj_bias: q | k | v) --------------------------------
     char* g_inw = (char*)grads->clip_attn_in_proj_weight;
     char* g_inb = (char*)grads->clip_attn_in_proj_bias;
-    //   q
-    TP_TRY(bias_grad_rows(bw + L.dQ, E, Rq, E, g_inb));
-    TP_TRY(wgrad_rows(bw + L.dQ, E, Rq, Rqp, E, E, fw + W.q1pre, E, TP_F16, bw + L.xt, g_inw, (const float*)(fw + W.mr_q), ln_g, ln_b));
-    TP_TRY(dgrad(bw + L.dQ, E, Rq, E, bw + L.wt_in, E, bw + L.dq1, E));
-    //   k, v
-    for (int t = 0; t < 2; ++t) {
-        const char* dX = bw + L.dKV + (size_t)t * kvE * 2;
-        char* x1T = bw + L.xt;
-        const float* mr = (const float*)(fw + W.mr_kv) + (size_t)t * R * 2;
-        TP_TRY(bias_grad_rows(dX, E, R, E, g_inb + (size_t)(1 + t) * E * 2));
-        TP_TRY(wgrad_rows(dX, E, R, Rp, E, E, fw + W.h2 + (size_t)t * kvE * 2, E, TP_F16, x1T, g_inw + (size_t)(1 + t) * E * E * 2,
-                          mr, ln_g + (1 + t) * E, ln_b + (1 + t) * E));
-        TP_TRY(dgrad(dX, E, R, E, bw + L.wt_in + (size_t)(1 + t) * E * E * 2, E, bw + L.dkv1 + (size_t)t * kvE * 2, E));
-    }
-    // ---- LayerNorms ---------------------------------------------------------------------------------------------
+    // Per LayerNorm'd input (q, then k, v): bias gradient of its in-projection rows, dgrad through the in-projection, the
+    // LayerNorm backward — which also leaves the LayerNorm's OUTPUT row-major in the gradient dtype (the in-projection's weight
+    // gradient reads it in place: no transposing / normalising pass) and the column sums of its dx (the bias gradient of the layer
+    // in front of the LayerNorm) —, then the in-projection's weight gradient.
     float* lnpart = (float*)(bw + L.lnpart);
+    const int nb = 256;
+    char* const xn = bw + L.xt;                          // the LayerNorm output of the moment [rows, E] (GT); consumed by the next launch
+    //   q
+    TP_TRY(bias_grad_rows(bw + L.dQ, E, Rq, E, g_inb, GT, inv_scale));
+    TP_TRY(dgrad(bw + L.dQ, E, Rq, E, bw + L.wt_in, E, bw + L.dq1, E));
+    TP_TRY(bw_ln_backward_launch(GT, bw + L.dq1, fw + W.q1pre, (const float*)(fw + W.mr_q), ln_g, bw + L.dQ1pre, lnpart, nb, Rq, stream,
+                                 ln_b, xn));
+    TP_TRY(bw_reduce_many_parts_launch(MT, lnpart, 3 * E, nb, E, grads->ln_q_1_weight, redscratch, stream, inv_scale));
+    TP_TRY(bw_reduce_many_parts_launch(MT, lnpart + E, 3 * E, nb, E, grads->ln_q_1_bias, redscratch, stream, inv_scale));
+    TP_TRY(wgrad_rows(bw + L.dQ, E, Rq, Rqp, E, E, xn, E, GT, nullptr, g_inw));
+    //   k, v
     {
-        const int nb = 256;
-        TP_TRY(bw_ln_backward_launch(GT, bw + L.dq1, fw + W.q1pre, (const float*)(fw + W.mr_q), ln_g, bw + L.dQ1pre, lnpart, nb, Rq, stream));
-        TP_TRY(bw_reduce_many_parts_launch(GT, lnpart, 2 * E, nb, E, grads->ln_q_1_weight, redscratch, stream));
-        TP_TRY(bw_reduce_many_parts_launch(GT, lnpart + E, 2 * E, nb, E, grads->ln_q_1_bias, redscratch, stream));
         void* gw[2] = {grads->ln_k_1_weight, grads->ln_v_1_weight};
         void* gb[2] = {grads->ln_k_1_bias, grads->ln_v_1_bias};
+        void* gb2[2] = {grads->k_proj_1_2_bias, grads->v_proj_1_2_bias};
         for (int t = 0; t < 2; ++t) {
+            const char* dX = bw + L.dKV + (size_t)t * kvE * 2;
+            // (in_proj_bias, v third: colsum(dV) = colsum(dO) — dv_j = p_j dO and every head's p sums to 1 over a region's keys — a
+            // pass over the 4 x smaller [Rq, E] instead of [R, E]; k third: colsum(dK), mathematically zero, summed as it is stored)
+            if (t == 1) TP_TRY(bias_grad_rows(bw + L.dO, E, Rq, E, g_inb + (size_t)2 * E * 2, GT, inv_scale));
+            else TP_TRY(bias_grad_rows(dX, E, R, E, g_inb + (size_t)(1 + t) * E * 2, GT, inv_scale));
+            TP_TRY(dgrad(dX, E, R, E, bw + L.wt_in + (size_t)(1 + t) * E * E * 2, E, bw + L.dkv1 + (size_t)t * kvE * 2, E));
             TP_TRY(bw_ln_backward_launch(GT, bw + L.dkv1 + (size_t)t * kvE * 2, fw + W.h2 + (size_t)t * kvE * 2,
                                          (const float*)(fw + W.mr_kv) + (size_t)t * R * 2, ln_g + (1 + t) * E,
-                                         bw + L.dH2 + (size_t)t * kvE * 2, lnpart, nb, R, stream));
-            TP_TRY(bw_reduce_many_parts_launch(GT, lnpart, 2 * E, nb, E, gw[t], redscratch, stream));
-            TP_TRY(bw_reduce_many_parts_launch(GT, lnpart + E, 2 * E, nb, E, gb[t], redscratch, stream));
+                                         bw + L.dH2 + (size_t)t * kvE * 2, lnpart, nb, R, stream, ln_b + (1 + t) * E, xn));
+            TP_TRY(bw_reduce_many_parts_launch(MT, lnpart, 3 * E, nb, E, gw[t], redscratch, stream, inv_scale));
+            TP_TRY(bw_reduce_many_parts_launch(MT, lnpart + E, 3 * E, nb, E, gb[t], redscratch, stream, inv_scale));
+            TP_TRY(bw_reduce_many_parts_launch(MT, lnpart + 2 * E, 3 * E, nb, E, gb2[t], redscratch, stream, inv_scale));   // colsum(dH2)
+            TP_TRY(wgrad_rows(dX, E, R, Rp, E, E, xn, E, GT, nullptr, g_inw + (size_t)(1 + t) * E * E * 2));
         }
     }
     // ---- q_proj_1 (no bias) ---------------------------------------------------------------------------------------
     TP_TRY(wgrad_rows(bw + L.dQ1pre, E, Rq, Rqp, E, E, fw + W.q0, E, TP_F16, bw + L.xt, grads->q_proj_1_weight));
     // ---- k/v_proj_1[2] -----------------------------------------------------------------------------------------------
     {
-        void* gw[2] = {grads->k_proj_1_2_weight, grads->v_proj_1_2_weight};
-        void* gb[2] = {grads->k_proj_1_2_bias, grads->v_proj_1_2_bias};
+        void* gw[2] = {grads->k_proj_1_2_weight, grads->v_proj_1_2_weight};     // (the bias gradients: colsum(dH2) from the LayerNorm backward above)
         for (int t = 0; t < 2; ++t) {
             const char* dH = bw + L.dH2 + (size_t)t * kvE * 2;
             char* hT = bw + L.xt;
-            TP_TRY(bias_grad_rows(dH, E, R, E, gb[t]));
             TP_TRY(wgrad_rows(dH, E, R, Rp, E, E, fw + W.hkv + (size_t)t * E * 2, 2 * E, TP_F16, hT, gw[t]));
+            // (dZ1 leaves the chain in the MODEL dtype, still scaled by S: x_multi is in that dtype, and the first layer's weight
+            // gradient reads both in place)
             TP_TRY(dgrad(dH, E, R, E, bw + L.wt_2 + (size_t)t * E * E * 2, E, bw + L.dZ1 + (size_t)t * E * 2, 2 * E,
-                         TP_LINEAR_GELU_BWD, fw + W.z1 + (size_t)t * E * 2, 2 * E));
+                         TP_LINEAR_GELU_BWD, fw + W.z1 + (size_t)t * E * 2, 2 * E, MT));
         }
     }
     // ---- k/v_proj_1[0] -----------------------------------------------------------------------------------------------
@@ -431,24 +474,24 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
         return TP_ERR_INVALID_ARG;
     }
     if (xm_tt) {
-        const int slices = bw_colsum_rows_launch(GT, bw + L.dZ1, 2 * E, R, 2 * E, colpart, stream);
+        const int slices = bw_colsum_rows_launch(MT, bw + L.dZ1, 2 * E, R, 2 * E, colpart, stream);
         if (slices < 0) return slices;
-        TP_TRY(bw_reduce_many_parts_launch(GT, colpart, 2 * E, slices, E, grads->k_proj_1_0_bias, redscratch, stream));
-        TP_TRY(bw_reduce_many_parts_launch(GT, colpart + E, 2 * E, slices, E, grads->v_proj_1_0_bias, redscratch, stream));
+        TP_TRY(bw_reduce_many_parts_launch(MT, colpart, 2 * E, slices, E, grads->k_proj_1_0_bias, redscratch, stream, inv_scale));
+        TP_TRY(bw_reduce_many_parts_launch(MT, colpart + E, 2 * E, slices, E, grads->v_proj_1_0_bias, redscratch, stream, inv_scale));
         int* ctr = (counters && launch_no < 64) ? counters + 32 * launch_no++ : nullptr;
-        return wgrad_tt_launch(GT, bw + L.dZ1, 2 * E, XM, R, 2 * E, kMulti, part, L.part_bytes, GT, grads->k_proj_1_0_weight,
-                               ctr, stream, grads->v_proj_1_0_weight, E);
+        return wgrad_tt_launch(MT, bw + L.dZ1, 2 * E, XM, R, 2 * E, kMulti, part, L.part_bytes, MT, grads->k_proj_1_0_weight,
+                               ctr, stream, grads->v_proj_1_0_weight, E, inv_scale);
     }
-    TP_TRY(T(GT, bw + L.dZ1, 2 * E, R, 2 * E, bw + L.dZ1T, Rp, nullptr, nullptr, nullptr, colpart));
-    TP_TRY(bw_reduce_many_parts_launch(GT, colpart, 2 * E, Rp / 64, E, grads->k_proj_1_0_bias, redscratch, stream));
-    TP_TRY(bw_reduce_many_parts_launch(GT, colpart + E, 2 * E, Rp / 64, E, grads->v_proj_1_0_bias, redscratch, stream));
+    TP_TRY(bw_transpose_launch(MT, MT, bw + L.dZ1, 2 * E, R, 0, R, 2 * E, bw + L.dZ1T, Rp, Rp, nullptr, nullptr, nullptr, colpart, stream));
+    TP_TRY(bw_reduce_many_parts_launch(MT, colpart, 2 * E, Rp / 64, E, grads->k_proj_1_0_bias, redscratch, stream, inv_scale));
+    TP_TRY(bw_reduce_many_parts_launch(MT, colpart + E, 2 * E, Rp / 64, E, grads->v_proj_1_0_bias, redscratch, stream, inv_scale));
     if (xm_parts) {                                     // four [B, N, 1024] sources -> rows part*1024 .. of x_multi^T
         for (int i = 0; i < 4; ++i)
-            TP_TRY(bw_transpose_launch(GT, GT, xm_parts[i], xm_strides[1], N, xm_strides[0], R, kMulti / 4,
+            TP_TRY(bw_transpose_launch(MT, MT, xm_parts[i], xm_strides[1], N, xm_strides[0], R, kMulti / 4,
                                        bw + L.xmT + (size_t)i * (kMulti / 4) * Rp * 2, Rp, Rp, nullptr, nullptr, nullptr,
                                        nullptr, stream));
     } else {
-        TP_TRY(bw_transpose_launch(GT, GT, x_multi, xm_strides[1], N, xm_strides[0], R, kMulti, bw + L.xmT, Rp, Rp, nullptr,
+        TP_TRY(bw_transpose_launch(MT, MT, x_multi, xm_strides[1], N, xm_strides[0], R, kMulti, bw + L.xmT, Rp, Rp, nullptr,
                                    nullptr, nullptr, nullptr, stream));
     }
     {   // dW0 [2E, 4096] = dZ1^T · x_multi: rows 0..E-1 belong to k_proj_1[0], E..2E-1 to v_proj_1[0]
@@ -457,10 +500,10 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
         GemmArgs a = plain_gemm(bw + L.dZ1T, Rp, bw + L.xmT, part, Kin, Nout, Kin, Rp / S, nullptr, 0);
         a.ldw_bytes = (long long)Rp * 2;
         a.groups = S; a.a_gs = (long long)(Rp / S) * 2; a.w_gs = (long long)(Rp / S) * 2; a.c_gs = (long long)Nout * Kin * 4;
-        TP_TRY(launch(GT, TP_F32, a));
-        TP_TRY(bw_reduce_parts_launch(GT, part, (long long)Nout * Kin, S, (long long)E * Kin, grads->k_proj_1_0_weight, stream));
-        TP_TRY(bw_reduce_parts_launch(GT, part + (size_t)E * Kin, (long long)Nout * Kin, S, (long long)E * Kin,
-                                      grads->v_proj_1_0_weight, stream));
+        TP_TRY(launch(MT, TP_F32, a));
+        TP_TRY(bw_reduce_parts_launch(MT, part, (long long)Nout * Kin, S, (long long)E * Kin, grads->k_proj_1_0_weight, stream, inv_scale));
+        TP_TRY(bw_reduce_parts_launch(MT, part + (size_t)E * Kin, (long long)Nout * Kin, S, (long long)E * Kin,
+                                      grads->v_proj_1_0_weight, stream, inv_scale));
     }
     return TP_OK;
 }

@@ -54,7 +54,12 @@ def main():
     ap.add_argument("--out", default="gpurun_out/train_bench.json")
     ap.add_argument("--hip-only", action="store_true", help="skip the eager baseline (profiling runs)")
     ap.add_argument("--optimizer", default="sgd", choices=["sgd", "none"])
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="library tuning knob, e.g. BWD_CHAIN=1")
     args = ap.parse_args()
+    from tokenpacker_amd import _capi
+    for kv in args.tune:
+        key, val = kv.split("=")
+        _capi.set_tuning(getattr(_capi, "TP_TUNE_" + key.upper()), int(val))
     s, D, dtype = args.scale_factor, args.hidden_size, torch.bfloat16
     results = []
     for B in args.batches:
@@ -113,7 +118,7 @@ def main():
                "optimizer_in_step": args.optimizer,
                "train_tflops_algorithmic": round(flops_train(B, s, D) / ms_hip / 1e9, 1),
                "train_gflop_per_image": round(flops_train(1, s, D) / 1e9, 2),
-               "weights_finite_after_training": finite, "max_param_grad_rel_l2_vs_eager": agree}
+               "weights_finite_after_training": finite, "max_param_grad_rel_l2_vs_eager": agree, "tune": args.tune}
         print(json.dumps(rec), flush=True)
         results.append(rec)
         del m, m_eager, x, xm, w
