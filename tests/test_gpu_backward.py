@@ -13,8 +13,9 @@ from tokenpacker_amd import TokenPacker, synth
 
 pytestmark = pytest.mark.gpu
 
-# gradients travel in the model dtype between kernels (bf16: 8-bit mantissa), accumulate in fp32
-GATE_L2 = {torch.float16: 1e-2, torch.bfloat16: 3e-2}
+# gradients travel in fp16 between the backward's kernels and accumulate in fp32 — for a bf16 model too since round 6 (behind a dynamic
+# power-of-two scale, TP_TUNE_BWD_CHAIN: worst parameter 3.2e-3 where the bf16 chain of rounds 1-5 had 1.6-1.8e-2 under a 3e-2 gate)
+GATE_L2 = {torch.float16: 1e-2, torch.bfloat16: 1e-2}
 
 
 def _grads(dtype, s, D, B, seed):
@@ -40,7 +41,7 @@ def _grads(dtype, s, D, B, seed):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("s,D,B", [(2, 256, 2), (3, 256, 3), (4, 512, 2), (2, 4096, 32)])
+@pytest.mark.parametrize("s,D,B", [(2, 256, 2), (3, 256, 3), (4, 512, 2), (2, 384, 2), (2, 4096, 32)])   # (D = 384: not a multiple of 256 -> the transposed-operand fallback of the mlp weight gradients)
 def test_parameter_gradients_vs_oracle_autograd(dtype, s, D, B):
     """(2, 4096, 32) is the reference's pretraining shape per GPU (pretrain.sh:19): every backward GEMM large
     enough runs on the persistent 256-tile kernel there (dgrad with the GELU' epilogue, split-K wgrad)."""

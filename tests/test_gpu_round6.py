@@ -107,3 +107,53 @@ def test_a_k_dup_gemm_is_bit_identical_on_both_routes(M):
     ref = A.float() @ Wsum.t() + bias
     err = float((c_small.float() - ref).abs().max() / ref.abs().max())
     assert err <= 2e-3, err
+
+
+def _bf16_grads(chain, upstream_scale, seed=77, s=2, D=256, B=3):
+    from tokenpacker_amd import TokenPacker
+    dtype = torch.bfloat16
+    params = synth.make_params(seed, D)
+    x, xm = synth.make_inputs(seed + 1, B, dtype)
+    w = (torch.randn(B, (24 // s) ** 2, D, generator=torch.Generator().manual_seed(seed + 2)) * upstream_scale).to(dtype)
+    m = TokenPacker(hidden_size=D, scale_factor=s)
+    m.load_state_dict(params)
+    m = m.to(device="cuda", dtype=dtype).train()
+    m.tuning = _capi.TuningContext(bwd_chain=chain)
+    y = m((x.cuda(), xm.cuda()))
+    y.backward(w.cuda())                                     # the upstream gradient IS w (bf16), whatever its magnitude
+    torch.cuda.synchronize()
+    return {k: p.grad.detach().float().cpu() for k, p in m.named_parameters()}, (params, x, xm, w)
+
+
+def test_fp16_gradient_chain_is_exactly_scale_invariant_and_survives_any_magnitude():
+    """TP_TUNE_BWD_CHAIN = 0 (default): a bf16 model's gradients travel in fp16 behind S = 2^k chosen from max |dy| on the device.  An
+    upstream gradient multiplied by a power of two therefore gives bit-identical chain values and parameter gradients that are
+    EXACTLY that power of two times the original — from 2^-40 (far below fp16's subnormals) to 2^+30 (far above its maximum)."""
+    g1, _ = _bf16_grads(0, 1.0)
+    for k2 in (-40, -14, 12, 30):
+        gk, _ = _bf16_grads(0, 2.0 ** k2)
+        for name in g1:
+            assert torch.isfinite(gk[name]).all(), (k2, name)
+            assert torch.equal(gk[name], (g1[name].double() * 2.0 ** k2).float().to(torch.bfloat16).float()), (k2, name)
+
+
+def test_both_gradient_chains_against_the_oracle():
+    """The fp16 chain (default) and the bf16 chain of rounds 1-5 (TP_TUNE_BWD_CHAIN = 1) against fp64 autograd on the oracle: same
+    gradients, the fp16 chain several times closer."""
+    from oracle import tokenpacker_oracle as orc2
+    worst = {}
+    for chain in (0, 1):
+        got, (params, x, xm, w) = _bf16_grads(chain, 1.0, seed=91)
+        p_lp = {k: v.to(torch.bfloat16) for k, v in params.items()}
+        ref_p = {k: v.double().requires_grad_(True) for k, v in p_lp.items()}
+        y_ref = orc2.forward(ref_p, x, xm, scale_factor=2, compute_dtype=torch.float64, io_dtype=torch.bfloat16)
+        y_ref.backward(w.double())
+        want = {k: v.grad for k, v in ref_p.items()}
+        rms = {k: float(v.norm()) / v.numel() ** 0.5 for k, v in want.items()}
+        errs = []
+        for k in want:
+            scale = max(rms[k], 0.1 * max(rms[j] for j in want if want[j].shape == want[k].shape))
+            errs.append(float((got[k].double() - want[k]).norm()) / want[k].numel() ** 0.5 / scale)
+        worst[chain] = max(errs)
+        print(f"\n[grad] bf16 model, TP_TUNE_BWD_CHAIN={chain}: worst parameter rel_l2 {worst[chain]:.3e}")
+    assert worst[0] <= 1e-2 and worst[1] <= 3e-2 and worst[0] < worst[1]
