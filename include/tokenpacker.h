@@ -396,6 +396,11 @@ int tp_hd_slice(const float* image, int H, int W, int h_block, int w_block, int 
 int tp_debug_count_saturated(const tp_desc* desc, const void* workspace, size_t workspace_bytes, int32_t* counts,
                              void* stream);
 
+/* The first TP_WORKSPACE_STATUS_BYTES of tp_backward's workspace are a status block like the forward workspace's: int32 word 0 holds
+ * the sticky saturation bits of THAT backward (zeroed by the call itself): bit 0 — the incoming dy was not finite, or a GEMM epilogue of
+ * the fp16 gradient chain clamped a value to +-65504; bit 1 — the LayerNorm backward did; bit 2 — the attention backward did.  Non-zero
+ * means the parameter gradients of that call are not trustworthy (TP_TUNE_BWD_CHAIN = 1 carries the gradients in bf16 instead). */
+
 /* ---- diagnostics counters of this process (read-only; ABI 5: the round-3/4 test hooks tp_test_side_cache_size /
  * tp_test_pair_launch_count under one entry — the other, stateless test hooks and the timing-probe instantiations of the GEMM
  * kernels are NOT in this library: include/tokenpacker_test.h, libtokenpacker_exp.so):

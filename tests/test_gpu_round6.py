@@ -157,3 +157,34 @@ def test_both_gradient_chains_against_the_oracle():
         worst[chain] = max(errs)
         print(f"\n[grad] bf16 model, TP_TUNE_BWD_CHAIN={chain}: worst parameter rel_l2 {worst[chain]:.3e}")
     assert worst[0] <= 1e-2 and worst[1] <= 3e-2 and worst[0] < worst[1]
+
+
+def test_a_backward_that_leaves_fp16_says_so():
+    """The fp16 gradient chain clamps instead of producing inf — and reports it: the backward workspace's status word (bit 0: the
+    incoming dy was not finite / a GEMM epilogue clamped, bit 1: LayerNorm backward, bit 2: attention backward), which the module
+    reads without synchronising and warns about once.  A clean backward leaves it 0."""
+    import warnings
+    from tokenpacker_amd import TokenPacker
+    dtype, s_, D, B = torch.bfloat16, 2, 256, 2
+    params = synth.make_params(31, D)
+    x, xm = synth.make_inputs(32, B, dtype)
+    m = TokenPacker(hidden_size=D, scale_factor=s_)
+    m.load_state_dict(params)
+    m = m.to(device="cuda", dtype=dtype).train()
+    w = torch.randn(B, 144, D, generator=torch.Generator().manual_seed(33)).to(dtype).cuda()
+    m((x.cuda(), xm.cuda())).backward(w)
+    torch.cuda.synchronize()
+    assert m.backward_saturated() == 0
+    m.zero_grad(set_to_none=True)
+    w_bad = w.clone()
+    w_bad[0, 0, 0] = float("inf")                            # no finite scale brings this into fp16's range
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        m((x.cuda(), xm.cuda())).backward(w_bad)
+        torch.cuda.synchronize()
+        assert m.backward_saturated() & 1
+        m.zero_grad(set_to_none=True)
+        m((x.cuda(), xm.cuda())).backward(w)                 # the next backward finds the finished copy of the word and warns
+        torch.cuda.synchronize()
+    assert any("saturated fp16" in str(r.message) for r in rec), [str(r.message) for r in rec]
+    assert m.backward_saturated() == 0                       # (the word belongs to ONE backward: this clean one cleared it)

@@ -16,6 +16,15 @@ template <typename T> __device__ __forceinline__ T sat_cast(float v);
 template <> __device__ __forceinline__ f16_t sat_cast<f16_t>(float v) { return (f16_t)fminf(fmaxf(v, -65504.f), 65504.f); }
 template <> __device__ __forceinline__ bf16_t sat_cast<bf16_t>(float v) { return (bf16_t)v; }
 template <> __device__ __forceinline__ float sat_cast<float>(float v) { return v; }
+// Sticky saturation report of the backward's fp16 chain (tp_backward's status word, bit `bit`): a wave in which any lane is about
+// to clamp (|v| >= 65520: what IEEE rounding would have turned into an fp16 inf; NaN counts) ORs the bit — one ballot per call site
+// and, when it fires, one atomic per wave.  `flag` NULL: nothing.
+template <typename T> __device__ __forceinline__ void bw_sat_report(int* flag, int bit, float max_abs) {
+    if constexpr (std::is_same<T, f16_t>::value) {
+        if (flag && __builtin_amdgcn_ballot_w64(!(max_abs < 65520.f)) != 0 && (threadIdx.x & 63) == 0)
+            __hip_atomic_fetch_or(flag, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------
 // dst[c][r] = cast( f(src[r][c]) )  for r < R (zero for R <= r < Rpad), c < C.   f = identity, or the LayerNorm
@@ -315,17 +324,20 @@ scale_from_amax_kernel(const float* __restrict__ part, int nparts, float* __rest
 }
 template <typename TS>
 __global__ void __launch_bounds__(256)
-scale_cast_f16_kernel(const TS* __restrict__ src, long long n8, const float* __restrict__ scale, f16_t* __restrict__ dst) {
+scale_cast_f16_kernel(const TS* __restrict__ src, long long n8, const float* __restrict__ scale, f16_t* __restrict__ dst,
+                      int* __restrict__ sat_flag) {
     using S8 = typename Vec<TS>::x8;
     using D8 = typename Vec<f16_t>::x8;
     const float S = scale[0];
+    float mx = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
         const S8 v = *(const S8*)(src + i * 8);
         D8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = sat_cast<f16_t>((float)v[e] * S);
+        for (int e = 0; e < 8; ++e) { const float f = (float)v[e] * S, a = fabsf(f); mx = (a != a || a > mx) ? a : mx; o[e] = sat_cast<f16_t>(f); }
         *(D8*)(dst + i * 8) = o;
     }
+    bw_sat_report<f16_t>(sat_flag, 1, mx);              // (an inf / NaN in dy, which no finite scale brings into range)
 }
 
 int bw_dynamic_scale_launch(int src_dtype, const void* src, long long n, float* part, float* scale, hipStream_t stream) {
@@ -345,13 +357,13 @@ int bw_scale_from_partials_launch(const float* amax_part, int nparts, float* sca
     return check_launch("scale_from_amax_kernel");
 }
 
-int bw_scale_cast_launch(int src_dtype, const void* src, long long n, const float* scale, void* dst_f16, hipStream_t stream) {
+int bw_scale_cast_launch(int src_dtype, const void* src, long long n, const float* scale, void* dst_f16, hipStream_t stream, int* sat_flag) {
     if ((n & 7) || ((uintptr_t)src & 15) || ((uintptr_t)dst_f16 & 15)) { set_error("bw scale cast: element count must be a multiple of 8, pointers 16-byte aligned"); return TP_ERR_INVALID_ARG; }
     const int nb = 2048;
     if (src_dtype == TP_BF16)
-        hipLaunchKernelGGL(scale_cast_f16_kernel<bf16_t>, dim3(nb), dim3(256), 0, stream, (const bf16_t*)src, n / 8, scale, (f16_t*)dst_f16);
+        hipLaunchKernelGGL(scale_cast_f16_kernel<bf16_t>, dim3(nb), dim3(256), 0, stream, (const bf16_t*)src, n / 8, scale, (f16_t*)dst_f16, sat_flag);
     else if (src_dtype == TP_F16)
-        hipLaunchKernelGGL(scale_cast_f16_kernel<f16_t>, dim3(nb), dim3(256), 0, stream, (const f16_t*)src, n / 8, scale, (f16_t*)dst_f16);
+        hipLaunchKernelGGL(scale_cast_f16_kernel<f16_t>, dim3(nb), dim3(256), 0, stream, (const f16_t*)src, n / 8, scale, (f16_t*)dst_f16, sat_flag);
     else { set_error("bw scale cast: unsupported dtype %d", src_dtype); return TP_ERR_INVALID_ARG; }
     return check_launch("scale_cast_f16_kernel");
 }
@@ -369,9 +381,10 @@ template <typename TG>
 __global__ void __launch_bounds__(256)
 ln_backward_kernel(const TG* __restrict__ dy, const f16_t* __restrict__ x, const float* __restrict__ mean_rstd,
                    const float* __restrict__ gamma, TG* __restrict__ dx, float* __restrict__ part, long long rows,
-                   const float* __restrict__ beta, TG* __restrict__ xn) {
+                   const float* __restrict__ beta, TG* __restrict__ xn, int* __restrict__ sat_flag) {
     constexpr int E = kEmbed;
     __shared__ float red[3][4][E];                       // 48 KiB
+    float sat_mx = 0.f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float dg[16], db[16], gm[16], dxs[16], bt[16];
 #pragma unroll
@@ -403,7 +416,9 @@ ln_backward_kernel(const TG* __restrict__ dy, const f16_t* __restrict__ x, const
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int k = h * 8 + e;
-                o[e] = sat_cast<TG>(rstd * (dyv[k] * gm[k] - m1 - xh[k] * m2));
+                const float dxv = rstd * (dyv[k] * gm[k] - m1 - xh[k] * m2);
+                { const float a = fabsf(dxv); sat_mx = (a != a || a > sat_mx) ? a : sat_mx; }
+                o[e] = sat_cast<TG>(dxv);
                 dxs[k] += (float)o[e];                  // (the ROUNDED value: what a column-sum pass over dx would have read)
                 dg[k] = fmaf(dyv[k], xh[k], dg[k]);
                 db[k] += dyv[k];
@@ -424,17 +439,19 @@ ln_backward_kernel(const TG* __restrict__ dy, const f16_t* __restrict__ x, const
         const int w = i / E, c = i - w * E;
         part[((long long)blockIdx.x * 3 + w) * E + c] = red[w][0][c] + red[w][1][c] + red[w][2][c] + red[w][3][c];
     }
+    bw_sat_report<TG>(sat_flag, 2, sat_mx);
 }
 
 int bw_ln_backward_launch(int gdtype, const void* dy, const void* x_f16, const float* mean_rstd, const float* gamma,
-                          void* dx, float* part, int nblocks, long long rows, hipStream_t stream, const float* beta, void* xn) {
+                          void* dx, float* part, int nblocks, long long rows, hipStream_t stream, const float* beta, void* xn,
+                          int* sat_flag) {
     if (xn && !beta) { set_error("bw ln backward: the normalised output needs beta"); return TP_ERR_INVALID_ARG; }
     if (gdtype == TP_BF16)
         hipLaunchKernelGGL(ln_backward_kernel<bf16_t>, dim3(nblocks), dim3(256), 0, stream, (const bf16_t*)dy,
-                           (const f16_t*)x_f16, mean_rstd, gamma, (bf16_t*)dx, part, rows, beta, (bf16_t*)xn);
+                           (const f16_t*)x_f16, mean_rstd, gamma, (bf16_t*)dx, part, rows, beta, (bf16_t*)xn, sat_flag);
     else
         hipLaunchKernelGGL(ln_backward_kernel<f16_t>, dim3(nblocks), dim3(256), 0, stream, (const f16_t*)dy,
-                           (const f16_t*)x_f16, mean_rstd, gamma, (f16_t*)dx, part, rows, beta, (f16_t*)xn);
+                           (const f16_t*)x_f16, mean_rstd, gamma, (f16_t*)dx, part, rows, beta, (f16_t*)xn, sat_flag);
     return check_launch("ln_backward_kernel");
 }
 
@@ -450,7 +467,9 @@ template <typename TG>
 __global__ void __launch_bounds__(256)
 region_attention_bwd_kernel(const f16_t* __restrict__ q, const f16_t* __restrict__ k, const f16_t* __restrict__ v,
                             const TG* __restrict__ dout, TG* __restrict__ dq, TG* __restrict__ dk, TG* __restrict__ dv,
-                            int B, int g, int s, float scale) {
+                            int B, int g, int s, float scale, int* __restrict__ sat_flag) {
+    float sat_mx = 0.f;
+    auto trk = [&](float v) __attribute__((always_inline)) { const float a = fabsf(v); sat_mx = (a != a || a > sat_mx) ? a : sat_mx; return v; };
     constexpr int E = kEmbed;
     using G8 = typename Vec<TG>::x8;
     const int lane = threadIdx.x & 63;
@@ -521,7 +540,7 @@ region_attention_bwd_kernel(const f16_t* __restrict__ q, const f16_t* __restrict
         Da = fmaf(pa, dot16(pa_), Da); Db = fmaf(pb, dot16(pb_), Db);
         G8 oa, ob;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { oa[e] = sat_cast<TG>(pa * doa[e]); ob[e] = sat_cast<TG>(pb * dob[e]); }
+        for (int e = 0; e < 8; ++e) { oa[e] = sat_cast<TG>(pa * doa[e]); ob[e] = sat_cast<TG>(pb * dob[e]); }   // (|p| <= 1: cannot exceed dO)
         *(G8*)(dv + r + ea) = oa; *(G8*)(dv + r + eb) = ob;
     }
     // sweep 3: dS, dq, dK
@@ -545,28 +564,29 @@ region_attention_bwd_kernel(const f16_t* __restrict__ q, const f16_t* __restrict
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             dqa[e] = fmaf(dsa, ka[e], dqa[e]); dqb[e] = fmaf(dsb, kb[e], dqb[e]);
-            oa[e] = sat_cast<TG>(dsa * qa[e]); ob[e] = sat_cast<TG>(dsb * qb[e]);
+            oa[e] = sat_cast<TG>(trk(dsa * qa[e])); ob[e] = sat_cast<TG>(trk(dsb * qb[e]));
         }
         *(G8*)(dk + r + ea) = oa; *(G8*)(dk + r + eb) = ob;
     }
     G8 oa, ob;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { oa[e] = sat_cast<TG>(dqa[e]); ob[e] = sat_cast<TG>(dqb[e]); }
+    for (int e = 0; e < 8; ++e) { oa[e] = sat_cast<TG>(trk(dqa[e])); ob[e] = sat_cast<TG>(trk(dqb[e])); }
     *(G8*)(dq + qi * E + ea) = oa; *(G8*)(dq + qi * E + eb) = ob;
+    bw_sat_report<TG>(sat_flag, 4, sat_mx);
 }
 
 int bw_region_attention_launch(int gdtype, const void* q, const void* k, const void* v, const void* dout, void* dq,
-                               void* dk, void* dv, int B, int grid, int s, hipStream_t stream) {
+                               void* dk, void* dv, int B, int grid, int s, hipStream_t stream, int* sat_flag) {
     const int G = grid / s, M = G * G;
     const long long nq = (long long)B * M;
     const unsigned blocks = (unsigned)((nq + 3) / 4);
     const float scale = 0.08838834764831845f;   // 1/sqrt(128)
     if (gdtype == TP_BF16)
         hipLaunchKernelGGL(region_attention_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const f16_t*)q,
-                           (const f16_t*)k, (const f16_t*)v, (const bf16_t*)dout, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, B, grid, s, scale);
+                           (const f16_t*)k, (const f16_t*)v, (const bf16_t*)dout, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, B, grid, s, scale, sat_flag);
     else
         hipLaunchKernelGGL(region_attention_bwd_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream, (const f16_t*)q,
-                           (const f16_t*)k, (const f16_t*)v, (const f16_t*)dout, (f16_t*)dq, (f16_t*)dk, (f16_t*)dv, B, grid, s, scale);
+                           (const f16_t*)k, (const f16_t*)v, (const f16_t*)dout, (f16_t*)dq, (f16_t*)dk, (f16_t*)dv, B, grid, s, scale, sat_flag);
     return check_launch("region_attention_bwd_kernel");
 }
 

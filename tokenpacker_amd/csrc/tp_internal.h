@@ -338,7 +338,8 @@ int bw_reduce_parts_launch(int dst_dtype, const float* part, long long part_stri
 // magnitude): scale[0] = S = 2^k with amax(src) * S in (16, 32], scale[1] = 1 / S (S = 1 for an all-zero or non-finite tensor).
 // `part`: >= 1024 floats of scratch.  Then dst_f16 = saturate(src * S).  Nothing here synchronises: S lives on the device.
 int bw_dynamic_scale_launch(int src_dtype, const void* src, long long n, float* part, float* scale, hipStream_t stream);
-int bw_scale_cast_launch(int src_dtype, const void* src, long long n, const float* scale, void* dst_f16, hipStream_t stream);
+int bw_scale_cast_launch(int src_dtype, const void* src, long long n, const float* scale, void* dst_f16, hipStream_t stream,
+                         int* sat_flag = nullptr);
 // Weight gradient straight from the row-major activations (tp_gemm8.hip, K-major operands):
 //   dW[Nout, Kin] = sum over the R token rows of dY[r, n] * X[r, k],   split over the rows, fp32 partials -> out_dtype.
 // X may be batch-strided (rows_per_batch % 64 == 0) and its Kin columns split over four tensors of n_part columns.
@@ -370,9 +371,9 @@ int bw_reduce_many_parts_launch(int dst_dtype, const float* part, long long part
 // part: [nblocks][3][E] — dgamma, dbeta, colsum(dx) partials.  beta / xn (optional): also write the LayerNorm's output in gdtype
 int bw_ln_backward_launch(int gdtype, const void* dy, const void* x_f16, const float* mean_rstd, const float* gamma,
                           void* dx, float* part, int nblocks, long long rows, hipStream_t stream, const float* beta = nullptr,
-                          void* xn = nullptr);
+                          void* xn = nullptr, int* sat_flag = nullptr);
 int bw_region_attention_launch(int gdtype, const void* q, const void* k, const void* v, const void* dout, void* dq,
-                               void* dk, void* dv, int B, int grid, int s, hipStream_t stream);
+                               void* dk, void* dv, int B, int grid, int s, hipStream_t stream, int* sat_flag = nullptr);
 int validate_desc(const tp_desc* d);
 void pack_registry_put(const void* packed, const tp_desc* d, bool train_pack);      // tp_api.hip: what an image was packed for
 int pack_registry_check(const void* packed, const tp_desc* d, bool train);

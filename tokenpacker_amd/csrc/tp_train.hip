@@ -50,6 +50,7 @@ struct BwLayout {
     // fp16 chain of a bf16 model (TP_TUNE_BWD_CHAIN = 0): dy scaled by a dynamic power of two and cast [Rq, D] f16, the scale
     // pair (S, 1 / S) on the device, 1024 amax partials; kNoSlab otherwise
     size_t dy16, scale, amaxpart;
+    size_t status;                                    // 256 B at offset 0: int32[0] = sticky saturation bits of the fp16 gradient chain (tp_backward_status_bytes)
     size_t part_bytes;
     size_t total;
     int Rp, Rqp;
@@ -77,6 +78,7 @@ static BwLayout bw_layout(int B, int grid, int s, int D, bool f16_chain) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = up(off + bytes); return o; };
     auto take_if = [&](bool need, size_t bytes) { return need ? take(bytes) : kNoSlab; };
+    L.status = take(256);                             // (first: the caller finds it at offset 0, like the forward workspace's status block)
     L.wt_m2 = take((size_t)D * D * 2); L.wt_m0 = take(E * D * 2); L.wt_out = take(E * E * 2);
     L.wt_in = take(3 * E * E * 2); L.wt_2 = take(2 * E * E * 2);
     L.ln_g = take(3 * E * 4); L.ln_b = take(3 * E * 4);
@@ -299,9 +301,19 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
         hipError_t e = hipMemsetAsync(counters, 0, 64 * 32 * 4, stream);
         if (e != hipSuccess) { set_error("tp_backward: hipMemsetAsync: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
     }
+    // Sticky saturation word of this backward (offset 0 of the workspace; zeroed here): bit 0 — dy itself was not finite / a GEMM
+    // epilogue of the fp16 chain clamped, bit 1 — LayerNorm backward, bit 2 — attention backward.  fp16's range is what the dynamic
+    // scale buys 2^11 of headroom in; a chain that outgrows it (a LayerNorm row of ~zero variance multiplies by rstd ~ 1e3) clamps
+    // instead of producing inf, and says so here — the module warns once and names TP_TUNE_BWD_CHAIN = 1.
+    int* const sat = GT == TP_F16 ? (int*)(bw + L.status) : nullptr;
+    {
+        hipError_t e = hipMemsetAsync(bw + L.status, 0, 256, stream);
+        if (e != hipSuccess) { set_error("tp_backward: hipMemsetAsync(status): %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
+    }
     int launch_no = 0;
     auto launch = [&](int in_dt, int out_dt, GemmArgs& a) -> int {
         a.tile_counters = (counters && launch_no < 64 && a.groups <= 4) ? counters + 32 * launch_no++ : nullptr;
+        if (out_dt == TP_F16) { a.sat_flag = sat; a.sat_bit = 1; }
         return gemm_launch(in_dt, out_dt, a, stream);
     };
     // ---- small helpers ------------------------------------------------------------------------------------
@@ -387,7 +399,7 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
         TP_TRY(bw_reduce_many_parts_launch(MT, colpart, D, slices, D, grads->mlp_2_bias, redscratch, stream, nullptr));
         if (f16_chain) {
             TP_TRY(bw_scale_from_partials_launch((const float*)(bw + L.amaxpart), n_amax, scale, stream));
-            TP_TRY(bw_scale_cast_launch(MT, dy, (long long)Rq * D, scale, bw + L.dy16, stream));
+            TP_TRY(bw_scale_cast_launch(MT, dy, (long long)Rq * D, scale, bw + L.dy16, stream, sat));
             dyc = bw + L.dy16;
         }
     }
@@ -417,7 +429,7 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
     TP_TRY(dgrad(bw + L.da1, E, Rq, E, bw + L.wt_out, E, bw + L.dO, E));
     // ---- region attention ---------------------------------------------------------------------------------------
     TP_TRY(bw_region_attention_launch(GT, fw + W.q, fw + W.kv, fw + W.kv + kvE * 2, bw + L.dO, bw + L.dQ, bw + L.dKV,
-                                      bw + L.dKV + kvE * 2, B, g, s, stream));
+                                      bw + L.dKV + kvE * 2, B, g, s, stream, sat));
     // ---- attention in-projection (rows of in_proj_weight / in_proj_bias: q | k | v) --------------------------------
     char* g_inw = (char*)grads->clip_attn_in_proj_weight;
     char* g_inb = (char*)grads->clip_attn_in_proj_bias;
@@ -432,7 +444,7 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
     TP_TRY(bias_grad_rows(bw + L.dQ, E, Rq, E, g_inb, GT, inv_scale));
     TP_TRY(dgrad(bw + L.dQ, E, Rq, E, bw + L.wt_in, E, bw + L.dq1, E));
     TP_TRY(bw_ln_backward_launch(GT, bw + L.dq1, fw + W.q1pre, (const float*)(fw + W.mr_q), ln_g, bw + L.dQ1pre, lnpart, nb, Rq, stream,
-                                 ln_b, xn));
+                                 ln_b, xn, sat));
     TP_TRY(bw_reduce_many_parts_launch(MT, lnpart, 3 * E, nb, E, grads->ln_q_1_weight, redscratch, stream, inv_scale));
     TP_TRY(bw_reduce_many_parts_launch(MT, lnpart + E, 3 * E, nb, E, grads->ln_q_1_bias, redscratch, stream, inv_scale));
     TP_TRY(wgrad_rows(bw + L.dQ, E, Rq, Rqp, E, E, xn, E, GT, nullptr, g_inw));
@@ -450,7 +462,7 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
             TP_TRY(dgrad(dX, E, R, E, bw + L.wt_in + (size_t)(1 + t) * E * E * 2, E, bw + L.dkv1 + (size_t)t * kvE * 2, E));
             TP_TRY(bw_ln_backward_launch(GT, bw + L.dkv1 + (size_t)t * kvE * 2, fw + W.h2 + (size_t)t * kvE * 2,
                                          (const float*)(fw + W.mr_kv) + (size_t)t * R * 2, ln_g + (1 + t) * E,
-                                         bw + L.dH2 + (size_t)t * kvE * 2, lnpart, nb, R, stream, ln_b + (1 + t) * E, xn));
+                                         bw + L.dH2 + (size_t)t * kvE * 2, lnpart, nb, R, stream, ln_b + (1 + t) * E, xn, sat));
             TP_TRY(bw_reduce_many_parts_launch(MT, lnpart, 3 * E, nb, E, gw[t], redscratch, stream, inv_scale));
             TP_TRY(bw_reduce_many_parts_launch(MT, lnpart + E, 3 * E, nb, E, gb[t], redscratch, stream, inv_scale));
             TP_TRY(bw_reduce_many_parts_launch(MT, lnpart + 2 * E, 3 * E, nb, E, gb2[t], redscratch, stream, inv_scale));   // colsum(dH2)

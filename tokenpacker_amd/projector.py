@@ -120,11 +120,12 @@ class TokenPacker(nn.Module):
         self._workspaces: Dict[tuple, torch.Tensor] = {}
         self._last_launch = None             # (desc, workspace) of the last inference forward: saturation_report()
         self._sat_warned, self._sat_pending, self._sat_count = False, None, 0
+        self._bwd_sat_warned, self._bwd_sat_pending = False, None      # the backward workspace's status word (fp16 gradient chain)
 
     # ------------------------------------------------------------------------------------------
     _CACHE_DEFAULTS = {"tuning": None, "_packed": None, "_packed_key": None, "_packed_event": None, "_packed_stream": None,
                        "_overflow_checked": False, "_last_launch": None, "_sat_warned": False, "_sat_pending": None,
-                       "_sat_count": 0}
+                       "_sat_count": 0, "_bwd_sat_warned": False, "_bwd_sat_pending": None}
 
     def __getstate__(self):
         """``copy.deepcopy`` / ``pickle`` / ``torch.save(module)`` carry the parameters and settings, never the kernel-side
@@ -529,7 +530,40 @@ class TokenPacker(nn.Module):
                 _capi.check(lib.tp_backward(ctypes.byref(desc), x_multi.data_ptr(), _capi.strides3(x_multi.stride()),
                                             ctypes.byref(raw), packed.data_ptr(), train_ws.data_ptr(), dy.data_ptr(),
                                             ctypes.byref(gptr), bw.data_ptr(), bw.numel(), stream_ptr), "tp_backward")
+            self._watch_backward_status(bw, device)
         return [g if g.dtype == p.dtype else g.to(p.dtype) for g, p in zip(grads, params)]
+
+    def backward_saturated(self) -> int:
+        """The sticky saturation word of the LAST backward on the current stream's workspace (include/tokenpacker.h: bit 0 a
+        non-finite dy or a clamping GEMM epilogue of the fp16 gradient chain, bit 1 the LayerNorm backward, bit 2 the attention
+        backward); 0 = every gradient of that call stayed inside fp16's range.  Synchronises."""
+        device = next(self.parameters()).device
+        ws = self._workspaces.get((device.index if device.index is not None else -1,
+                                   ("bwd", torch.cuda.current_stream(device).cuda_stream)))
+        return 0 if ws is None else int(ws[:4].view(torch.int32).item())
+
+    def _watch_backward_status(self, bw: torch.Tensor, device) -> None:
+        """No synchronisation: the status word of this backward is copied to pinned memory behind it and looked at when a later
+        backward finds the copy finished; warns once."""
+        if self._bwd_sat_warned or torch.cuda.is_current_stream_capturing():
+            return
+        pend = self._bwd_sat_pending
+        if pend is not None:
+            if not pend[1].query():
+                return
+            if int(pend[0].item()) != 0:
+                self._bwd_sat_warned = True
+                import warnings
+                warnings.warn("tokenpacker_amd.TokenPacker: a backward pass saturated fp16 (status bits "
+                              f"{int(pend[0].item()):#x}: 1 = dy not finite / a GEMM epilogue, 2 = LayerNorm backward, 4 = attention backward) — "
+                              "its parameter gradients were clamped; _capi.TuningContext(bwd_chain=1) carries gradients in bf16 instead",
+                              RuntimeWarning, stacklevel=3)
+                return
+        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host.copy_(bw[:4].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        self._bwd_sat_pending = (host, ev)
 
     def forward_staged(self, x):
         """Forward that also times every kernel of the schedule with HIP events recorded by the
