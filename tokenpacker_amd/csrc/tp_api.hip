@@ -944,9 +944,34 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     // only trades the K launch's wait for a 13 us cross-stream join; 0.665 (1) / 0.658 (2) / 0.661 ms (0).  Off by default.
     const bool decouple_k = plan.decouple_k;
     const bool k_on_side = decouple_k && side != nullptr && tuning(TP_TUNE_DECOUPLE_K) == 1;
+    // 2. Hkv = GELU(x_multi · [Wk0;Wv0]^T + b): strided A (tower hands over [:,1:] slices)
+    auto kv_layer0 = [&]() -> int {
+        GemmArgs a = plain_gemm(x_multi, xm_strides[1], pw + P.w_kv0, ws + W.hkv, 2 * E, rows_kv, 2 * E, kMulti,
+                                (const float*)(pw + P.b_kv0), TP_LINEAR_GELU | (train ? TP_LINEAR_SAVE_PRE : 0));
+        a.rows_per_batch = N; a.a_batch_stride_bytes = xm_strides[0] * 2;
+        if (region_major) { a.a_region_g = g; a.a_region_s = s; }      // rows of Hkv (and of everything behind it) by region
+        if (hkv_split) { a.ldc = E; a.c_split_cols = E; a.c_split_stride_bytes = kvE * 2; }
+        a.C2 = train ? ws + W.z1 : nullptr;
+        if (xm_parts) {
+            for (int i = 0; i < 4; ++i) a.A_parts[i] = (const char*)xm_parts[i];
+            a.k_part = kMulti / 4;
+        }
+        const int keep = stage_idx;
+        stage_idx = 2;                                   // (its saturation bit is stage kv_layer0's, wherever in the enqueue order it goes out)
+        const int rc = launch_maybe_splitk(dt, TP_F16, a, stream);       // raw operands in the io dtype, fp16 activations out
+        stage_idx = keep;
+        return rc;
+    };
     if (side) {
+        // The fork event is recorded FIRST, then the first K/V layer goes out on the caller's stream, then the side stream's launches
+        // (round 6): a one-image forward is bound by the HOST's enqueue rate (11 launches of 5-25 us each), and with the query side's
+        // three launches enqueued in front of it the first layer — the head of the critical path — started 23 us late
+        // (profiles/r06p_timeline_B1.txt).  Measured +-0 (0.1277 vs 0.1282 ms at B = 1): the host enqueues just in time either way;
+        // kept because it is the right order.  The side stream still waits only for what preceded this forward.
         hipError_t e = hipEventRecord(side->fork, stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(side->s, side->fork, 0);
+        if (e != hipSuccess) { set_error("tp_forward: side stream fork: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
+        TP_TRY(kv_layer0());
+        e = hipStreamWaitEvent(side->s, side->fork, 0);
         if (e != hipSuccess) { set_error("tp_forward: side stream fork: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
         TP_TRY(point_queries_launch(dt, x, x_strides, ws + W.q0, B, g, s, side->s));
         TP_TRY(q_proj(side->s));
@@ -972,20 +997,8 @@ int forward_impl(const tp_desc* desc, const void* x, const int64_t x_strides[3],
     if (!side && fuse_attn) { TP_TRY(q_proj(stream)); TP_TRY(q_inproj(stream)); }
 
     TP_TRY(mark());
-    // 2. Hkv = GELU(x_multi · [Wk0;Wv0]^T + b): strided A (tower hands over [:,1:] slices)
-    {
-        GemmArgs a = plain_gemm(x_multi, xm_strides[1], pw + P.w_kv0, ws + W.hkv, 2 * E, rows_kv, 2 * E, kMulti,
-                                (const float*)(pw + P.b_kv0), TP_LINEAR_GELU | (train ? TP_LINEAR_SAVE_PRE : 0));
-        a.rows_per_batch = N; a.a_batch_stride_bytes = xm_strides[0] * 2;
-        if (region_major) { a.a_region_g = g; a.a_region_s = s; }      // rows of Hkv (and of everything behind it) by region
-        if (hkv_split) { a.ldc = E; a.c_split_cols = E; a.c_split_stride_bytes = kvE * 2; }
-        a.C2 = train ? ws + W.z1 : nullptr;
-        if (xm_parts) {
-            for (int i = 0; i < 4; ++i) a.A_parts[i] = (const char*)xm_parts[i];
-            a.k_part = kMulti / 4;
-        }
-        TP_TRY(launch_maybe_splitk(dt, TP_F16, a, stream));      // raw operands in the io dtype, fp16 activations out
-    }
+    // 2. (kv_layer0: enqueued above, in front of the side stream's launches, when there is a side stream)
+    if (!side) TP_TRY(kv_layer0());
     if (k_on_side) {                                    // the decoupled K launch's cue (enqueued further down, on the side stream)
         hipError_t e = hipEventRecord(side->kv0, stream);
         if (e != hipSuccess) { set_error("tp_forward: hipEventRecord(kv0): %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
