@@ -62,6 +62,10 @@ def _forget_packed(ptr: int) -> None:
         pass
 
 
+import contextlib as _contextlib
+_NULLCTX = _contextlib.nullcontext()
+
+
 class TokenPacker(nn.Module):
     """Region-to-point visual projector (see module docstring)."""
 
@@ -155,9 +159,19 @@ class TokenPacker(nn.Module):
                 nn.init.zeros_(mod.bias)
 
     # ------------------------------------------------------------------------------------------
+    _WEIGHT_PATHS = tuple(tuple(name.split(".")) for name in _capi.WEIGHT_FIELDS)
+
     def _named_weights(self):
-        sd = dict(self.named_parameters())
-        return [sd[name] for name in _capi.WEIGHT_FIELDS]
+        """The 23 parameters in tp_weights order.  Walks the registration dicts directly (``dict(self.named_parameters())`` costs 25 us
+        per call — a fifth of a one-image forward, which is bound by the host's enqueue rate: profiles/r06p_timeline_B1.txt);
+        always the CURRENT objects, so a replaced submodule / parameter is seen."""
+        out = []
+        for path in self._WEIGHT_PATHS:
+            mod = self
+            for key in path[:-1]:
+                mod = mod._modules[key]
+            out.append(mod._parameters[path[-1]])
+        return out
 
     def _expected_shapes(self):
         E, C, D = self.embed_dim, self.MULTI_LEVEL_DIM, self.hidden_size
@@ -188,6 +202,13 @@ class TokenPacker(nn.Module):
         """(Re)build the kernel-side weight image: always when ``force`` (training forward), otherwise when any
         parameter storage / version or the compute dtype changed."""
         weights = self._named_weights()
+        # (an inference image carries every folded / pre-multiplied weight whatever the tuning table says: the schedule is
+        # chosen per forward, the image never has to follow a knob)
+        key = (dtype, device, tuple((w.data_ptr(), w._version) for w in weights))
+        if not force and self._packed is not None and self._packed_key == key:
+            if self._packed_stream != stream_ptr and self._packed_event is not None:
+                torch.cuda.current_stream(device).wait_event(self._packed_event)     # packed on another stream: order this one behind it
+            return self._packed
         expected = self._expected_shapes()
         for name, w in zip(_capi.WEIGHT_FIELDS, weights):
             if w.numel() == 0 or tuple(w.shape) != expected[name]:
@@ -199,14 +220,7 @@ class TokenPacker(nn.Module):
                     f"parameter {name} has shape {tuple(w.shape)} (expected {expected[name]}): the parameter looks partitioned "
                     f"(DeepSpeed ZeRO-3?).  TokenPacker reads its weights directly and does not trigger per-submodule gather hooks; "
                     f"use ZeRO-2, or wrap the forward in deepspeed.zero.GatheredParameters(list(projector.parameters())).")
-        # (an inference image carries every folded / pre-multiplied weight whatever the tuning table says: the schedule is
-        # chosen per forward, the image never has to follow a knob)
-        key = (dtype, device, tuple((w.data_ptr(), w._version) for w in weights))
         stream = torch.cuda.current_stream(device)
-        if not force and self._packed is not None and self._packed_key == key:
-            if self._packed_stream != stream_ptr and self._packed_event is not None:
-                stream.wait_event(self._packed_event)         # packed on another stream: order this one behind it
-            return self._packed
         for name, w in zip(_capi.WEIGHT_FIELDS, weights):
             if w.device != device or not w.dtype.is_floating_point:
                 raise TypeError(f"parameter {name} is {w.dtype} on {w.device}; inputs are {dtype} on {device} "
@@ -384,8 +398,12 @@ class TokenPacker(nn.Module):
                 raise NotImplementedError("staged timing takes the concatenated x_multi")
             part_ptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in parts])
             part_strides = _capi.strides3(parts[0].stride())
-        with torch.cuda.device(device):
-            stream_ptr = torch.cuda.current_stream(device).cuda_stream
+        # (host cost matters: a one-image forward is bound by the host's enqueue rate — 72 us inside the library's 11 launches, and
+        # what this wrapper adds on top, profiles/r06p_timeline_B1.txt: no device-guard when the device is current, ONE
+        # current_stream lookup, plain-dict writes instead of nn.Module.__setattr__)
+        with (_NULLCTX if device.index == torch.cuda.current_device() else torch.cuda.device(device)):
+            stream = torch.cuda.current_stream(device)
+            stream_ptr = stream.cuda_stream
             lib = _capi.load_library()
             packed = self._ensure_packed(x.dtype, device, stream_ptr, force=train)
             fp32_out = fp32_out or self.output_fp32
@@ -442,8 +460,8 @@ class TokenPacker(nn.Module):
                                                   x_multi.data_ptr(), _capi.strides3(x_multi.stride()),
                                                   packed.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
                                                   stream_ptr, handles, len(_stage_events)), "tp_forward_staged")
-            self._last_launch = (desc, ws, stream_ptr)
-            self._poll_saturation(ws, torch.cuda.current_stream(device))
+            self.__dict__["_last_launch"] = (desc, ws, stream_ptr)
+            self._poll_saturation(ws, stream)
         return out, ws, desc, packed
 
     def saturated_stages(self, clear: bool = False):
@@ -475,9 +493,8 @@ class TokenPacker(nn.Module):
                               "where the reference would have produced inf); module.saturated_stages() names the stage",
                               RuntimeWarning, stacklevel=3)
                 return
-            self._sat_pending = pend = None
-        self._sat_count += 1
-        n = self._sat_count
+            self.__dict__["_sat_pending"] = pend = None
+        n = self.__dict__["_sat_count"] = self._sat_count + 1
         if pend is None and ((n & (n - 1)) == 0 or n % 1024 == 0):
             host = torch.empty(1, dtype=torch.int32, pin_memory=True)
             host.copy_(ws[:4].view(torch.int32), non_blocking=True)
