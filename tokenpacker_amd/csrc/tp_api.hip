@@ -368,11 +368,6 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
     hipStream_t stream = (hipStream_t)stream_;
     char* P = (char*)packed;
     const size_t E = kEmbed;
-    auto copy = [&](size_t off, const void* src, size_t bytes) -> int {
-        hipError_t e = hipMemcpyAsync(P + off, src, bytes, hipMemcpyDeviceToDevice, stream);
-        if (e != hipSuccess) { set_error("tp_pack_weights: hipMemcpyAsync: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
-        return TP_OK;
-    };
 #define TP_TRY(expr) do { int rc_ = (expr); if (rc_ != TP_OK) return rc_; } while (0)
     int* status = (int*)(P + L.status);
     int* sat = status;                                   // [0]: weight elements clamped to the fp16 range
@@ -380,18 +375,24 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
         hipError_t e = hipMemsetAsync(status, 0, 256, stream);
         if (e != hipSuccess) { set_error("tp_pack_weights: hipMemsetAsync: %s", hipGetErrorString(e)); return TP_ERR_LAUNCH; }
     }
-    // K/V first layers concatenated: one GEMM reads x_multi once
-    TP_TRY(copy(L.w_kv0, raw->k_proj_1_0_weight, E * kMulti * 2));
-    TP_TRY(copy(L.w_kv0 + E * kMulti * 2, raw->v_proj_1_0_weight, E * kMulti * 2));
-    TP_TRY(pack_cast_f32_launch(dt, raw->k_proj_1_0_bias, (float*)(P + L.b_kv0), (int)E, stream));
-    TP_TRY(pack_cast_f32_launch(dt, raw->v_proj_1_0_bias, (float*)(P + L.b_kv0) + E, (int)E, stream));
-    // everything after the first layer runs on fp16 activations: widen those weights to fp16 (exact for
-    // in-range bf16 values; identity for fp16 models)
-    TP_TRY(pack_cast_f16_launch(dt, raw->k_proj_1_2_weight, P + L.w_kv2, (long long)(E * E), stream, sat));
-    TP_TRY(pack_cast_f16_launch(dt, raw->v_proj_1_2_weight, P + L.w_kv2 + E * E * 2, (long long)(E * E), stream, sat));
-    TP_TRY(pack_cast_f32_launch(dt, raw->k_proj_1_2_bias, (float*)(P + L.b_kv2), (int)E, stream));
-    TP_TRY(pack_cast_f32_launch(dt, raw->v_proj_1_2_bias, (float*)(P + L.b_kv2) + E, (int)E, stream));
-    TP_TRY(pack_cast_f16_launch(dt, raw->q_proj_1_weight, P + L.w_q1, (long long)(E * E), stream, sat));
+    // The casts and copies of the image, gathered into ONE launch (round 6: the training pack runs every step — twenty 4-27 us
+    // launches were 0.15 ms of it): K/V first layers concatenated (one GEMM reads x_multi once); everything after the first layer
+    // runs on fp16 activations, so those weights are widened to fp16 (exact for in-range bf16 values, identity for fp16 models);
+    // biases in fp32.
+    BatchOps ops{};
+    auto c16 = [&](const void* src, size_t off, long long n) { return ops.add(BATCH_OP_TO_F16, src, P + off, n); };
+    auto c32 = [&](const void* src, float* dst, long long n) { return ops.add(BATCH_OP_TO_F32, src, dst, n); };
+    bool fits = ops.add(BATCH_OP_COPY16, raw->k_proj_1_0_weight, P + L.w_kv0, (long long)(E * kMulti));
+    fits = fits && ops.add(BATCH_OP_COPY16, raw->v_proj_1_0_weight, P + L.w_kv0 + E * kMulti * 2, (long long)(E * kMulti));
+    fits = fits && c32(raw->k_proj_1_0_bias, (float*)(P + L.b_kv0), (long long)E) && c32(raw->v_proj_1_0_bias, (float*)(P + L.b_kv0) + E, (long long)E);
+    fits = fits && c16(raw->k_proj_1_2_weight, L.w_kv2, (long long)(E * E)) && c16(raw->v_proj_1_2_weight, L.w_kv2 + E * E * 2, (long long)(E * E));
+    fits = fits && c32(raw->k_proj_1_2_bias, (float*)(P + L.b_kv2), (long long)E) && c32(raw->v_proj_1_2_bias, (float*)(P + L.b_kv2) + E, (long long)E);
+    fits = fits && c16(raw->q_proj_1_weight, L.w_q1, (long long)(E * E));
+    fits = fits && c16(raw->clip_attn_out_proj_weight, L.w_out, (long long)(E * E)) && c32(raw->clip_attn_out_proj_bias, (float*)(P + L.b_out), (long long)E);
+    fits = fits && c16(raw->mlp_0_weight, L.w_m0, (long long)D * E) && c32(raw->mlp_0_bias, (float*)(P + L.b_m0), (long long)D);
+    fits = fits && c16(raw->mlp_2_weight, L.w_m2, (long long)D * D) && c32(raw->mlp_2_bias, (float*)(P + L.b_m2), (long long)D);
+    if (!fits) { set_error("tp_pack_weights: batch table too small"); return TP_ERR_LAUNCH; }
+    TP_TRY(pack_batch_launch(dt, ops, stream, sat));
     // LayerNorm affines folded into the q/k/v in-projections (in_proj rows: q | k | v)
     const char* inw = (const char*)raw->clip_attn_in_proj_weight;
     const char* inb = (const char*)raw->clip_attn_in_proj_bias;
@@ -404,12 +405,6 @@ int tp_pack_weights(const tp_desc* desc, const tp_weights* raw, void* packed, si
                                (int)E, (int)E, stream, sat));
     const bool train_pack = (desc->flags & TP_DESC_TRAIN_PACK) != 0;     // training image: inference-only weights are skipped
     if (!train_pack) TP_TRY(pack_head_transpose_launch(P + L.w_in_kv, P + L.w_qt, stream));      // of the ROUNDED W'k: the absorbed schedule
-    TP_TRY(pack_cast_f16_launch(dt, raw->clip_attn_out_proj_weight, P + L.w_out, (long long)(E * E), stream, sat));
-    TP_TRY(pack_cast_f32_launch(dt, raw->clip_attn_out_proj_bias, (float*)(P + L.b_out), (int)E, stream));
-    TP_TRY(pack_cast_f16_launch(dt, raw->mlp_0_weight, P + L.w_m0, (long long)D * E, stream, sat));
-    TP_TRY(pack_cast_f32_launch(dt, raw->mlp_0_bias, (float*)(P + L.b_m0), D, stream));
-    TP_TRY(pack_cast_f16_launch(dt, raw->mlp_2_weight, P + L.w_m2, (long long)D * D, stream, sat));
-    TP_TRY(pack_cast_f32_launch(dt, raw->mlp_2_bias, (float*)(P + L.b_m2), D, stream));
     // Fused LayerNorm chain of the K/V side (inference, plain schedule; TP_TUNE_FUSE_KV_LN):
     //   K = LN(H2)·Win^T + b,  H2 = Hkv·W2^T + b2   =>   K = rstd·(Hkv·Wc^T + d − mu·c) + b',
     //   Wc = W'·W2 (fp32 accumulate on the MFMA kernel, rounded once to fp16),  d = W'·b2,  (mu, rstd) = row statistics

@@ -101,6 +101,73 @@ static int transpose_launch_t(const void* src, long long ld, int rpb, long long 
     return check_launch("transpose_kernel");
 }
 
+// The same 64 x 64 tiling for a BATCH of plain matrices in one launch (round 6: the eight weights the dgrad GEMMs read transposed —
+// 7 us each at a 32-image step, launch latency mostly): blockIdx.z picks the matrix, blocks beyond its tile grid leave at once.
+template <typename TS, typename TD>
+__global__ void __launch_bounds__(256)
+transpose_batch_kernel(const TransposeBatch tb) {
+    const TransposeOp o = tb.op[blockIdx.z];
+    if ((int)blockIdx.x * 64 >= o.C || (int)blockIdx.y * 64 >= o.Rpad) return;
+    __shared__ float tile[64][65];
+    using S8 = typename Vec<TS>::x8;
+    using D8 = typename Vec<TD>::x8;
+    const TS* __restrict__ src = (const TS*)o.src;
+    TD* __restrict__ dst = (TD*)o.dst;
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tr = threadIdx.x >> 2, seg = (threadIdx.x & 3) * 16;
+    {
+        const int r = r0 + tr;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = c0 + seg + h * 8;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            if (r < o.R && c < o.C) {
+                const S8 t = *(const S8*)(src + (long long)r * o.ld + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tile[tr][seg + h * 8 + e] = v[e];
+        }
+    }
+    __syncthreads();
+    const int c = c0 + tr;
+    if (c < o.C) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rb = r0 + seg + h * 8;
+            if (rb < o.Rpad) {
+                D8 out;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) out[e] = sat_cast<TD>(rb + e < o.R ? tile[seg + h * 8 + e][tr] : 0.f);
+                *(D8*)(dst + (long long)c * o.ldd + rb) = out;
+            }
+        }
+    }
+}
+
+int bw_transpose_batch_launch(int src_dtype, int dst_dtype, const TransposeBatch& tb, hipStream_t stream) {
+    if (tb.count <= 0) return TP_OK;
+    if (tb.count > kTransposeBatch) { set_error("bw transpose batch: %d matrices > %d", tb.count, kTransposeBatch); return TP_ERR_INVALID_ARG; }
+    int gx = 1, gy = 1;
+    for (int i = 0; i < tb.count; ++i) {
+        const TransposeOp& o = tb.op[i];
+        if ((o.C & 7) || (o.ld & 7) || (o.ldd & 7) || (o.Rpad & 7) || ((uintptr_t)o.src & 15) || ((uintptr_t)o.dst & 15)) {
+            set_error("bw transpose batch: matrix %d is not 8-element / 16-byte aligned", i);
+            return TP_ERR_INVALID_ARG;
+        }
+        gx = std::max(gx, (o.C + 63) / 64); gy = std::max(gy, (o.Rpad + 63) / 64);
+    }
+    const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)tb.count);
+#define TP_TRB(SD, DD, TS, TD) if (src_dtype == SD && dst_dtype == DD) { hipLaunchKernelGGL((transpose_batch_kernel<TS, TD>), grid, dim3(256), 0, stream, tb); return check_launch("transpose_batch_kernel"); }
+    TP_TRB(TP_BF16, TP_BF16, bf16_t, bf16_t) TP_TRB(TP_F16, TP_F16, f16_t, f16_t) TP_TRB(TP_BF16, TP_F16, bf16_t, f16_t) TP_TRB(TP_F16, TP_BF16, f16_t, bf16_t)
+#undef TP_TRB
+    set_error("bw transpose batch: unsupported dtypes %d -> %d", src_dtype, dst_dtype);
+    return TP_ERR_INVALID_ARG;
+}
+
 int bw_transpose_launch(int src_dtype, int dst_dtype, const void* src, long long ld, int rows_per_batch,
                         long long batch_stride, int R, int C, void* dst, long long ldd, int Rpad, const float* mean_rstd,
                         const float* gamma, const float* beta, float* colsum_part, hipStream_t stream) {
@@ -276,28 +343,9 @@ int bw_reduce_parts_launch(int dst_dtype, const float* part, long long part_stri
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Dynamic power-of-two scale of a gradient tensor (tp_internal.h: bw_dynamic_scale_launch).  Stage 1: 1024 workgroups, a thread
-// strides over 16-byte pieces and keeps max |v| (NaN-propagating through the comparison's falsehood is not needed: a non-finite
-// maximum is detected in stage 2 by its exponent); stage 2: one workgroup reduces the 1024 partials and writes S, 1 / S.
-template <typename TS>
-__global__ void __launch_bounds__(256)
-amax_partials_kernel(const TS* __restrict__ src, long long n8, float* __restrict__ part) {
-    using S8 = typename Vec<TS>::x8;
-    __shared__ float red[256];
-    float m = 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
-        const S8 v = *(const S8*)(src + i * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float a = fabsf((float)v[e]); m = a > m ? a : (a != a ? a : m); }   // (NaN sticks)
-    }
-    red[threadIdx.x] = m;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) { const float a = red[threadIdx.x + o], b = red[threadIdx.x]; red[threadIdx.x] = (a != a || a > b) ? a : b; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
-}
+// Dynamic power-of-two scale of a gradient tensor (tp_internal.h: bw_scale_from_partials_launch).  The per-workgroup max |v| come
+// from the column-sum pass that reads dy anyway (colsum_rows_kernel's amax_part; a NaN sticks through the comparisons); one
+// workgroup reduces them and writes S = 2^k with amax * S in [16, 32) and 1 / S (S = 1 for an all-zero or non-finite tensor).
 __global__ void __launch_bounds__(256)
 scale_from_amax_kernel(const float* __restrict__ part, int nparts, float* __restrict__ scale) {
     __shared__ float red[256];
@@ -338,18 +386,6 @@ scale_cast_f16_kernel(const TS* __restrict__ src, long long n8, const float* __r
         *(D8*)(dst + i * 8) = o;
     }
     bw_sat_report<f16_t>(sat_flag, 1, mx);              // (an inf / NaN in dy, which no finite scale brings into range)
-}
-
-int bw_dynamic_scale_launch(int src_dtype, const void* src, long long n, float* part, float* scale, hipStream_t stream) {
-    if ((n & 7) || ((uintptr_t)src & 15)) { set_error("bw dynamic scale: element count must be a multiple of 8, the source 16-byte aligned"); return TP_ERR_INVALID_ARG; }
-    const int nb = 1024;
-    if (src_dtype == TP_BF16)
-        hipLaunchKernelGGL(amax_partials_kernel<bf16_t>, dim3(nb), dim3(256), 0, stream, (const bf16_t*)src, n / 8, part);
-    else if (src_dtype == TP_F16)
-        hipLaunchKernelGGL(amax_partials_kernel<f16_t>, dim3(nb), dim3(256), 0, stream, (const f16_t*)src, n / 8, part);
-    else { set_error("bw dynamic scale: unsupported dtype %d", src_dtype); return TP_ERR_INVALID_ARG; }
-    if (int rc = check_launch("amax_partials_kernel")) return rc;
-    return bw_scale_from_partials_launch(part, nb, scale, stream);
 }
 
 int bw_scale_from_partials_launch(const float* amax_part, int nparts, float* scale, hipStream_t stream) {

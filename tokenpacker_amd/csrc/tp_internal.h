@@ -238,6 +238,20 @@ int hd_assemble_launch(const tp_hd_image* plan_host, int n_images, const void* t
 int ln_finalize_launch(const float* parts, float* mean_rstd, long long M, int nparts, int groups, int ln_dim,
                        float eps, hipStream_t stream, bool second_moment = false, bool pair_rstd = false);
 int pack_cast_f32_launch(int dtype, const void* src, float* dst, int n, hipStream_t stream);
+// a batch of casts / copies of `dtype` sources in one launch (tp_kernels.hip: pack_batch_kernel)
+enum { BATCH_OP_TO_F32 = 0, BATCH_OP_TO_F16 = 1, BATCH_OP_COPY16 = 2 };
+struct BatchOp { const void* src; void* dst; long long n; int kind; int pad_; };
+constexpr int kBatchOps = 24;
+struct BatchOps {
+    BatchOp op[kBatchOps]; int count;
+    // (false: the table is full — the caller flushes with pack_batch_launch and starts over)
+    bool add(int kind, const void* src, void* dst, long long n) {
+        if (count >= kBatchOps) return false;
+        op[count++] = BatchOp{src, dst, n, kind, 0};
+        return true;
+    }
+};
+int pack_batch_launch(int dtype, const BatchOps& ops, hipStream_t stream, int* sat);
 // `sat` (optional): device int incremented once per element that did not fit fp16 and was clamped to +-65504
 int pack_cast_f16_launch(int dtype, const void* src, void* dst_f16, long long n, hipStream_t stream, int* sat = nullptr);
 int pack_transpose_f16_launch(const void* src_f16, void* dst_f16, int n, hipStream_t stream);          // [n,n]
@@ -330,14 +344,26 @@ int bw_transpose_launch(int src_dtype, int dst_dtype, const void* src, long long
                         long long batch_stride, int R, int C, void* dst, long long ldd, int Rpad, const float* mean_rstd,
                         const float* gamma, const float* beta, float* colsum_part, hipStream_t stream);
 // `out_scale` (device, optional): the sum is multiplied by out_scale[0] before the cast — the 1 / S of a backward chain that carries
-// its gradients scaled by a power of two S (bw_dynamic_scale_launch)
+// its gradients scaled by a power of two S (bw_scale_from_partials_launch)
+// a batch of plain [R, C] -> [C, Rpad] transposes (+ cast) in one launch (tp_bwd.hip: transpose_batch_kernel)
+struct TransposeOp { const void* src; void* dst; long long ld, ldd; int R, C, Rpad, pad_; };
+constexpr int kTransposeBatch = 8;
+struct TransposeBatch {
+    TransposeOp op[kTransposeBatch]; int count;
+    bool add(const void* src, long long ld, int R, int C, void* dst, int Rpad) {
+        if (count >= kTransposeBatch) return false;
+        op[count++] = TransposeOp{src, dst, ld, (long long)Rpad, R, C, Rpad, 0};
+        return true;
+    }
+};
+int bw_transpose_batch_launch(int src_dtype, int dst_dtype, const TransposeBatch& tb, hipStream_t stream);
 int bw_reduce_parts_launch(int dst_dtype, const float* part, long long part_stride, int nparts, long long n, void* out,
                            hipStream_t stream, const float* out_scale = nullptr);
 // Dynamic power-of-two scale of a gradient tensor (the backward of a bf16 model runs its chain in fp16 — 11-bit mantissas, the
 // saved fp16 activations read in place by the weight gradients — and fp16's range needs the incoming dy brought to a known
-// magnitude): scale[0] = S = 2^k with amax(src) * S in (16, 32], scale[1] = 1 / S (S = 1 for an all-zero or non-finite tensor).
-// `part`: >= 1024 floats of scratch.  Then dst_f16 = saturate(src * S).  Nothing here synchronises: S lives on the device.
-int bw_dynamic_scale_launch(int src_dtype, const void* src, long long n, float* part, float* scale, hipStream_t stream);
+// magnitude): bw_scale_from_partials_launch turns the per-workgroup max |dy| a column-sum pass left behind into scale[0] = S = 2^k with
+// amax * S in [16, 32) and scale[1] = 1 / S (S = 1 for an all-zero or non-finite tensor); bw_scale_cast_launch writes
+// dst_f16 = saturate(src * S).  Nothing here synchronises: S lives on the device.
 int bw_scale_cast_launch(int src_dtype, const void* src, long long n, const float* scale, void* dst_f16, hipStream_t stream,
                          int* sat_flag = nullptr);
 // Weight gradient straight from the row-major activations (tp_gemm8.hip, K-major operands):

@@ -747,6 +747,57 @@ int pack_cast_f16_launch(int dtype, const void* src, void* dst, long long n, hip
     return check_launch("pack_cast_f16_kernel");
 }
 
+// A batch of small element-wise operations in ONE launch (round 6): the per-step weight pack of a training step is ~20 casts and
+// copies of 1 K .. 17 M elements — 4-27 us each, most of it launch latency, 0.15 ms per step together (5 % of a 32-image training
+// step, profiles/r06n_train_b32_kernel_stats.csv).  blockIdx.y picks the operation, the x blocks stride over its elements in
+// 8-element vectors (every operand of the pack is 16-byte aligned with a multiple of 8 elements; anything else takes the scalar path).
+template <typename T>
+__global__ void __launch_bounds__(256)
+pack_batch_kernel(const BatchOps ops, int* __restrict__ sat) {
+    const BatchOp o = ops.op[blockIdx.y];
+    using S8 = typename Vec<T>::x8;
+    const long long stride = (long long)gridDim.x * blockDim.x, t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool vec = (o.n & 7) == 0 && (((uintptr_t)o.src | (uintptr_t)o.dst) & 15) == 0;
+    if (vec) {
+        for (long long i = t0; i < o.n / 8; i += stride) {
+            const S8 v = *((const S8*)o.src + i);
+            if (o.kind == BATCH_OP_COPY16) { *((S8*)o.dst + i) = v; }
+            else if (o.kind == BATCH_OP_TO_F32) {
+                f32x4 a, b;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[e] = (float)v[e]; b[e] = (float)v[4 + e]; }
+                *((f32x4*)o.dst + 2 * i) = a; *((f32x4*)o.dst + 2 * i + 1) = b;
+            } else {
+                f16x8 r;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[e] = (f16_t)clamp_f16_range((float)v[e], sat);
+                *((f16x8*)o.dst + i) = r;
+            }
+        }
+    } else {
+        for (long long i = t0; i < o.n; i += stride) {
+            const T v = ((const T*)o.src)[i];
+            if (o.kind == BATCH_OP_COPY16) ((T*)o.dst)[i] = v;
+            else if (o.kind == BATCH_OP_TO_F32) ((float*)o.dst)[i] = (float)v;
+            else ((f16_t*)o.dst)[i] = (f16_t)clamp_f16_range((float)v, sat);
+        }
+    }
+}
+
+int pack_batch_launch(int dtype, const BatchOps& ops, hipStream_t stream, int* sat) {
+    if (ops.count <= 0) return TP_OK;
+    if (ops.count > kBatchOps) { set_error("pack batch: %d operations > %d", ops.count, kBatchOps); return TP_ERR_INVALID_ARG; }
+    long long nmax = 0;
+    for (int i = 0; i < ops.count; ++i) nmax = ops.op[i].n > nmax ? ops.op[i].n : nmax;
+    long long bx = (nmax / 8 + 255) / 256;
+    bx = bx < 1 ? 1 : (bx > 1024 ? 1024 : bx);
+    if (dtype == TP_BF16)
+        hipLaunchKernelGGL(pack_batch_kernel<bf16_t>, dim3((unsigned)bx, (unsigned)ops.count), dim3(256), 0, stream, ops, sat);
+    else
+        hipLaunchKernelGGL(pack_batch_kernel<f16_t>, dim3((unsigned)bx, (unsigned)ops.count), dim3(256), 0, stream, ops, sat);
+    return check_launch("pack_batch_kernel");
+}
+
 // Debug scan of an fp16 activation buffer for saturated epilogue outputs (tp_debug_count_saturated): every kernel of
 // the path clamps to +-65504 instead of producing inf, so an element AT the bound (or a NaN) marks a clamp.
 __global__ void __launch_bounds__(256)

@@ -373,20 +373,24 @@ static int backward_impl(const tp_desc* desc, const void* x_multi, const void* c
 
     // ---- operands the backward needs in its own layout --------------------------------------------------------
     // transposed weights (model dtype): W [out, in] -> W^T [in, out]
-    TP_TRY(T(MT, raw->mlp_2_weight, D, D, D, bw + L.wt_m2, D));
-    TP_TRY(T(MT, raw->mlp_0_weight, E, D, E, bw + L.wt_m0, D));
-    TP_TRY(T(MT, raw->clip_attn_out_proj_weight, E, E, E, bw + L.wt_out, E));
-    for (int t = 0; t < 3; ++t)
-        TP_TRY(T(MT, (const char*)raw->clip_attn_in_proj_weight + (size_t)t * E * E * 2, E, E, E, bw + L.wt_in + (size_t)t * E * E * 2, E));
-    TP_TRY(T(MT, raw->k_proj_1_2_weight, E, E, E, bw + L.wt_2, E));
-    TP_TRY(T(MT, raw->v_proj_1_2_weight, E, E, E, bw + L.wt_2 + (size_t)E * E * 2, E));
+    {
+        TransposeBatch tb{};                             // (eight matrices, one launch)
+        bool ok = tb.add(raw->mlp_2_weight, D, D, D, bw + L.wt_m2, D) && tb.add(raw->mlp_0_weight, E, D, E, bw + L.wt_m0, D) &&
+                  tb.add(raw->clip_attn_out_proj_weight, E, E, E, bw + L.wt_out, E);
+        for (int t = 0; t < 3; ++t)
+            ok = ok && tb.add((const char*)raw->clip_attn_in_proj_weight + (size_t)t * E * E * 2, E, E, E, bw + L.wt_in + (size_t)t * E * E * 2, E);
+        ok = ok && tb.add(raw->k_proj_1_2_weight, E, E, E, bw + L.wt_2, E) && tb.add(raw->v_proj_1_2_weight, E, E, E, bw + L.wt_2 + (size_t)E * E * 2, E);
+        if (!ok) { set_error("tp_backward: transpose batch table too small"); return TP_ERR_LAUNCH; }
+        TP_TRY(bw_transpose_batch_launch(MT, GT, tb, stream));
+    }
     float* ln_g = (float*)(bw + L.ln_g);
     float* ln_b = (float*)(bw + L.ln_b);
     const void* gam_src[3] = {raw->ln_q_1_weight, raw->ln_k_1_weight, raw->ln_v_1_weight};
     const void* bet_src[3] = {raw->ln_q_1_bias, raw->ln_k_1_bias, raw->ln_v_1_bias};
-    for (int t = 0; t < 3; ++t) {
-        TP_TRY(pack_cast_f32_launch(MT, gam_src[t], ln_g + t * E, E, stream));
-        TP_TRY(pack_cast_f32_launch(MT, bet_src[t], ln_b + t * E, E, stream));
+    {
+        BatchOps ops{};                                  // (six 1 K-element casts: one launch)
+        for (int t = 0; t < 3; ++t) { ops.add(BATCH_OP_TO_F32, gam_src[t], ln_g + t * E, E); ops.add(BATCH_OP_TO_F32, bet_src[t], ln_b + t * E, E); }
+        TP_TRY(pack_batch_launch(MT, ops, stream, nullptr));
     }
 
     // ---- the incoming gradient: as it is, or (fp16 chain) scaled by a dynamic power of two and cast ----------------------
