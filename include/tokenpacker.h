@@ -433,7 +433,7 @@ enum { TP_TUNE_GEMM_TILE = 0,   /* 0 auto (full tiles, half-tile tail, all half 
                                      folded weight only then) and at forward time */
        TP_TUNE_DYNAMIC_TILES = 3, /* 1 (default): persistent GEMMs draw tiles from per-XCD queues | 0: static striding */
        TP_TUNE_Q_SIDE_STREAM = 4, /* 1 (default): the query side runs on a forked side stream | 0: one stream */
-       TP_TUNE_RESERVE_CUS = 5,   /* r in 0..7 (default 0): persistent GEMMs launch (CUs/8 - r) workgroups per XCD, leaving
+       TP_TUNE_RESERVE_CUS = 5,   /* r in 0 .. CUs/8 - 1 (default 0): persistent GEMMs launch (CUs/8 - r) workgroups per XCD, leaving
                                      r CUs per XCD to kernels of other streams (RCCL's all-gather overlapping the next forward) */
        TP_TUNE_ABSORB_KV = 6,     /* K/V in-projection absorbed into the query side (see tp_forward): 0 auto (scale_factor >= 3),
                                      1 never, 2 always */

@@ -58,6 +58,41 @@ template <> struct Mma4<f16_t> {
     }
 };
 
+// ---- FETCH >= 2: the SPREAD schedule (round 6) --------------------------------------------------------------------------------
+// One K-tile = 128 MFMAs in program order m = 64 s + 8 j + i (k-step s, W fragment j, A fragment i); behind MFMA m at most ONE other
+// instruction (a fragment read, an LDS-DMA piece, or a wait + barrier), never two memory instructions in a row, the DMA pieces of
+// K-tile t + 2 spread over the whole iteration instead of riding the second k-step only, and THREE barriers per K-tile so that each
+// operand's region of buffer t & 1 is re-filled as soon as its last read has retired:
+//     m  0..14   reads A set 1 (buffer B, k-half 1)                     -> lgkmcnt(0), barrier #1: A region of buffer B is free
+//     m 22..45   DMA A pieces 0..7 of K-tile t + 2 -> buffer B  |  reads W set 1   -> lgkmcnt(0), barrier #2: W region free
+//     m 52..80   DMA W pieces 0..7
+//     m 84       vmcnt(16) — the 16 pieces issued in iteration t - 1 (K-tile t + 1) have landed —, barrier #3
+//     m 86..116  reads set 0 <- buffer B ^ 1, k-half 0                   -> lgkmcnt(0) behind MFMA 127
+// A piece is in flight for 1.0 .. 1.5 K-tile periods before it is waited for (schedule 0: 0.5 .. 1.0, behind a vmcnt(0)).  PH = 1
+// (odd waves when FETCH = 3) moves every memory instruction one MFMA slot later, so the four SIMDs of a CU do not present their reads
+// and DMA pieces to the LDS / the texture addresser in the same cycles.
+enum { G4_NONE = 0, G4_RA1, G4_RW1, G4_RA0, G4_RW0, G4_DA, G4_DW, G4_LB, G4_VB, G4_L };
+struct G4Slot { int kind, arg; };
+struct G4Sched { G4Slot s[128]; };
+constexpr G4Sched g4_make_sched(int ph) {
+    G4Sched r{};
+    for (int i = 0; i < 8; ++i) r.s[0 + 2 * i + ph] = G4Slot{G4_RA1, i};
+    r.s[21 + ph] = G4Slot{G4_LB, 0};
+    for (int q = 0; q < 8; ++q) r.s[22 + 3 * q + ph + (ph ? 0 : 0)] = G4Slot{G4_DA, q};
+    for (int j = 0; j < 8; ++j) r.s[24 + 3 * j + ph] = G4Slot{G4_RW1, j};
+    r.s[50 + ph] = G4Slot{G4_LB, 1};
+    for (int q = 0; q < 8; ++q) r.s[52 + 4 * q + ph] = G4Slot{G4_DW, q};
+    r.s[83 + ph] = G4Slot{G4_VB, 16};
+    for (int i = 0; i < 8; ++i) r.s[86 + 2 * i + ph] = G4Slot{G4_RA0, i};
+    for (int j = 0; j < 8; ++j) r.s[102 + 2 * j + ph] = G4Slot{G4_RW0, j};
+    r.s[127] = G4Slot{G4_L, 0};
+    return r;
+}
+template <int PH> struct G4SchedOf { static constexpr G4Sched value = g4_make_sched(PH); };
+template <int I, int N, typename F> __device__ __forceinline__ void g4_static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); g4_static_for<I + 1, N>(f); }
+}
+
 constexpr int G4_BM = 256, G4_BN = 256, G4_WM = 128, G4_WN = 128;
 constexpr int G4_HALF = 256 * ROW_BYTES;           // 32 KiB: the A (or W) rows of one K-tile
 constexpr int G4_BUF = 2 * G4_HALF;                // 64 KiB: one K-tile
@@ -253,6 +288,47 @@ gemm4_kernel(const GemmArgs p, const int tiles_m, const int tiles_n) {
         step(I1{}, std::integral_constant<bool, !LAST>{}, std::integral_constant<int, B ^ 1>{}, I0{}, ISSUE_, B_, t + 2);
     };
 
+    // FETCH >= 2: one K-tile of the spread schedule (header).  PH: memory instructions one slot later
+    auto ktile_spread = [&](auto B_, auto ISSUE_, auto LAST_, auto PH_, const int t) __attribute__((always_inline)) {
+        constexpr int B = decltype(B_)::value, PH = decltype(PH_)::value;
+        constexpr bool ISSUE = decltype(ISSUE_)::value, LAST = decltype(LAST_)::value;
+        g4_static_for<0, 128>([&](auto M_) __attribute__((always_inline)) {
+            constexpr int m = decltype(M_)::value;
+            constexpr int ks = m >> 6, j = (m >> 3) & 7, i = m & 7;
+            if constexpr (DBG != 4) Mma4<TI>::run(fb[ks][j], fa[ks][i], acc[i][j]);
+            else asm volatile("" :: "v"(fb[ks][j]), "v"(fa[ks][i]));
+            constexpr G4Slot op = G4SchedOf<PH>::value.s[m];
+            if constexpr (op.kind == G4_RA1 && DBG != 2) fa[1][op.arg] = *(const X8*)(rd_a[B][1] + op.arg * 2048);
+            if constexpr (op.kind == G4_RW1 && DBG != 2) fb[1][op.arg] = *(const X8*)(rd_w[B][1] + op.arg * 2048);
+            if constexpr (op.kind == G4_RA0 && DBG != 2 && !LAST) fa[0][op.arg] = *(const X8*)(rd_a[B ^ 1][0] + op.arg * 2048);
+            if constexpr (op.kind == G4_RW0 && DBG != 2 && !LAST) fb[0][op.arg] = *(const X8*)(rd_w[B ^ 1][0] + op.arg * 2048);
+            if constexpr (op.kind == G4_DA && ISSUE && DBG != 1) issue_piece(std::integral_constant<int, op.arg>{}, B, t + 2);
+            if constexpr (op.kind == G4_DW && ISSUE && DBG != 1) issue_piece(std::integral_constant<int, 8 + op.arg>{}, B, t + 2);
+            if constexpr (op.kind == G4_LB) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                if constexpr (!LAST) __builtin_amdgcn_s_barrier();
+            }
+            if constexpr (op.kind == G4_VB && !LAST) {
+                if constexpr (ISSUE && DBG != 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if constexpr (op.kind == G4_L) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                // the hazard recogniser does not see the inline-asm MFMAs (Mma4): at the exit of the steady loop the register allocator
+                // re-homes accumulators with v_accvgpr moves, which would read a[252:255] inside the last MFMA's latency (found as a
+                // deterministic loss of exactly that MFMA's contribution, tools/probes/solo_debug.py)
+                asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    auto k_loop_spread = [&](auto PH_) __attribute__((always_inline)) {
+        int t = 0;
+        for (; t < nk - 2; t += 2) { ktile_spread(I0{}, T_{}, F_{}, PH_, t); ktile_spread(I1{}, T_{}, F_{}, PH_, t + 1); }
+        ktile_spread(I0{}, F_{}, F_{}, PH_, t); ktile_spread(I1{}, F_{}, T_{}, PH_, t + 1);
+    };
+
     auto k_loop = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < FM; ++i)
@@ -275,6 +351,11 @@ gemm4_kernel(const GemmArgs p, const int tiles_m, const int tiles_n) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FETCH == 2) { k_loop_spread(I0{}); return; }
+        if constexpr (FETCH == 3) {
+            if (wave & 1) k_loop_spread(I1{}); else k_loop_spread(I0{});
+            return;
+        }
         int t = 0;
         for (; t < nk - 2; t += 2) { ktile(I0{}, T_{}, F_{}, t); ktile(I1{}, T_{}, F_{}, t + 1); }
         ktile(I0{}, F_{}, F_{}, t); ktile(I1{}, F_{}, T_{}, t + 1);
@@ -361,11 +442,19 @@ static int launch4_cfg(const GemmArgs& a, hipStream_t stream) {
     if constexpr (FETCH < 0) {
         if constexpr (DBG == 0 && AMODE == 0 && std::is_same<TI, f16_t>::value && std::is_same<TO, f16_t>::value) {
             const int dbg = tuning(TP_TUNE_PAIR_DEBUG) & 7;
-            if (dbg == 1) return g4_fetch_mode ? launch4_cfg<TI, TO, AMODE, 1, 1>(a, stream) : launch4_cfg<TI, TO, AMODE, 1, 0>(a, stream);
-            if (dbg == 2) return g4_fetch_mode ? launch4_cfg<TI, TO, AMODE, 2, 1>(a, stream) : launch4_cfg<TI, TO, AMODE, 2, 0>(a, stream);
-            if (dbg == 4) return g4_fetch_mode ? launch4_cfg<TI, TO, AMODE, 4, 1>(a, stream) : launch4_cfg<TI, TO, AMODE, 4, 0>(a, stream);
+            if (dbg == 1 || dbg == 2 || dbg == 4) {
+                const int f = g4_fetch_mode;
+                if (dbg == 1) return f == 2 ? launch4_cfg<TI, TO, AMODE, 1, 2>(a, stream) : f == 1 ? launch4_cfg<TI, TO, AMODE, 1, 1>(a, stream) : launch4_cfg<TI, TO, AMODE, 1, 0>(a, stream);
+                if (dbg == 2) return f == 2 ? launch4_cfg<TI, TO, AMODE, 2, 2>(a, stream) : f == 1 ? launch4_cfg<TI, TO, AMODE, 2, 1>(a, stream) : launch4_cfg<TI, TO, AMODE, 2, 0>(a, stream);
+                return f == 2 ? launch4_cfg<TI, TO, AMODE, 4, 2>(a, stream) : f == 1 ? launch4_cfg<TI, TO, AMODE, 4, 1>(a, stream) : launch4_cfg<TI, TO, AMODE, 4, 0>(a, stream);
+            }
         }
-        return g4_fetch_mode ? launch4_cfg<TI, TO, AMODE, DBG, 1>(a, stream) : launch4_cfg<TI, TO, AMODE, DBG, 0>(a, stream);
+        switch (g4_fetch_mode) {
+            case 1: return launch4_cfg<TI, TO, AMODE, DBG, 1>(a, stream);
+            case 2: return launch4_cfg<TI, TO, AMODE, DBG, 2>(a, stream);
+            case 3: return launch4_cfg<TI, TO, AMODE, DBG, 3>(a, stream);
+            default: return launch4_cfg<TI, TO, AMODE, DBG, 0>(a, stream);
+        }
     } else {
     auto kern = gemm4_kernel<TI, TO, AMODE, DBG, FETCH>;
     constexpr int lds = G4_LDS_BYTES;
@@ -415,7 +504,8 @@ int gemm4_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t str
 
 }  // namespace tp
 
-// tools/solo_ab.py: tp_linear's argument block on the experimental kernel.  fetch: 0 LDS-DMA | 1 register-staged
+// tools/solo_ab.py: tp_linear's argument block on the experimental kernel.  fetch: 0 LDS-DMA | 1 register-staged | 2 LDS-DMA, spread
+// schedule | 3 the same, odd waves one slot later
 extern "C" int tp_exp_gemm4(const tp_linear_args* a, void* stream, int fetch) {
     using namespace tp;
     GemmArgs g{};

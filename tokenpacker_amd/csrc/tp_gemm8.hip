@@ -42,6 +42,10 @@
 #include "tp_gemm_common.h"
 #include <mutex>
 
+#ifndef TP_G8_STAGGER_NS
+#define TP_G8_STAGGER_NS 0      // A/B build flag (round 6), see gemm8_kernel
+#endif
+
 namespace tp {
 
 namespace {
@@ -205,6 +209,14 @@ gemm8_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int x
         const int start = x * q + (x < r ? x : r);
         L = start + (blockIdx.x >> 3); L_end = start + q + (x < r ? 1 : 0); L_step = nwg >> 3;
         if (p.tile_counters) { queue = p.tile_counters + g * 8 + x; queue_base = start + L_step; }
+#if TP_G8_STAGGER_NS
+        // A/B build flag (round 6): the workgroups of an XCD start TP_G8_STAGGER_NS apart, so that their epilogues' store bursts (4 MiB
+        // per XCD and round, at the write roof when they coincide) meet other workgroups' K loops instead of each other
+        {
+            const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(blockIdx.x >> 3) * TP_G8_STAGGER_NS / 10;
+            while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(4);
+        }
+#endif
     } else {
         L = blockIdx.x; L_end = ntiles; L_step = nwg;
     }
@@ -810,7 +822,7 @@ bool gemm_probes_built() {
 // forward needs somewhere to run; a persistent workgroup holds its CU's LDS and registers for the whole launch).
 int gemm8_persistent_cus() {
     int r = tuning(TP_TUNE_RESERVE_CUS);
-    r = r < 0 ? 0 : (r > 7 ? 7 : r);
+    r = r < 0 ? 0 : r;                                  // (past 7: probes — tools/probes/store_bound_probe.py runs the kernel on 4 CUs per XCD)
     const int per_xcd = g8_num_cus() / 8 - r;
     return (per_xcd < 1 ? 1 : per_xcd) * 8;
 }

@@ -5,6 +5,16 @@
 #include "tp_internal.h"
 #include <type_traits>
 
+#ifndef TP_EPI_PROBE
+#define TP_EPI_PROBE 0         // timing probes of the epilogue (variant builds only; garbage results): 1 no output stores | 2 no arithmetic in front of them
+#endif
+#ifndef TP_EPI_FULL_LINE
+#define TP_EPI_FULL_LINE 0     // A/B build flag (round 6): half-precision outputs as whole 128-byte lines per row (1; 2 = non-temporal)
+#endif
+#ifndef TP_EPI_LANE_ADJ
+#define TP_EPI_LANE_ADJ 0      // A/B build flag (round 6): the half-precision output stores with adjacent lanes adjacent in memory
+#endif
+
 namespace tp {
 
 template <typename T> struct Mma;
@@ -203,6 +213,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
             // fragment-(j+1) half, after which every lane holds 8 consecutive columns -> 16-byte stores, 64
             // contiguous bytes per output row and instruction (the epilogue is store-ISSUE bound: measured 12.5 us
             // per 256x256 tile with 8-byte stores, profiles/r01g_epilogue_probe.txt).
+#if TP_EPI_FULL_LINE
+            typedef unsigned u32x4_fl __attribute__((ext_vector_type(4)));
+            u32x4_fl pk_fl[2];                          // the packed 64-byte segments of the slice's two fragment pairs
+#endif
 #pragma unroll
             for (int jj = 0; jj < FNV; jj += 2) {
                 const int j0 = vs * FNV + jj, j1 = j0 + 1;
@@ -216,8 +230,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
                     v0 += *(const f32x4*)(lds_par + (lc_lazy + j0 * 16) * 4);
                     v1 += *(const f32x4*)(lds_par + (lc_lazy + j1 * 16) * 4);
                 } else {
+#if TP_EPI_PROBE != 2
                 if (flags & TP_LINEAR_LN_FOLD) { v0 = rstd * (v0 - mu * csum_v[j0]); v1 = rstd * (v1 - mu * csum_v[j1]); }
                 v0 += bias_v[j0]; v1 += bias_v[j1];
+#endif
                 }
                 if constexpr (TRAIN_EPI) {
                 if (flags & TP_LINEAR_GELU_BWD) {          // backward of a GELU layer: dZ = dA * gelu'(Z), Z fp16 [M, ldz]
@@ -240,7 +256,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
                     }
                 }
                 }
-                if (flags & TP_LINEAR_GELU) {
+                if ((flags & TP_LINEAR_GELU) && TP_EPI_PROBE != 2) {
 #pragma unroll
                     for (int r = 0; r < 4; r += 2) {
                         const f32x2_ev g0 = gelu_erf2(f32x2_ev{v0[r], v0[r + 1]}), g1 = gelu_erf2(f32x2_ev{v1[r], v1[r + 1]});
@@ -265,7 +281,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
                 } else {
                     using O4 = typename Vec<TO>::x4;
                     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                    if constexpr (std::is_same<TO, f16_t>::value) {     // saturate instead of producing inf
+                    if constexpr (std::is_same<TO, f16_t>::value && TP_EPI_PROBE != 2) {     // saturate instead of producing inf
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             if constexpr (!TRAIN_EPI) sat_max = sat_track(sat_max, v0[r], v1[r]);
@@ -291,9 +307,49 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[WM / 16][WN / 16], co
                     // even 16-lane rows now hold columns g*4 .. g*4+7 of fragment j0 (own | upper neighbour's),
                     // odd rows columns (g-1)*4 .. (g-1)*4+7 of fragment j1 (lower neighbour's | own)
                     const int gq = lane >> 4;
+#if TP_EPI_PROBE == 1
+                    asm volatile("" :: "v"(sx[0]), "v"(sy[0]), "v"(sx[1]), "v"(sy[1]));   // (timing probe: arithmetic, no store)
+#elif TP_EPI_FULL_LINE
+                    pk_fl[jj >> 1] = u32x4_fl{sx[0], sy[0], sx[1], sy[1]};
+                    if (jj == 2) {
+                        // WHOLE-LINE stores: the slice's 64 columns are one 128-byte line per row.  Lane l takes (row l / 8 [+ 8 for the second
+                        // instruction], 16-byte chunk l % 8): chunk c comes from pair c / 4, lane group gq(c % 4), through ds_bpermute.  One
+                        // bpermute serves both instructions: in bpermute h' the source lanes of rows 0..7 offer pair h', those of rows 8..15
+                        // pair 1 - h'; a destination lane whose chunk is of pair h' reads row r (first instruction), the others row r + 8.
+                        const int c8 = lane & 7, rr = lane >> 3, hp = c8 >> 2;
+                        const int gsrc = ((c8 & 1) << 1) | ((c8 >> 1) & 1);
+                        const int a0 = (16 * gsrc + rr + (hp ? 8 : 0)) * 4, a1 = (16 * gsrc + rr + (hp ? 0 : 8)) * 4;
+                        const bool up = (lane & 8) != 0;
+                        u32x4_fl A4, B4;
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const unsigned s0 = up ? pk_fl[1][d] : pk_fl[0][d], s1 = up ? pk_fl[0][d] : pk_fl[1][d];
+                            const unsigned r0 = (unsigned)__builtin_amdgcn_ds_bpermute(a0, (int)s0), r1 = (unsigned)__builtin_amdgcn_ds_bpermute(a1, (int)s1);
+                            A4[d] = hp ? r1 : r0; B4[d] = hp ? r0 : r1;
+                        }
+                        const int m_fl = m0 + wm * WM + i * 16 + rr;
+                        const int col_fl = n0s + wn * WN + vs * 64 + c8 * 8;
+                        const unsigned off_fl = (unsigned)(((long long)m_fl * p.ldc + col_fl) * (long long)sizeof(TO));
+                        __builtin_amdgcn_raw_buffer_store_b128(A4, rsrc_c, (int)off_fl, 0, TP_EPI_FULL_LINE == 2 ? 2 : 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(B4, rsrc_c, (int)(off_fl + (unsigned)(8 * p.ldc * (int)sizeof(TO))), 0, TP_EPI_FULL_LINE == 2 ? 2 : 0);
+                    }
+#elif TP_EPI_LANE_ADJ
+                    // The 64-byte segment of row r sits in lanes r, r + 16, r + 32, r + 48 (16-byte chunks 0, 2, 1, 3): adjacent lanes
+                    // are adjacent ROWS, and the store unit handles that at ~53 cycles per instruction and CU where the same 16 rows x 64 B
+                    // with adjacent lanes adjacent in MEMORY take ~16 (tools/probes/store_pattern_probe.hip).  Four ds_bpermute_b32 (the
+                    // LDS crossbar, no LDS memory) move (row r, chunk c) to lane 4 r + c.
+                    const int src4 = ((((lane & 1) << 1) | ((lane >> 1) & 1)) * 16 + (lane >> 2)) * 4;
+                    const unsigned w0 = (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)sx[0]), w1 = (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)sy[0]);
+                    const unsigned w2 = (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)sx[1]), w3 = (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)sy[1]);
+                    const int m_adj = m0 + wm * WM + i * 16 + (lane >> 2);
+                    const int col_adj = n0s + wn * WN + j0 * 16 + (lane & 3) * 8;
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0, w1, w2, w3}, rsrc_c,
+                                                           (int)(unsigned)(((long long)m_adj * p.ldc + col_adj) * (long long)sizeof(TO)), 0, 0);
+#else
                     const int col = n0s + wn * WN + (j0 + (gq & 1)) * 16 + (gq >> 1) * 8;
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4{sx[0], sy[0], sx[1], sy[1]}, rsrc_c,
                                                            (int)(unsigned)(((long long)m * p.ldc + col) * (long long)sizeof(TO)), 0, 0);
+#endif
                 }
                 if constexpr (OUT_F32) {
                     if (flags & TP_LINEAR_ROW_STATS) {                  // (rejected by gemm_launch; kept for completeness)

@@ -45,6 +45,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/solo_ab.json")
     ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--dbg", type=int, default=0, help="TP_TUNE_PAIR_DEBUG probe build of the f16 -> f16 launches (1 no DMA | 2 no fragment reads | 4 no MFMAs; garbage results: skips the bit-identity check)")
+    ap.add_argument("--vendor", action="store_true", help="add torch.matmul (hipBLASLt) on the probe shapes: its per-K-tile / per-tile fit")
+    ap.add_argument("--arms", default="", help="comma-separated subset of the solo arms (pingpong always runs)")
     a = ap.parse_args()
     lib = ctypes.CDLL(os.path.join(ROOT, "tokenpacker_amd", "libtokenpacker_exp.so"))
     lib.tp_linear.restype = ctypes.c_int
@@ -55,10 +58,20 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     arms = {"pingpong": lambda args: lib.tp_linear(ctypes.byref(args), stream),
             "solo_dma": lambda args: lib.tp_exp_gemm4(ctypes.byref(args), stream, 0),
-            "solo_reg": lambda args: lib.tp_exp_gemm4(ctypes.byref(args), stream, 1)}
+            "solo_reg": lambda args: lib.tp_exp_gemm4(ctypes.byref(args), stream, 1),
+            # round 6: LDS-DMA with the SPREAD schedule (tp_gemm4.hip header: one memory instruction per MFMA slot at most, DMA pieces
+            # over the whole K-tile behind a counted vmcnt, three barriers), and the same with odd waves one slot later
+            "solo_spread": lambda args: lib.tp_exp_gemm4(ctypes.byref(args), stream, 2),
+            "solo_spread_stagger": lambda args: lib.tp_exp_gemm4(ctypes.byref(args), stream, 3)}
+    if a.arms:
+        arms = {k: v for k, v in arms.items() if k == "pingpong" or k in a.arms.split(",")}
 
     bad = 0
-    for dtype in (torch.bfloat16, torch.float16):
+    if a.dbg:
+        lib.tp_set_tuning.restype = ctypes.c_int
+        lib.tp_set_tuning.argtypes = [ctypes.c_int, ctypes.c_int]
+        assert lib.tp_set_tuning(_capi.TP_TUNE_PAIR_DEBUG, a.dbg) == 0, lib.tp_last_error()
+    for dtype in (() if a.dbg else (torch.bfloat16, torch.float16)):
         for (M, N, K) in [(256, 256, 128), (512, 512, 256), (1000, 1024, 1024), (300, 256, 4096), (77, 256, 1024), (18432, 2048, 4096)]:
             A, W, bias = rand((M, K), dtype, 1), rand((N, K), dtype, 2, K ** -0.5), rand((N,), torch.float32, 3)
             for odt in (torch.float16, torch.bfloat16):
@@ -70,7 +83,7 @@ def main():
                         assert rc == 0, (name, lib.tp_last_error())
                         torch.cuda.synchronize()
                         outs[name] = C
-                    for name in ("solo_dma", "solo_reg"):
+                    for name in [k for k in arms if k != "pingpong"]:
                         if not torch.equal(outs[name], outs["pingpong"]):
                             bad += 1
                             d = (outs[name].float() - outs["pingpong"].float()).abs()
@@ -80,11 +93,19 @@ def main():
     shapes = [("kv_layer0", 147456, 2048, 4096, torch.bfloat16, torch.float16, G), ("mlp2", 36864, 4096, 4096, torch.float16, torch.bfloat16, 0),
               ("mlp0", 36864, 4096, 1024, torch.float16, torch.float16, G), ("k1024", 147456, 1024, 1024, torch.float16, torch.float16, 0),
               ("probe_k4096", 36864, 4096, 4096, torch.float16, torch.float16, 0), ("probe_k1024", 36864, 4096, 1024, torch.float16, torch.float16, 0)]
-    res = {"mismatches": bad}
+    res = {"mismatches": bad, "dbg": a.dbg}
+    if a.dbg:
+        shapes = shapes[-2:]
+    if a.vendor:
+        arms = dict(arms)
+        arms["vendor_matmul"] = None
     for name, M, N, K, dt, odt, flags in shapes:
         A, W, bias = rand((M, K), dt, 1), rand((N, K), dt, 2, K ** -0.5), rand((N,), torch.float32, 3)
         C = torch.empty(M, N, dtype=odt, device="cuda")
         args = make_args(A, W, bias, C, flags)
+        if a.vendor:
+            Wt, Cv = W.t(), torch.empty(M, N, dtype=dt, device="cuda")
+            arms["vendor_matmul"] = lambda args, A=A, Wt=Wt, Cv=Cv: torch.matmul(A, Wt, out=Cv)
         for fn in arms.values():
             fn(args)
         torch.cuda.synchronize()
@@ -100,8 +121,7 @@ def main():
                 torch.cuda.synchronize()
                 times[k].append(e0.elapsed_time(e1) / 5)
         r = {k: round(statistics.median(v), 4) for k, v in times.items()}
-        res[name] = {"M": M, "N": N, "K": K, "ms": r, "solo_reg_over_pingpong": round(r["solo_reg"] / r["pingpong"], 4),
-                     "solo_dma_over_pingpong": round(r["solo_dma"] / r["pingpong"], 4)}
+        res[name] = {"M": M, "N": N, "K": K, "ms": r, **{k + "_over_pingpong": round(r[k] / r["pingpong"], 4) for k in r if k != "pingpong"}}
         print(name, res[name], flush=True)
     for k in arms:
         t4, t1 = res["probe_k4096"]["ms"][k], res["probe_k1024"]["ms"][k]
