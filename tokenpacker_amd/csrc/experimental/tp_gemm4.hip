@@ -47,14 +47,23 @@ namespace {
 // behind the loop's closing barrier and the next tile's prologue issue (>> the 18 wait states of the longest XDL -> VALU rule;
 // two s_nop 7 are placed there anyway).
 template <typename T> struct Mma4;
+// run_guarded (the spread schedule's tail K-tiles): outside the steady loop the register allocator re-homes accumulators (v_accvgpr_mov a248, a0
+// two instructions in front of the MFMA that reads a[248:251] — found as ONE stale register per 16 x 16 block, tools/probes/solo_debug.py);
+// the hazard recogniser cannot place the wait states for an instruction it does not see, so the asm carries them itself.
 template <> struct Mma4<bf16_t> {
     static __device__ __forceinline__ void run(bf16x8 a, bf16x8 b, f32x4& c) {
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    }
+    static __device__ __forceinline__ void run_guarded(bf16x8 a, bf16x8 b, f32x4& c) {
+        asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
     }
 };
 template <> struct Mma4<f16_t> {
     static __device__ __forceinline__ void run(f16x8 a, f16x8 b, f32x4& c) {
         asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    }
+    static __device__ __forceinline__ void run_guarded(f16x8 a, f16x8 b, f32x4& c) {
+        asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
     }
 };
 
@@ -295,8 +304,9 @@ gemm4_kernel(const GemmArgs p, const int tiles_m, const int tiles_n) {
         g4_static_for<0, 128>([&](auto M_) __attribute__((always_inline)) {
             constexpr int m = decltype(M_)::value;
             constexpr int ks = m >> 6, j = (m >> 3) & 7, i = m & 7;
-            if constexpr (DBG != 4) Mma4<TI>::run(fb[ks][j], fa[ks][i], acc[i][j]);
-            else asm volatile("" :: "v"(fb[ks][j]), "v"(fa[ks][i]));
+            if constexpr (DBG == 4) asm volatile("" :: "v"(fb[ks][j]), "v"(fa[ks][i]));
+            else if constexpr (ISSUE) Mma4<TI>::run(fb[ks][j], fa[ks][i], acc[i][j]);
+            else Mma4<TI>::run_guarded(fb[ks][j], fa[ks][i], acc[i][j]);
             constexpr G4Slot op = G4SchedOf<PH>::value.s[m];
             if constexpr (op.kind == G4_RA1 && DBG != 2) fa[1][op.arg] = *(const X8*)(rd_a[B][1] + op.arg * 2048);
             if constexpr (op.kind == G4_RW1 && DBG != 2) fb[1][op.arg] = *(const X8*)(rd_w[B][1] + op.arg * 2048);
@@ -309,7 +319,11 @@ gemm4_kernel(const GemmArgs p, const int tiles_m, const int tiles_n) {
                 if constexpr (!LAST) __builtin_amdgcn_s_barrier();
             }
             if constexpr (op.kind == G4_VB && !LAST) {
+#ifdef TP_G4_VM0
+                if constexpr (ISSUE && DBG != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
                 if constexpr (ISSUE && DBG != 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#endif
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
@@ -489,6 +503,10 @@ int gemm4_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t str
         set_error("tp gemm4: launch not supported by the solo kernel (M=%d N=%d K=%d flags=%d)", a.M, a.N, a.K, a.flags);
         return TP_ERR_INVALID_ARG;
     }
+#ifdef TP_G4_FAST      // (debug builds: one instantiation, seconds to compile)
+    if (in_dtype == TP_F16 && out_dtype == TP_F32) return launch4_cfg<f16_t, float, 0, 0, TP_G4_FAST>(a, stream);
+    set_error("tp gemm4: TP_G4_FAST build"); return TP_ERR_INVALID_ARG;
+#else
     if (in_dtype == TP_BF16) {
         if (out_dtype == TP_BF16) return launch4_types<bf16_t, bf16_t>(a, stream);
         if (out_dtype == TP_F16) return launch4_types<bf16_t, f16_t>(a, stream);
@@ -500,6 +518,7 @@ int gemm4_launch(int in_dtype, int out_dtype, const GemmArgs& a, hipStream_t str
     }
     set_error("tp gemm4: unsupported dtypes in=%d out=%d", in_dtype, out_dtype);
     return TP_ERR_INVALID_ARG;
+#endif
 }
 
 }  // namespace tp

@@ -34,8 +34,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/loop_probe.json")
     ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--reserve", type=int, default=0, help="TP_TUNE_RESERVE_CUS: run on (32 - reserve) CUs per XCD (16 / 24 / 28: 128 / 64 / 32 CUs; M is scaled to keep 9 tile rounds per CU)")
     a = ap.parse_args()
-    M, N = 36864, 4096
+    assert (32 - a.reserve) % 4 == 0 or a.reserve == 0, "reserve: 0, 4, 8, ..., 28 (whole rounds)"
+    M, N = 36864 * (32 - a.reserve) // 32, 4096
+    _capi.set_tuning(_capi.TP_TUNE_RESERVE_CUS, a.reserve)
     ops = {}
     for K in (1024, 4096):
         ops[K] = (rand((M, K), torch.float16, 1), rand((N, K), torch.float16, 2, K ** -0.5), rand((N,), torch.float32, 3))
@@ -61,6 +64,7 @@ def main():
     finally:
         _capi.set_tuning(_capi.TP_TUNE_PAIR_DEBUG, 0)
         _capi.set_tuning(_capi.TP_TUNE_PAIR_GEMM, 0)
+        _capi.set_tuning(_capi.TP_TUNE_RESERVE_CUS, 0)
     res = []
     for p, name in PROBES:
         t1, t4 = statistics.median(times[(p, 1024)]), statistics.median(times[(p, 4096)])
@@ -70,7 +74,7 @@ def main():
         res.append(r)
         print(r, flush=True)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
-    json.dump({"shape": [M, N], "probes": res}, open(a.out, "w"), indent=1)
+    json.dump({"shape": [M, N], "cus": (32 - a.reserve) * 8, "probes": res}, open(a.out, "w"), indent=1)
 
 
 if __name__ == "__main__":

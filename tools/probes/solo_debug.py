@@ -3,7 +3,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 from tokenpacker_amd import _capi
 import solo_ab
-lib = ctypes.CDLL(os.path.join(ROOT, "tokenpacker_amd", "libtokenpacker_exp.so"))
+lib = ctypes.CDLL(os.path.join(ROOT, "tokenpacker_amd", os.environ.get("SOLO_LIB", "libtokenpacker_exp.so")))
 lib.tp_linear.restype = ctypes.c_int; lib.tp_linear.argtypes = [ctypes.POINTER(_capi.tp_linear_args), ctypes.c_void_p]
 lib.tp_exp_gemm4.restype = ctypes.c_int; lib.tp_exp_gemm4.argtypes = [ctypes.POINTER(_capi.tp_linear_args), ctypes.c_void_p, ctypes.c_int]
 stream = torch.cuda.current_stream().cuda_stream
