@@ -37,6 +37,8 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
                  on the launch stream inside a real forward (tp_forward_staged), against the dense bf16 MFMA peak;
                  ``traffic`` = HBM bytes per launch from the rocprofv3 PMC passes condensed in profiles/traffic.json
                  (stamped with the git tree of the kernel sources they were measured on; a stale file is refused).
+                 ``at_sustained_clock`` (information BESIDE ``frac``, which stays achieved / 2.5 PFLOP/s): the same rate against
+                 the MFMA peak at the shader clock the power limit held over this launch in that PMC session (~1.8 of 2.4 GHz).
   cpu_baseline — the reference's op sequence (nn.Linear / F.interpolate / nn.MultiheadAttention ..., fp32) on the host
                  cores, BASELINE config 1 (B=4), a bounded ~12 s sample, rank 0 at N=1 only.
   eager_rocm_baseline — the same op sequence under PyTorch-ROCm eager on THIS GPU, same inputs / dtype / batch: the
@@ -338,6 +340,20 @@ def load_traffic(B: int, dtype: str, layout: str):
         return entry["total"], f"{stamp.get('tag')} @ {stamp.get('head')}"
     except Exception as exc:        # noqa: a broken file must not break the bench line
         return None, f"profiles/traffic.json unreadable: {exc}"
+
+
+def load_sustained_clock(B: int, dtype: str, layout: str):
+    """The shader clock the chip sustained over the dominant launch in the PMC session traffic.json was stamped in (GHz), or None.
+    The MFMA peak is priced at the 2.4 GHz boost clock; under this kernel the power limit holds the chip at ~1.8 GHz, and the loop's
+    time per K-tile follows the number of active CUs (DESIGN.md section 5.9 b).  Reported BESIDE `frac`, never instead of it."""
+    try:
+        doc = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        entry = doc.get(f"kv_layer0_B{B}_{dtype}")
+        if layout != "tower" or not entry or doc.get("_stamp", {}).get("kernel_source_sha16") != kernel_source_digest():
+            return None
+        return float(entry["shader_clock_ghz"])
+    except Exception:               # noqa
+        return None
 
 
 def build_model(D, s, dtype, device):
@@ -951,6 +967,13 @@ def main():
         # the store-heavy short-K launch over the launch that stores nothing: 0.8 - 0.9 normally, ~1.3 in the slow memory-side
         # power state some boxes put a 32 ... 128-image forward in (profiles/r03u_mid_batch_anomaly.txt)
         out["clocks"] = clocks
+        sclk = load_sustained_clock(B, args.dtype, args.layout)
+        if sclk:
+            # information beside `frac` (which stays achieved / 2.5 PFLOP/s): the same rate against the peak at the clock the power limit allows
+            out["roofline"]["at_sustained_clock"] = {"shader_clock_ghz": round(sclk, 3), "boost_clock_ghz": 2.4,
+                                                     "peak": round(MFMA_PEAK_TFLOPS * sclk / 2.4, 1),
+                                                     "frac": round(achieved / (MFMA_PEAK_TFLOPS * sclk / 2.4), 4),
+                                                     "source": "profiles/traffic.json (cycle counters of the PMC session over this launch); DESIGN.md 5.9 (b)"}
         if stage_ms[2] > 0 and s == 2:
             out["memory_side"] = {"mlp0_over_statistics": round(stage_ms[8] / stage_ms[2], 3),
                                   "note": "mlp0_gelu / kv_layer2_stats of this rank's forward; ~0.85 normal, >= 1.2 = the node's slow memory-side power state"}
