@@ -1,3 +1,4 @@
+// (round 6: FETCH = 2 / 3 — the SPREAD schedule re-built from the disassembly of the vendor's hand-written kernel, see G4Sched below and DESIGN.md 5.9.)
 // EXPERIMENTAL (round 5; NOT part of libtokenpacker_hip.so — `make exp` links it into libtokenpacker_exp.so for tools/solo_ab.py).
 // Round 4's one-wave-per-SIMD kernel (commit 638f1b9) with a second operand fetch: FETCH = 1 stages the loop's operands through
 // REGISTERS (buffer_load_dwordx4 -> VGPR -> ds_write_b128, the vendor library's way — its kernel for these shapes is a hand-written
@@ -440,6 +441,7 @@ gemm4_kernel(const GemmArgs p, const int tiles_m, const int tiles_n) {
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
+#if !defined(TP_G4_PART) || TP_G4_PART == 0
 bool gemm4_supports(int in_dtype, int out_dtype, const GemmArgs& a) {
     if (a.tt_rows > 0 || a.half_tiles || a.m_begin != 0 || a.m_end != 0 || a.stats_parts || a.parts_k_groups || a.A_parts[0]) return false;
     if (a.flags & (TP_LINEAR_SAVE_PRE | TP_LINEAR_GELU_BWD | TP_LINEAR_NO_STORE)) return false;
@@ -450,7 +452,9 @@ bool gemm4_supports(int in_dtype, int out_dtype, const GemmArgs& a) {
     return in_dtype == TP_BF16 || in_dtype == TP_F16;
 }
 
-static int g4_fetch_mode = 0;       // set by tp_exp_gemm4 (single-threaded tool)
+#endif
+[[maybe_unused]] static int g4_fetch_mode = 0;       // set by tp_exp_gemm4 (single-threaded tool)
+int gemm4_launch_spread(int in_dtype, int out_dtype, int dbg, bool stagger, const GemmArgs& a, hipStream_t stream);   // (-DTP_G4_PART=1 object)
 template <typename TI, typename TO, int AMODE, int DBG = 0, int FETCH = -1>
 static int launch4_cfg(const GemmArgs& a, hipStream_t stream) {
     if constexpr (FETCH < 0) {
@@ -458,15 +462,22 @@ static int launch4_cfg(const GemmArgs& a, hipStream_t stream) {
             const int dbg = tuning(TP_TUNE_PAIR_DEBUG) & 7;
             if (dbg == 1 || dbg == 2 || dbg == 4) {
                 const int f = g4_fetch_mode;
-                if (dbg == 1) return f == 2 ? launch4_cfg<TI, TO, AMODE, 1, 2>(a, stream) : f == 1 ? launch4_cfg<TI, TO, AMODE, 1, 1>(a, stream) : launch4_cfg<TI, TO, AMODE, 1, 0>(a, stream);
-                if (dbg == 2) return f == 2 ? launch4_cfg<TI, TO, AMODE, 2, 2>(a, stream) : f == 1 ? launch4_cfg<TI, TO, AMODE, 2, 1>(a, stream) : launch4_cfg<TI, TO, AMODE, 2, 0>(a, stream);
-                return f == 2 ? launch4_cfg<TI, TO, AMODE, 4, 2>(a, stream) : f == 1 ? launch4_cfg<TI, TO, AMODE, 4, 1>(a, stream) : launch4_cfg<TI, TO, AMODE, 4, 0>(a, stream);
+                if (f == 2) return gemm4_launch_spread(TP_F16, TP_F16, dbg, 0, a, stream);
+                if (dbg == 1) return f == 1 ? launch4_cfg<TI, TO, AMODE, 1, 1>(a, stream) : launch4_cfg<TI, TO, AMODE, 1, 0>(a, stream);
+                if (dbg == 2) return f == 1 ? launch4_cfg<TI, TO, AMODE, 2, 1>(a, stream) : launch4_cfg<TI, TO, AMODE, 2, 0>(a, stream);
+                return f == 1 ? launch4_cfg<TI, TO, AMODE, 4, 1>(a, stream) : launch4_cfg<TI, TO, AMODE, 4, 0>(a, stream);
             }
         }
+        // The spread schedule's 128-slot static_for is slow to compile, so its instantiations are a second object of this file
+        // (-DTP_G4_PART=1, built in parallel: gemm4_launch_spread) and exist where tools/solo_ab.py uses them: contiguous A, half-precision
+        // outputs; the SIMD-parity stagger (FETCH 3: measured, slower) only with -DTP_G4_STAGGER.
         switch (g4_fetch_mode) {
             case 1: return launch4_cfg<TI, TO, AMODE, DBG, 1>(a, stream);
-            case 2: return launch4_cfg<TI, TO, AMODE, DBG, 2>(a, stream);
-            case 3: return launch4_cfg<TI, TO, AMODE, DBG, 3>(a, stream);
+            case 2: case 3:
+                if constexpr (AMODE == 0 && DBG == 0 && !std::is_same<TO, float>::value)
+                    return gemm4_launch_spread(std::is_same<TI, bf16_t>::value ? TP_BF16 : TP_F16, std::is_same<TO, bf16_t>::value ? TP_BF16 : TP_F16, 0,
+                                               g4_fetch_mode == 3, a, stream);
+                else { set_error("tp gemm4: the spread schedule is built for contiguous A and half-precision outputs"); return TP_ERR_INVALID_ARG; }
             default: return launch4_cfg<TI, TO, AMODE, DBG, 0>(a, stream);
         }
     } else {
@@ -492,6 +503,24 @@ static int launch4_cfg(const GemmArgs& a, hipStream_t stream) {
     }
 }
 
+#if defined(TP_G4_PART) && TP_G4_PART == 1
+// the spread schedule's instantiations (dbg: the probe builds of the f16 -> f16 launch)
+int gemm4_launch_spread(int in_dtype, int out_dtype, int dbg, bool stagger, const GemmArgs& a, hipStream_t stream) {
+#ifdef TP_G4_STAGGER
+    if (stagger && dbg == 0) {
+        if (in_dtype == TP_BF16) return out_dtype == TP_BF16 ? launch4_cfg<bf16_t, bf16_t, 0, 0, 3>(a, stream) : launch4_cfg<bf16_t, f16_t, 0, 0, 3>(a, stream);
+        return out_dtype == TP_BF16 ? launch4_cfg<f16_t, bf16_t, 0, 0, 3>(a, stream) : launch4_cfg<f16_t, f16_t, 0, 0, 3>(a, stream);
+    }
+#endif
+    if (stagger) { set_error("tp gemm4: fetch 3 (spread schedule + SIMD-parity stagger) needs a -DTP_G4_STAGGER build"); return TP_ERR_INVALID_ARG; }
+    if (dbg == 1) return launch4_cfg<f16_t, f16_t, 0, 1, 2>(a, stream);
+    if (dbg == 2) return launch4_cfg<f16_t, f16_t, 0, 2, 2>(a, stream);
+    if (dbg == 4) return launch4_cfg<f16_t, f16_t, 0, 4, 2>(a, stream);
+    if (in_dtype == TP_BF16) return out_dtype == TP_BF16 ? launch4_cfg<bf16_t, bf16_t, 0, 0, 2>(a, stream) : launch4_cfg<bf16_t, f16_t, 0, 0, 2>(a, stream);
+    return out_dtype == TP_BF16 ? launch4_cfg<f16_t, bf16_t, 0, 0, 2>(a, stream) : launch4_cfg<f16_t, f16_t, 0, 0, 2>(a, stream);
+}
+}  // namespace tp
+#else
 template <typename TI, typename TO>
 static int launch4_types(const GemmArgs& a, hipStream_t stream) {
     const bool strided_a = a.rows_per_batch < a.M || a.a_region_s > 0;
@@ -536,3 +565,4 @@ extern "C" int tp_exp_gemm4(const tp_linear_args* a, void* stream, int fetch) {
     g4_fetch_mode = fetch;
     return gemm4_launch(a->dtype, a->out_dtype, g, (hipStream_t)stream);
 }
+#endif      // TP_G4_PART
