@@ -70,6 +70,38 @@ __device__ __forceinline__ float gelu_erf(float v) {
 // the same on two elements at once, written on 2-vectors so that hipcc emits v_pk_fma_f32 / v_pk_mul_f32 (two
 // elements per instruction at the scalar instruction's issue cost) for the Horner chain and the squarings
 typedef float f32x2_ev __attribute__((ext_vector_type(2)));
+#ifndef TP_GELU_FAST
+#define TP_GELU_FAST 0          // A/B build flag (round 6): 22 instead of 25 issue slots per pair (below)
+#endif
+#if TP_GELU_FAST
+// The same approximation with three issue slots less per pair (22 for 25): |v| and a clamp at 9 in ONE v_min_f32 (source modifier; beyond 9 the
+// correction term is < 1e-16 and the clamp keeps t^16 of BOTH lanes inside fp32 for the shared reciprocal), 1/sqrt2 folded into the coefficients,
+// ONE v_rcp_f32 per pair (1/a = b * rcp(a b), 1/b = a * rcp(a b): the reciprocal is a quarter-rate instruction), relu as v_med3_f32.
+__device__ __forceinline__ f32x2_ev gelu_erf2(f32x2_ev v) {
+    // (inline asm: fminf / fmaxf / fmed3f on a value the compiler cannot prove canonical cost a canonicalising v_max_f32 each)
+    f32x2_ev a;
+    { float a0, a1;
+      asm("v_min_f32_e64 %0, |%1|, %2" : "=v"(a0) : "v"(v[0]), "v"(9.0f));
+      asm("v_min_f32_e64 %0, |%1|, %2" : "=v"(a1) : "v"(v[1]), "v"(9.0f));
+      a[0] = a0; a[1] = a1; }
+    constexpr float s = 0.70710678118654752440f, s2 = s * s, s3 = s2 * s, s4 = s2 * s2, s5 = s4 * s, s6 = s3 * s3;
+    f32x2_ev p = __builtin_elementwise_fma(a, (f32x2_ev)(0.0000430638f * s6), (f32x2_ev)(0.0002765672f * s5));
+    p = __builtin_elementwise_fma(p, a, (f32x2_ev)(0.0001520143f * s4));
+    p = __builtin_elementwise_fma(p, a, (f32x2_ev)(0.0092705272f * s3));
+    p = __builtin_elementwise_fma(p, a, (f32x2_ev)(0.0422820123f * s2));
+    p = __builtin_elementwise_fma(p, a, (f32x2_ev)(0.0705230784f * s));
+    p = __builtin_elementwise_fma(p, a, (f32x2_ev)(1.0f));
+    p *= p; p *= p; p *= p; p *= p;
+    const float R = __builtin_amdgcn_rcpf(p[0] * p[1]);
+    const f32x2_ev r = f32x2_ev{p[1], p[0]} * R;
+    f32x2_ev relu;
+    { float r0, r1;
+      asm("v_max_f32_e32 %0, 0, %1" : "=v"(r0) : "v"(v[0]));
+      asm("v_max_f32_e32 %0, 0, %1" : "=v"(r1) : "v"(v[1]));
+      relu[0] = r0; relu[1] = r1; }
+    return __builtin_elementwise_fma(a * -0.5f, r, relu);
+}
+#else
 __device__ __forceinline__ f32x2_ev gelu_erf2(f32x2_ev v) {
     const f32x2_ev av = __builtin_elementwise_abs(v);
     const f32x2_ev x = av * 0.70710678118654752440f;
@@ -86,6 +118,7 @@ __device__ __forceinline__ f32x2_ev gelu_erf2(f32x2_ev v) {
     // (relu as 0.5 (v + |v|): exact, and packed — fmaxf would cost a canonicalising v_max_f32 besides the max)
     return __builtin_elementwise_fma(av * -0.5f, r, (v + av) * 0.5f);
 }
+#endif
 
 // GemmArgs::a_region_s: region-major row index -> raster row index (reference divide_feature's grouping, builder.py:96-105)
 __device__ __forceinline__ int region_major_to_raster(int row, int g, int s) {
