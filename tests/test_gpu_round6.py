@@ -188,3 +188,23 @@ def test_a_backward_that_leaves_fp16_says_so():
         torch.cuda.synchronize()
     assert any("saturated fp16" in str(r.message) for r in rec), [str(r.message) for r in rec]
     assert m.backward_saturated() == 0                       # (the word belongs to ONE backward: this clean one cleared it)
+
+
+@pytest.mark.parametrize("reserve", [3, 28, 31, 40])
+def test_a_forward_on_any_number_of_reserved_cus_is_the_same_function(reserve):
+    """TP_TUNE_RESERVE_CUS leaves r CUs per XCD to other streams; since round 6 the persistent kernels take any r (probes run them on 4 CUs per
+    XCD; past CUs/8 - 1 one workgroup per XCD is left).  The tile queues make the result independent of how many workgroups draw from them."""
+    D, s, B, dtype = 4096, 2, 40, torch.bfloat16
+    params = synth.make_params(621, D)
+    x, xm = synth.make_inputs(622, B, dtype)
+    xg, xmg = x.cuda(), xm.cuda()
+    m = _module(params, s, D, dtype)
+    with torch.no_grad():
+        ref = m((xg, xmg))
+        try:
+            _capi.set_tuning(_capi.TP_TUNE_RESERVE_CUS, reserve)
+            out = m((xg, xmg))
+            torch.cuda.synchronize()
+        finally:
+            _capi.set_tuning(_capi.TP_TUNE_RESERVE_CUS, 0)
+    assert torch.equal(out, ref)
