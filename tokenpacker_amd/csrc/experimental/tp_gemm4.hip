@@ -185,6 +185,11 @@ gemm4_kernel(const GemmArgs p, const int tiles_m, const int tiles_n) {
             if constexpr (AMODE == 0) voff_a[q] = __mul24(row - m0, (int)p.lda_bytes) + kslot * 16;
             else voff_a[q] = (int)(a_row_off(row) - a_tile_off) + kslot * 16;
             voff_w[q] = __mul24(r, (int)ldw) + kslot * 16;
+            // FETCH 4 / 5 (TIMING PROBES, garbage results — round 6): the addresses a TILE-MAJOR operand layout would produce (each 256-row x 64-k
+            // slab 32 KiB contiguous: a DMA piece is 1 KiB contiguous instead of 8 rows x 128 B a row stride apart), inside the tile's own
+            // 256 x K bytes.  4: both operands  5: W only (the weights are ours to lay out; A is the caller's)
+            if constexpr (FETCH == 4) voff_a[q] = (row - m0) * ROW_BYTES + kslot * 16;
+            if constexpr (FETCH == 4 || FETCH == 5) voff_w[q] = r * ROW_BYTES + kslot * 16;
         }
     };
     // piece idx (0..7: A, 8..15: W) of K-tile kt -> buffer `buf`
@@ -193,8 +198,9 @@ gemm4_kernel(const GemmArgs p, const int tiles_m, const int tiles_n) {
         constexpr bool is_a = idx < 8;
         constexpr int q = idx & 7;
         char* dst = smem + buf * G4_BUF + (is_a ? 0 : G4_HALF) + (wave * 8 + q) * 1024;
-        if constexpr (is_a) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)dst, 16, voff_a[q], kt * ROW_BYTES, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void*)dst, 16, voff_w[q], kt * ROW_BYTES, 0, 0);
+        constexpr int KSTEP_A = FETCH == 4 ? 256 * ROW_BYTES : ROW_BYTES, KSTEP_W = (FETCH == 4 || FETCH == 5) ? 256 * ROW_BYTES : ROW_BYTES;
+        if constexpr (is_a) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)dst, 16, voff_a[q], kt * KSTEP_A, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void*)dst, 16, voff_w[q], kt * KSTEP_W, 0, 0);
     };
     auto issue_ktile = [&](const int buf, const int kt) __attribute__((always_inline)) {
         issue_piece(std::integral_constant<int, 0>{}, buf, kt); issue_piece(std::integral_constant<int, 1>{}, buf, kt);
@@ -264,7 +270,7 @@ gemm4_kernel(const GemmArgs p, const int tiles_m, const int tiles_n) {
                 if constexpr (c < 8) fa[SET ^ 1][c] = *(const X8*)(rd_a[NB][NKS] + c * 2048);
                 else fb[SET ^ 1][c - 8] = *(const X8*)(rd_w[NB][NKS] + (c - 8) * 2048);
             }
-            if constexpr (ISSUE && DBG != 1 && FETCH == 0) issue_piece(C_, IB, kt_issue);
+            if constexpr (ISSUE && DBG != 1 && (FETCH == 0 || FETCH >= 4)) issue_piece(C_, IB, kt_issue);
             if constexpr (ISSUE && DBG != 1 && FETCH == 1) {
                 write_piece(C_, IB);                                    // K-tile kt_issue (loaded a K-tile ago) -> the buffer B_t freed
                 // ... and the registers take the K-tile after it (past the end: the last K-tile again — no branch in the stream;
@@ -291,7 +297,7 @@ gemm4_kernel(const GemmArgs p, const int tiles_m, const int tiles_n) {
         step(I0{}, T_{}, B_, I1{}, F_{}, I0{}, 0);
         // (FETCH = 0: K-tile t + 1's DMA pieces must have landed.  FETCH = 1: nothing is in flight towards LDS except ds_writes, which the
         // lgkmcnt(0) below retires; the register loads of K-tile t + 2 stay in flight across the barrier)
-        if constexpr (!LAST && FETCH == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!LAST && (FETCH == 0 || FETCH >= 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): this wave's reads of buffer B (and its ds_writes) have retired
         if constexpr (!LAST) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -471,6 +477,11 @@ static int launch4_cfg(const GemmArgs& a, hipStream_t stream) {
         // The spread schedule's 128-slot static_for is slow to compile, so its instantiations are a second object of this file
         // (-DTP_G4_PART=1, built in parallel: gemm4_launch_spread) and exist where tools/solo_ab.py uses them: contiguous A, half-precision
         // outputs; the SIMD-parity stagger (FETCH 3: measured, slower) only with -DTP_G4_STAGGER.
+        if (g4_fetch_mode == 4 || g4_fetch_mode == 5) {
+            if constexpr (AMODE == 0 && DBG == 0 && std::is_same<TI, f16_t>::value && std::is_same<TO, f16_t>::value)
+                return g4_fetch_mode == 4 ? launch4_cfg<TI, TO, AMODE, 0, 4>(a, stream) : launch4_cfg<TI, TO, AMODE, 0, 5>(a, stream);
+            else { set_error("tp gemm4: the tile-major timing probes are built for contiguous fp16 -> fp16 launches"); return TP_ERR_INVALID_ARG; }
+        }
         switch (g4_fetch_mode) {
             case 1: return launch4_cfg<TI, TO, AMODE, DBG, 1>(a, stream);
             case 2: case 3:

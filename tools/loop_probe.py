@@ -35,9 +35,11 @@ def main():
     ap.add_argument("--out", default="gpurun_out/loop_probe.json")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reserve", type=int, default=0, help="TP_TUNE_RESERVE_CUS: run on (32 - reserve) CUs per XCD (16 / 24 / 28: 128 / 64 / 32 CUs; M is scaled to keep 9 tile rounds per CU)")
+    ap.add_argument("--rows", type=int, default=0, help="M (default 36864 = 9 tile rounds per CU; 20480 = 5 rounds, A = 168 MB at K = 4096: inside the Infinity Cache)")
     a = ap.parse_args()
     assert (32 - a.reserve) % 4 == 0 or a.reserve == 0, "reserve: 0, 4, 8, ..., 28 (whole rounds)"
-    M, N = 36864 * (32 - a.reserve) // 32, 4096
+    M, N = (a.rows or 36864) * (32 - a.reserve) // 32, 4096
+    rounds_per_cu = M // 256 * 16 / ((32 - a.reserve) * 8)
     _capi.set_tuning(_capi.TP_TUNE_RESERVE_CUS, a.reserve)
     ops = {}
     for K in (1024, 4096):
@@ -68,9 +70,9 @@ def main():
     res = []
     for p, name in PROBES:
         t1, t4 = statistics.median(times[(p, 1024)]), statistics.median(times[(p, 4096)])
-        per = (t4 - t1) / 9 / 48 * 1e3
+        per = (t4 - t1) / rounds_per_cu / 48 * 1e3
         r = {"probe": p, "what": name, "ms_K1024": round(t1, 4), "ms_K4096": round(t4, 4), "us_per_ktile": round(per, 4),
-             "us_fixed_per_tile": round(t1 / 9 * 1e3 - 16 * per, 3)}
+             "us_fixed_per_tile": round(t1 / rounds_per_cu * 1e3 - 16 * per, 3), "us_per_tile_K4096": round(t4 / rounds_per_cu * 1e3, 2)}
         res.append(r)
         print(r, flush=True)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)

@@ -49,7 +49,30 @@ __global__ void __launch_bounds__(512, 2) probe(const char* __restrict__ src, fl
         voff = row * LDA + slot16 * 16;
     }
     constexpr int PSTEP = PATTERN == 0 ? 8192 : 64 * LDA;           // piece p -> p-th block of 64 rows
-    if constexpr (MODE == 0 && PATTERN >= 9) {
+    if constexpr (MODE == 0 && PATTERN >= 13) {
+        // (round 6) Shared STRIDED streams — the GEMM's real operand walk: a step = one 64-wide K-tile slab of 512 operand rows (64 pieces of
+        // 8 rows x 128 B, rows LDS apart), 64 steps along K (128 B each, K = 4096), then the next 512 rows; the workgroups of an XCD all read
+        // the same stream.  13: row stride 8 KiB (K = 4096 fp16, what the GEMMs address)  14: 8 KiB + 128 B  15: 2 KiB (K = 1024)  16: 2 KiB + 128 B
+        constexpr int LDS_ = (PATTERN == 13 ? 8192 : PATTERN == 14 ? 8192 + 128 : PATTERN == 15 ? 2048 : 2048 + 128);
+        constexpr int KSTEPS = (PATTERN <= 14 ? 64 : 16);
+        const char* base = src + (size_t)x * (100u << 20);               // 100 MiB of span per XCD: 24 blocks of 512 rows
+        const int r = lane >> 3, pslot = lane & 7;
+        const int voff_s = (wave * 8 + r) * LDS_ + pslot * 16;          // piece p of this wave: rows 64 p + 8 wave + r
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+        int kt = 0, blk = 0;
+        for (int it = 0; it < iters; ++it) {
+            char* dst = smem + (it & 1) * 65536 + wave * 1024;
+            const int soff = blk * 512 * LDS_ + kt * 128;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(dst + p * 8192), 16, voff_s, soff + p * 64 * LDS_, 0, 0);
+                wait_vm<IN_FLIGHT - 1>();
+            }
+            if (++kt == KSTEPS) { kt = 0; blk = blk + 1 == 24 ? 0 : blk + 1; }
+            if constexpr (BARRIER) __builtin_amdgcn_s_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if constexpr (MODE == 0 && PATTERN >= 9) {
         // Shared streams (what a GEMM's operands are): the 32 workgroups of an XCD read the SAME 64 KiB per step, in lockstep only by
         // their equal pace.  9: always the same 64 KiB (L2-resident, shared)  10: a 24-MiB region per XCD walked round and round
         // (beyond the 4-MiB L2, inside the Infinity Cache)  11: as 10 but each workgroup starts a quarter of the region apart in
@@ -108,14 +131,15 @@ __global__ void __launch_bounds__(512, 2) probe(const char* __restrict__ src, fl
     if (iters < 0) out[blockIdx.x * 512 + threadIdx.x] = *(const float*)(smem + threadIdx.x * 4);     // keep the LDS writes alive
 }
 
+static int g_nwg = 256;          // argv[1]: workgroups (256 = one per CU; 64 = 8 per XCD, round 6: is the fetch rate a per-CU or a per-XCD figure?)
 template <int MODE, int IN_FLIGHT, bool BARRIER, int PATTERN = 0>
 static double run(const char* src, float* out, int iters) {
     auto kern = probe<MODE, IN_FLIGHT, BARRIER, PATTERN>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(kern, dim3(256), dim3(512), 131072, 0, src, out, iters / 8, 0);    // warm-up: the windows reach the L2s
+    hipLaunchKernelGGL(kern, dim3(g_nwg), dim3(512), 131072, 0, src, out, iters / 8, 0);    // warm-up: the windows reach the L2s
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(kern, dim3(256), dim3(512), 131072, 0, src, out, iters, 0);
+    hipLaunchKernelGGL(kern, dim3(g_nwg), dim3(512), 131072, 0, src, out, iters, 0);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
@@ -123,21 +147,26 @@ static double run(const char* src, float* out, int iters) {
     return (double)iters * 65536.0 / (ms * 1e-3) / 1e9;       // GB/s per CU
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_nwg = atoi(argv[1]);
+    const bool quick = argc > 2;                               // argv[2]: only the LDS-DMA rows
+    printf("workgroups: %d (%d per XCD)\n", g_nwg, g_nwg / 8);
     char* src; float* out;
     const size_t bytes = ((size_t)256 << 22) + (64u << 20);                   // 1 GiB of span for the row patterns (64 KiB of lines per workgroup are touched)
     hipMalloc(&src, bytes); hipMalloc(&out, 256 * 512 * sizeof(float));
     hipMemset(src, 1, bytes);
     const int iters = 24000;                                   // 1.5 GB per CU: ~15-30 ms per launch
-    for (int rep = 0; rep < 3; ++rep) {
+    for (int rep = 0; rep < (quick ? 2 : 3); ++rep) {
         printf("rep %d  (GB/s per CU; x256 = chip)\n", rep);
 #define ROW(MODE, NAME) \
         printf("  %-44s  in flight 4: %6.1f   8: %6.1f   12: %6.1f   | with a barrier per 64 KiB, 8 in flight: %6.1f\n", NAME, \
                run<MODE, 4, false>(src, out, iters), run<MODE, 8, false>(src, out, iters), run<MODE, 12, false>(src, out, iters), \
                run<MODE, 8, true>(src, out, iters));
         ROW(0, "buffer_load_dwordx4 ... lds (LDS-DMA)")
+        if (!quick) {
         ROW(1, "global_load_dwordx4 -> VGPR (no LDS write)")
         ROW(2, "global_load_dwordx4 -> VGPR -> ds_write_b128")
+        }
 #define PAT(P, NAME) printf("    %-58s  in flight 6: %6.1f   8: %6.1f   12: %6.1f   | barrier per 64 KiB, 6 in flight: %6.1f\n", NAME, \
                run<0, 6, false, P>(src, out, iters), run<0, 8, false, P>(src, out, iters), run<0, 12, false, P>(src, out, iters), run<0, 6, true, P>(src, out, iters));
         printf("  LDS-DMA by address pattern of a piece:\n");
@@ -155,6 +184,11 @@ int main() {
         PAT(10, "one 24-MiB stream per XCD (Infinity Cache), 32 sharers")
         PAT(11, "four 24-MiB streams per XCD, 8 sharers each")
         PAT(12, "32 streams per XCD, no sharing")
+        printf("  LDS-DMA, the GEMM's own walk (8 rows x 128 B per piece, K-tile after K-tile along the rows), one stream per XCD, all its workgroups share it:\n");
+        PAT(13, "row stride 8 KiB (K = 4096)")
+        PAT(14, "row stride 8 KiB + 128 B")
+        PAT(15, "row stride 2 KiB (K = 1024)")
+        PAT(16, "row stride 2 KiB + 128 B")
         fflush(stdout);
     }
     hipError_t e = hipDeviceSynchronize();

@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--dbg", type=int, default=0, help="TP_TUNE_PAIR_DEBUG probe build of the f16 -> f16 launches (1 no DMA | 2 no fragment reads | 4 no MFMAs; garbage results: skips the bit-identity check)")
     ap.add_argument("--vendor", action="store_true", help="add torch.matmul (hipBLASLt) on the probe shapes: its per-K-tile / per-tile fit")
+    ap.add_argument("--tile-major", action="store_true", help="add the tile-major addressing probes of the solo kernel on the fp16 probe shapes (skips the bit-identity check)")
     ap.add_argument("--arms", default="", help="comma-separated subset of the solo arms (pingpong always runs)")
     a = ap.parse_args()
     lib = ctypes.CDLL(os.path.join(ROOT, "tokenpacker_amd", "libtokenpacker_exp.so"))
@@ -63,15 +64,18 @@ def main():
             # over the whole K-tile behind a counted vmcnt, three barriers), and the same with odd waves one slot later
             "solo_spread": lambda args: lib.tp_exp_gemm4(ctypes.byref(args), stream, 2),
             "solo_spread_stagger": lambda args: lib.tp_exp_gemm4(ctypes.byref(args), stream, 3)}
+    if a.tile_major:                        # timing probes (garbage results): the addresses of a tile-major operand layout
+        arms["solo_tile_major"] = lambda args: lib.tp_exp_gemm4(ctypes.byref(args), stream, 4)
+        arms["solo_tile_major_w"] = lambda args: lib.tp_exp_gemm4(ctypes.byref(args), stream, 5)
     if a.arms:
-        arms = {k: v for k, v in arms.items() if k == "pingpong" or k in a.arms.split(",")}
+        arms = {k: v for k, v in arms.items() if k == "pingpong" or k in a.arms.split(",") or k.startswith("solo_tile_major")}
 
     bad = 0
     if a.dbg:
         lib.tp_set_tuning.restype = ctypes.c_int
         lib.tp_set_tuning.argtypes = [ctypes.c_int, ctypes.c_int]
         assert lib.tp_set_tuning(_capi.TP_TUNE_PAIR_DEBUG, a.dbg) == 0, lib.tp_last_error()
-    for dtype in (() if a.dbg else (torch.bfloat16, torch.float16)):
+    for dtype in (() if (a.dbg or a.tile_major) else (torch.bfloat16, torch.float16)):
         for (M, N, K) in [(256, 256, 128), (512, 512, 256), (1000, 1024, 1024), (300, 256, 4096), (77, 256, 1024), (18432, 2048, 4096)]:
             A, W, bias = rand((M, K), dtype, 1), rand((N, K), dtype, 2, K ** -0.5), rand((N,), torch.float32, 3)
             for odt in (torch.float16, torch.bfloat16):
@@ -94,7 +98,7 @@ def main():
               ("mlp0", 36864, 4096, 1024, torch.float16, torch.float16, G), ("k1024", 147456, 1024, 1024, torch.float16, torch.float16, 0),
               ("probe_k4096", 36864, 4096, 4096, torch.float16, torch.float16, 0), ("probe_k1024", 36864, 4096, 1024, torch.float16, torch.float16, 0)]
     res = {"mismatches": bad, "dbg": a.dbg}
-    if a.dbg:
+    if a.dbg or a.tile_major:
         shapes = shapes[-2:]
     if a.vendor:
         arms = dict(arms)
