@@ -199,8 +199,10 @@ gemm4_kernel(const GemmArgs p, const int tiles_m, const int tiles_n) {
         constexpr int q = idx & 7;
         char* dst = smem + buf * G4_BUF + (is_a ? 0 : G4_HALF) + (wave * 8 + q) * 1024;
         constexpr int KSTEP_A = FETCH == 4 ? 256 * ROW_BYTES : ROW_BYTES, KSTEP_W = (FETCH == 4 || FETCH == 5) ? 256 * ROW_BYTES : ROW_BYTES;
-        if constexpr (is_a) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)dst, 16, voff_a[q], kt * KSTEP_A, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void*)dst, 16, voff_w[q], kt * KSTEP_W, 0, 0);
+        // FETCH 6 / 7 (round 6): the cache-policy bits of the LDS-DMA loads — 6: nt (streaming, no allocation in the vector cache), 7: sc0
+        constexpr int AUX = FETCH == 6 ? 2 : FETCH == 7 ? 1 : 0;
+        if constexpr (is_a) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)dst, 16, voff_a[q], kt * KSTEP_A, 0, AUX);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void*)dst, 16, voff_w[q], kt * KSTEP_W, 0, AUX);
     };
     auto issue_ktile = [&](const int buf, const int kt) __attribute__((always_inline)) {
         issue_piece(std::integral_constant<int, 0>{}, buf, kt); issue_piece(std::integral_constant<int, 1>{}, buf, kt);
@@ -477,9 +479,10 @@ static int launch4_cfg(const GemmArgs& a, hipStream_t stream) {
         // The spread schedule's 128-slot static_for is slow to compile, so its instantiations are a second object of this file
         // (-DTP_G4_PART=1, built in parallel: gemm4_launch_spread) and exist where tools/solo_ab.py uses them: contiguous A, half-precision
         // outputs; the SIMD-parity stagger (FETCH 3: measured, slower) only with -DTP_G4_STAGGER.
-        if (g4_fetch_mode == 4 || g4_fetch_mode == 5) {
+        if (g4_fetch_mode >= 4 && g4_fetch_mode <= 7) {
             if constexpr (AMODE == 0 && DBG == 0 && std::is_same<TI, f16_t>::value && std::is_same<TO, f16_t>::value)
-                return g4_fetch_mode == 4 ? launch4_cfg<TI, TO, AMODE, 0, 4>(a, stream) : launch4_cfg<TI, TO, AMODE, 0, 5>(a, stream);
+                return g4_fetch_mode == 4 ? launch4_cfg<TI, TO, AMODE, 0, 4>(a, stream) : g4_fetch_mode == 5 ? launch4_cfg<TI, TO, AMODE, 0, 5>(a, stream)
+                     : g4_fetch_mode == 6 ? launch4_cfg<TI, TO, AMODE, 0, 6>(a, stream) : launch4_cfg<TI, TO, AMODE, 0, 7>(a, stream);
             else { set_error("tp gemm4: the tile-major timing probes are built for contiguous fp16 -> fp16 launches"); return TP_ERR_INVALID_ARG; }
         }
         switch (g4_fetch_mode) {

@@ -67,6 +67,8 @@ def main():
     if a.tile_major:                        # timing probes (garbage results): the addresses of a tile-major operand layout
         arms["solo_tile_major"] = lambda args: lib.tp_exp_gemm4(ctypes.byref(args), stream, 4)
         arms["solo_tile_major_w"] = lambda args: lib.tp_exp_gemm4(ctypes.byref(args), stream, 5)
+        arms["solo_tile_major_dma_nt"] = lambda args: lib.tp_exp_gemm4(ctypes.byref(args), stream, 6)     # (row-major; the DMA loads non-temporal — valid results)
+        arms["solo_tile_major_dma_sc0"] = lambda args: lib.tp_exp_gemm4(ctypes.byref(args), stream, 7)    # (row-major; sc0)
     if a.arms:
         arms = {k: v for k, v in arms.items() if k == "pingpong" or k in a.arms.split(",") or k.startswith("solo_tile_major")}
 
